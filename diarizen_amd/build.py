@@ -1,0 +1,70 @@
+"""Build libdzn_hip.so (gfx950) in-tree with hipcc.
+
+    python -m diarizen_amd.build            # incremental
+    python -m diarizen_amd.build --force
+
+hipcc cross-compiles for gfx950 without a GPU.  The shared object is written to
+diarizen_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).  The library only
+depends on the HIP runtime (libamdhip64): inside a PyTorch-ROCm process the already loaded
+runtime of torch is reused, so device pointers / streams are shared with torch tensors.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+CSRC = ROOT / "csrc"
+OBJ = ROOT / "build"
+LIBDIR = ROOT / "lib"
+LIB = LIBDIR / "libdzn_hip.so"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result",
+         "-ffp-contract=off"]
+
+
+def _headers_mtime() -> float:
+    hs = list(CSRC.glob("*.h")) + list((ROOT.parent / "include").glob("*.h"))
+    return max(h.stat().st_mtime for h in hs)
+
+
+def _compile(src: Path, force: bool, hdr_mtime: float) -> Path:
+    obj = OBJ / (src.name + ".o")
+    if (not force and obj.exists() and obj.stat().st_mtime > src.stat().st_mtime
+            and obj.stat().st_mtime > hdr_mtime):
+        return obj
+    cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr[-4000:]}")
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    OBJ.mkdir(exist_ok=True)
+    LIBDIR.mkdir(exist_ok=True)
+    srcs = sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp")))
+    if not srcs:
+        raise RuntimeError("no sources under csrc/")
+    hdr = _headers_mtime()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, hdr), srcs))
+    newest = max(o.stat().st_mtime for o in objs)
+    if force or not LIB.exists() or LIB.stat().st_mtime < newest:
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB),
+               *map(str, objs)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"linked {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose=True)
+    print(p)

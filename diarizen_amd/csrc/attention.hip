@@ -1,0 +1,288 @@
+// attention.hip — fused multi-head self-attention for the WavLM encoder (with the gated
+// relative-position bias) and the Conformer head (no bias), on fp32 MFMA (gfx950).
+//
+// Reference arithmetic (W2V/components.py:453-486 SelfAttention.forward, :690-725
+// WavLMSelfAttention.forward; diarizen/models/module/conformer.py:47-71):
+//     S = (q * d^-0.5) k^T + gate[q] * P[head][key - query]   ;  A = softmax(S) ;  o = A v
+// The reference materialises P as [B*H, L, L] and S as [B, h, L, L]; here the bias is a
+// per-head Toeplitz table of 2L-1 floats held in LDS, S never leaves registers
+// (flash-style online softmax) and only kept heads are computed.
+//
+// Work split: grid (ceil(L/64), kept heads, B); 4 wavefronts x 16 query rows.  The
+// score block is computed TRANSPOSED (S^T = K Q^T) so that every lane owns one query
+// column: row max / sum are in-lane reductions plus two cross-lane-group shuffles, and
+// the C-layout of S^T is exactly the A-operand layout of P for the P.V MFMA (k index
+// = lane group * 4 + step on both operands), so P never round-trips through LDS.
+// Output columns of P.V are permuted (lane lr owns dd = 4 lr + block) so each V operand
+// fetch is one ds_read_b128 and the final store is a contiguous float4 per lane.
+#include "common.h"
+
+namespace {
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv,
+                                                   float* __restrict__ out,
+                                                   const float* __restrict__ gate,
+                                                   const float* __restrict__ table,
+                                                   const int32_t* __restrict__ head_idx, int B,
+                                                   int L, int h, int Htot, int ldqkv, int ldo,
+                                                   float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  float* sK = smem_f;            // [64 keys][64 d], 16-B slot XOR (key & 15)
+  float* sV = smem_f + 64 * 64;  // [64 keys][64 d], linear
+  float* sT = smem_f + 2 * 64 * 64;  // [2L-1] bias table of this head
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int qt = blockIdx.x, j = blockIdx.y, b = blockIdx.z;
+  const int64_t rowbase = (int64_t)b * L;
+  const float* Qp = qkv + j * 64;
+  const float* Kp = qkv + (h + j) * 64;
+  const float* Vp = qkv + (2 * h + j) * 64;
+
+  int H = 0;
+  if constexpr (BIAS) {
+    H = head_idx[j];
+    for (int i = tid; i < 2 * L - 1; i += 256) sT[i] = table[(int64_t)H * (2 * L - 1) + i];
+  }
+
+  // ---- Q fragment (B operand of S^T = K Q^T): lane owns query row q_row ----
+  const int q_row = qt * 64 + wave * 16 + lr;
+  const bool q_ok = q_row < L;
+  f32x4 qf[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    if (q_ok) {
+      const float4 v =
+          *reinterpret_cast<const float4*>(Qp + (rowbase + q_row) * ldqkv + db * 16 + lq * 4);
+      qf[db] = (f32x4){v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+    } else {
+      qf[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float g = 0.f;
+  if constexpr (BIAS) {
+    if (q_ok) g = gate[(rowbase + q_row) * Htot + H];
+  }
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 O[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) O[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (L + 63) / 64;
+  float4 rk[4], rv[4];
+  auto prefetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 4, slot = idx & 15;
+      const int key = kt * 64 + row;
+      if (key < L) {
+        rk[i] = *reinterpret_cast<const float4*>(Kp + (rowbase + key) * ldqkv + slot * 4);
+        rv[i] = *reinterpret_cast<const float4*>(Vp + (rowbase + key) * ldqkv + slot * 4);
+      } else {
+        rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  prefetch(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 4, slot = idx & 15;
+      *reinterpret_cast<float4*>(sK + row * 64 + ((slot ^ (row & 15)) << 2)) = rk[i];
+      *reinterpret_cast<float4*>(sV + row * 64 + (slot << 2)) = rv[i];
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) prefetch(kt + 1);
+
+    // ---- S^T = K Q^T : 4 key blocks x (4 d blocks x 4 steps) ----
+    f32x4 s[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(
+            sK + (kb * 16 + lr) * 64 + (((db * 4 + lq) ^ lr) << 2));
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          s[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[st], qf[db][st], s[kb], 0, 0, 0);
+      }
+    }
+
+    // ---- bias, mask, online softmax (lane owns query q_row; keys kb*16 + lq*4 + rg) ----
+    const int key0 = kt * 64;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int key = key0 + kb * 16 + lq * 4 + rg;
+        float v = s[kb][rg];
+        if constexpr (BIAS) {
+          if (q_ok && key < L) v += g * sT[key - q_row + L - 1];
+        }
+        if (key >= L) v = -INFINITY;
+        s[kb][rg] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float p = expf(s[kb][rg] - m_new);
+        s[kb][rg] = p;
+        psum += p;
+      }
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+
+    // O rows are query (lq*4 + rg): fetch that query's alpha from lane (lq*4 + rg)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float a = __shfl(alpha, lq * 4 + rg, 64);
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) O[dblk][rg] *= a;
+    }
+
+    // ---- O += P V ----
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const f32x4 vf =
+            *reinterpret_cast<const f32x4*>(sV + (kb * 16 + lq * 4 + st) * 64 + (lr << 2));
+#pragma unroll
+        for (int dblk = 0; dblk < 4; ++dblk)
+          O[dblk] = __builtin_amdgcn_mfma_f32_16x16x4f32(s[kb][st], vf[dblk], O[dblk], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds O[q = lq*4+rg][dd = lr*4 + dblk] ----
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const float lt = __shfl(l_tot, lq * 4 + rg, 64);
+    const int q = qt * 64 + wave * 16 + lq * 4 + rg;
+    if (q < L) {
+      const float inv = 1.0f / lt;
+      float4 o = make_float4(O[0][rg] * inv, O[1][rg] * inv, O[2][rg] * inv, O[3][rg] * inv);
+      *reinterpret_cast<float4*>(out + (rowbase + q) * ldo + j * 64 + lr * 4) = o;
+    }
+  }
+}
+
+// gate_a_1[row, H] of the gated relative position bias, W2V/components.py:702-710:
+//   t = Linear(64->8)(y[row, H*64:(H+1)*64]) ; (a, b) = sigmoid(sum t[0:4]), sigmoid(sum t[4:8])
+//   gate = a * (b * const[H] - 1) + 2
+// One wavefront per row; lane (H = lane/4, sub = lane%4) computes outputs 2*sub, 2*sub+1.
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ y, int64_t ldy,
+                                                   const float* __restrict__ Wg,  // [8,64]
+                                                   const float* __restrict__ bg,  // [8]
+                                                   const float* __restrict__ cst,  // [Htot]
+                                                   float* __restrict__ gate, int64_t rows,
+                                                   int Htot) {
+  __shared__ float sW[8 * 64 + 8];
+  for (int i = threadIdx.x; i < 8 * 64; i += 256) sW[i] = Wg[i];
+  if (threadIdx.x < 8) sW[512 + threadIdx.x] = bg[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int sub = lane & 3;
+  for (int H0 = 0; H0 < Htot; H0 += 16) {
+    const int H = H0 + (lane >> 2);
+    float t0 = 0.f, t1 = 0.f;
+    if (H < Htot) {
+      const float* yp = y + row * ldy + H * 64;
+      const float* w0 = sW + (2 * sub) * 64;
+      const float* w1 = w0 + 64;
+#pragma unroll 8
+      for (int d = 0; d < 64; ++d) {
+        const float v = yp[d];
+        t0 = fmaf(v, w0[d], t0);
+        t1 = fmaf(v, w1[d], t1);
+      }
+      t0 += sW[512 + 2 * sub];
+      t1 += sW[512 + 2 * sub + 1];
+    }
+    // outputs 0..3 live in sub 0,1 ; outputs 4..7 in sub 2,3  (sum in the reference's order)
+    float pair = t0 + t1;
+    float other = __shfl_xor(pair, 1, 64);
+    float sum4 = (sub & 1) ? (other + pair) : (pair + other);
+    // lane sub==0 -> sum of t[0..3]; sub==2 -> sum of t[4..7]
+    const float sa = __shfl(sum4, (lane & ~3), 64);
+    const float sb = __shfl(sum4, (lane & ~3) + 2, 64);
+    if (H < Htot && sub == 0) {
+      const float ga = 1.0f / (1.0f + expf(-sa));
+      const float gb = 1.0f / (1.0f + expf(-sb));
+      gate[row * Htot + H] = ga * (gb * cst[H] - 1.0f) + 2.0f;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_attention(const float* qkv, float* out, const float* gate, const float* table,
+                     const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
+                     float scale, int precision, hipStream_t s) {
+  (void)precision;
+  if (h <= 0 || B <= 0 || L <= 0) return DZN_OK;
+  const bool bias = gate && table && head_idx;
+  const size_t lds = (2 * 64 * 64 + (bias ? (2 * L - 1) : 0)) * sizeof(float);
+  if (lds > 160 * 1024) return DZN_E_INVALID;
+  dim3 grid((L + 63) / 64, h, B);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (bias)
+    hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), lds, s, qkv, out, gate, table,
+                       head_idx, B, L, h, Htot, ldqkv, ldo, scale);
+  else
+    hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), lds, s, qkv, out, gate, table,
+                       head_idx, B, L, h, Htot, ldqkv, ldo, scale);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_gate(const float* y, int64_t ldy, const float* Wg, const float* bg, const float* cst,
+                float* gate, int64_t rows, int Htot, hipStream_t s) {
+  if (rows <= 0) return DZN_OK;
+  hipLaunchKernelGGL(gate_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, y, ldy, Wg, bg,
+                     cst, gate, rows, Htot);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+extern "C" int dzn_op_attention(const float* qkv, float* out, const float* gate,
+                                const float* table, const int32_t* head_idx, int32_t B, int32_t L,
+                                int32_t h, int32_t Htot, int32_t ldqkv, int32_t ldo, float scale,
+                                int32_t precision, void* stream) {
+  if (!qkv || !out) return DZN_E_INVALID;
+  return launch_attention(qkv, out, gate, table, head_idx, B, L, h, Htot, ldqkv, ldo, scale,
+                          precision, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dzn_op_gate(const float* y, int64_t ldy, const float* Wg, const float* bg,
+                           const float* cst, float* gate, int64_t rows, int32_t Htot,
+                           void* stream) {
+  return launch_gate(y, ldy, Wg, bg, cst, gate, rows, Htot, reinterpret_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,286 @@
+// gemm.hip — the MFMA contraction every dense op of the hot path runs on (gfx950).
+//
+//   C[m,n] = epilogue( sum_k A(m,k) * W[n,k] )          (see include/dzn_ops.h: dzn_gemm_desc)
+//
+// Used for: conv1..6 of the WavLM feature extractor (1-D conv as a contraction over
+// overlapping channels-last rows, W2V/components.py:119-122), feature projection,
+// the grouped positional conv (two-level K addressing, components.py:366-380),
+// q/k/v/out projections, feed-forward layers (components.py:805-813), the Conformer
+// linears / pointwise convs (conformer.py:136-144, 192-214), the DFT + mel contractions
+// of kaldi fbank, all 3x3 / 1x1 convs of ResNet34 (wespeaker/resnet.py:139-144) and seg_1.
+//
+// Design (CDNA4): 256 threads = 4 wavefronts of 64; each wavefront owns a TM x TN
+// sub-tile built from 16x16 MFMA blocks.  Two arithmetic modes share one structure,
+// because both read a 16-byte K-run per lane from a 128-byte LDS row:
+//   f32 : v_mfma_f32_16x16x4_f32   (exact fp32 == fmaf chain), 32 k per tile
+//   bf16: v_mfma_f32_16x16x32_bf16 (fp32 accumulate),           64 k per tile
+// The K order inside a 16-float block is permuted (lane group q supplies k = 4q+s at
+// step s) identically for both operands, which lets every fragment be one ds_read_b128.
+// LDS rows are XOR-swizzled on the 16-B slot ((row>>1)&7) so that the four 16-lane
+// groups of ds_read_b128 hit 16 distinct slots (conflict free) and the ds_write_b128
+// of the staging pass stays conflict free too.  Global->register->LDS double buffering
+// with one barrier per K tile; workgroup ids are remapped so each XCD (private L2)
+// walks a contiguous run of tiles.
+#include "common.h"
+
+namespace {
+
+template <bool LOWP>
+struct Frag {
+  using type = f32x4;
+};
+template <>
+struct Frag<true> {
+  using type = bf16x8;
+};
+
+__device__ __forceinline__ uint4 pack_bf16x8(const float4& a, const float4& b) {
+  bf16x8 v;
+  v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+  v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+  return *reinterpret_cast<uint4*>(&v);
+}
+
+template <int BM, int BN, int WGM, int WGN, bool LOWP>
+__global__ __launch_bounds__(256) void gemm_kernel(const dzn_gemm_desc d) {
+  static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
+  constexpr int BK = LOWP ? 64 : 32;   // k per tile; an LDS row is 128 B in both modes
+  constexpr int KV = LOWP ? 8 : 4;     // k per 16-B LDS chunk
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int ACH = BM / 32;         // 16-B LDS chunks per thread, A tile
+  constexpr int WCH = BN / 32;         // same, W tile
+  constexpr int BUF = (BM + BN) * 128; // bytes per LDS stage
+  using frag_t = typename Frag<LOWP>::type;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // ---- tile id, XCD-contiguous remap (bijective for any grid size) ----
+  const int tilesN = (d.N + BN - 1) / BN;
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = t / tilesN, tn = t % tilesN;
+
+  const int z = blockIdx.y;
+  const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
+  const float* __restrict__ A = d.A + z0 * d.a_z0 + z1 * d.a_z1;
+  const int64_t wz = z0 * d.w_z0 + z1 * d.w_z1;
+  const float* __restrict__ W = d.W + (LOWP ? 0 : wz);
+  const u16* __restrict__ W16 = reinterpret_cast<const u16*>(d.W16) + (LOWP ? wz : 0);
+  const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
+  const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
+
+  // ---- staging assignment: thread -> (row = tid/8 + 32 i, 16-B chunk c = tid%8) ----
+  const int c = tid & 7;
+  const int r0 = tid >> 3;
+  int64_t abase[ACH];
+  bool aval[ACH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    const int m = tm * BM + r0 + 32 * i;
+    aval[i] = m < d.M;
+    const int mm = aval[i] ? m : 0;
+    abase[i] = d.a_rowoff ? (int64_t)d.a_rowoff[mm] : (int64_t)mm * d.lda;
+  }
+  int64_t wbase[WCH];
+  bool wval[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) {
+    const int n = tn * BN + r0 + 32 * i;
+    wval[i] = n < d.N;
+    wbase[i] = (int64_t)(wval[i] ? n : 0) * d.ldw;
+  }
+
+  float4 ra[ACH][LOWP ? 2 : 1];
+  uint4 rw[WCH];
+
+  auto load_tile = [&](int k0) {
+    const int k = k0 + c * KV;
+    const bool kval = k < d.K;
+    const int ch = k / d.kc;
+    const int64_t koff = (int64_t)ch * d.ldk + (k - ch * d.kc);
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      if (aval[i] && kval) {
+        const float4* p = reinterpret_cast<const float4*>(A + abase[i] + koff);
+        ra[i][0] = p[0];
+        if constexpr (LOWP) ra[i][1] = p[1];
+      } else {
+        ra[i][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (LOWP) ra[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      if (wval[i] && kval) {
+        if constexpr (LOWP)
+          rw[i] = *reinterpret_cast<const uint4*>(W16 + wbase[i] + k);
+        else
+          rw[i] = *reinterpret_cast<const uint4*>(W + wbase[i] + k);
+      } else {
+        rw[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    unsigned char* sA = smem + buf * BUF;
+    unsigned char* sW = sA + BM * 128;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      const int r = r0 + 32 * i;
+      const int off = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+      if constexpr (LOWP)
+        *reinterpret_cast<uint4*>(sA + off) = pack_bf16x8(ra[i][0], ra[i][1]);
+      else
+        *reinterpret_cast<float4*>(sA + off) = ra[i][0];
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int r = r0 + 32 * i;
+      const int off = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+      *reinterpret_cast<uint4*>(sW + off) = rw[i];
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 15;  // row inside a 16x16 block
+  const int lq = lane >> 4;  // lane group -> 16-B slot inside a 64-B K block
+
+  auto compute = [&](int buf) {
+    const unsigned char* sA = smem + buf * BUF;
+    const unsigned char* sW = sA + BM * 128;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      frag_t af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * TM + i * 16 + lr;
+        const int slot = (kb * 4 + lq) ^ ((row >> 1) & 7);
+        af[i] = *reinterpret_cast<const frag_t*>(sA + row * 128 + (slot << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = wn * TN + j * 16 + lr;
+        const int slot = (kb * 4 + lq) ^ ((row >> 1) & 7);
+        bf[j] = *reinterpret_cast<const frag_t*>(sW + row * 128 + (slot << 4));
+      }
+      if constexpr (LOWP) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- main loop: register-staged double buffer, one barrier per K tile ----
+  const int nk = (d.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_tile((kt + 1) * BK);
+    compute(kt & 1);
+    if (more) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int m = tm * BM + wm * TM + i * 16 + lq * 4 + rg;
+      if (m >= d.M) continue;
+      const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = tn * BN + wn * TN + j * 16 + lr;
+        if (n >= d.N) continue;
+        float v = acc[i][j][rg];
+        if (bias) v += bias[n];
+        v = apply_act(v, d.act) * d.alpha;
+        if (d.R) v += d.R[crow + n];
+        if (d.post_relu) v = fmaxf(v, 0.f);
+        d.C[crow + n] = v;
+        if (d.WS) {
+          float* w = d.WS + (int64_t)m * d.ldws + n;
+          *w = d.ws_init ? d.ws_w * v : (*w + d.ws_w * v);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool LOWP>
+int launch_cfg(const dzn_gemm_desc& d, hipStream_t s) {
+  const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+  const size_t lds = 2 * (BM + BN) * 128;
+  auto kern = gemm_kernel<BM, BN, WGM, WGN, LOWP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(tilesM * tilesN, d.nz > 0 ? d.nz : 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+template <bool LOWP>
+int launch_prec(const dzn_gemm_desc& d, hipStream_t s) {
+  if (d.N <= 32) return launch_cfg<256, 32, 4, 1, LOWP>(d, s);
+  if (d.N <= 64) return launch_cfg<128, 64, 2, 2, LOWP>(d, s);
+  return launch_cfg<128, 128, 2, 2, LOWP>(d, s);
+}
+
+}  // namespace
+
+int launch_gemm(const dzn_gemm_desc& din, hipStream_t s) {
+  dzn_gemm_desc d = din;
+  if (d.M <= 0 || d.N <= 0) return DZN_OK;
+  if (d.K <= 0 || (d.K & 7)) return DZN_E_INVALID;
+  if (d.kc <= 0) { d.kc = d.K; d.ldk = 0; }
+  if (d.kc & 7) return DZN_E_INVALID;
+  if (d.zdiv <= 0) d.zdiv = 1;
+  if (d.nz <= 0) d.nz = 1;
+  if (d.alpha == 0.f) d.alpha = 1.f;
+  if (d.precision == DZN_PREC_BF16) {
+    if (!d.W16) return DZN_E_INVALID;
+    return launch_prec<true>(d, s);
+  }
+  if (!d.W) return DZN_E_INVALID;
+  return launch_prec<false>(d, s);
+}
+
+extern "C" int dzn_op_gemm(const dzn_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->C) return DZN_E_INVALID;
+  return launch_gemm(*d, reinterpret_cast<hipStream_t>(stream));
+}

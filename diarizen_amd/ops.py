@@ -1,0 +1,93 @@
+"""Thin torch-tensor wrappers over the kernel-level C ABI (include/dzn_ops.h).
+
+Only used by tests/ and bench.py to exercise single kernels; the engine itself
+orchestrates the same launchers in C++.  Tensors must live on the HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import DznGemmDesc, check
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None, ws_w=0.0,
+         ws_init=False, a_rowoff=None, c_rowoff=None, lda=None, kc=0, ldk=0, ldw=None, ldc=None,
+         ldws=0, act=0, alpha=1.0, post_relu=False, nz=1, zdiv=1, zs=None, precision=0,
+         W16=None):
+    """C = epilogue(A @ W^T); see dzn_gemm_desc.  A: [M, K] (or raw buffer with lda / rowoff),
+    W: [N, K] fp32 (and optionally W16 bf16)."""
+    lib = _lib.load()
+    assert A.is_cuda and A.dtype == torch.float32
+    if N is None:
+        N = W.shape[0]
+    if K is None:
+        K = W.shape[1]
+    if M is None:
+        M = A.shape[0]
+    if lda is None:
+        lda = A.stride(0) if A.dim() == 2 else K
+    if ldw is None:
+        ldw = W.stride(0) if W is not None else W16.stride(0)
+    if C_out is None:
+        C_out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    if ldc is None:
+        ldc = C_out.stride(0) if C_out.dim() == 2 else N
+    d = DznGemmDesc()
+    d.A, d.W, d.W16, d.C = _p(A), _p(W), _p(W16), _p(C_out)
+    d.bias, d.R, d.WS = _p(bias), _p(R), _p(WS)
+    d.a_rowoff, d.c_rowoff = _p(a_rowoff), _p(c_rowoff)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.kc, d.ldk, d.ldw, d.ldc, d.ldws = lda, kc, ldk, ldw, ldc, ldws
+    d.act, d.alpha, d.post_relu = act, alpha, int(post_relu)
+    d.ws_w, d.ws_init = ws_w, int(ws_init)
+    d.nz, d.zdiv = nz, zdiv
+    if zs:
+        for k, v in zs.items():
+            setattr(d, k, v)
+    d.precision = precision
+    check(lib.dzn_op_gemm(C.byref(d), _stream()), what="dzn_op_gemm")
+    return C_out
+
+
+def layernorm(x, gamma, beta, C_true=None, eps=1e-5, gelu=False, out=None):
+    lib = _lib.load()
+    rows, ld = x.shape[0], x.stride(0)
+    Cpad = x.shape[1]
+    if C_true is None:
+        C_true = Cpad
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.dzn_op_layernorm(_p(x), ld, _p(out), out.stride(0), _p(gamma), _p(beta), rows,
+                               C_true, Cpad, eps, int(gelu), _stream()), what="dzn_op_layernorm")
+    return out
+
+
+def gate(y, Wg, bg, cst):
+    lib = _lib.load()
+    rows = y.shape[0]
+    Htot = cst.numel()
+    out = torch.empty((rows, Htot), device=y.device, dtype=torch.float32)
+    check(lib.dzn_op_gate(_p(y), y.stride(0), _p(Wg), _p(bg), _p(cst), _p(out), rows, Htot,
+                          _stream()), what="dzn_op_gate")
+    return out
+
+
+def attention(qkv, B, L, h, *, gate=None, table=None, head_idx=None, Htot=0, scale=0.125,
+              precision=0):
+    lib = _lib.load()
+    out = torch.empty((B * L, h * 64), device=qkv.device, dtype=torch.float32)
+    check(lib.dzn_op_attention(_p(qkv), _p(out), _p(gate), _p(table), _p(head_idx), B, L, h,
+                               Htot, qkv.stride(0), out.stride(0), scale, precision, _stream()),
+          what="dzn_op_attention")
+    return out

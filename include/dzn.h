@@ -1,0 +1,170 @@
+/*
+ * dzn.h — C ABI of libdzn_hip.so, the MI355X (gfx950) engine for the DiariZen
+ * sliding-window inference hot path.
+ *
+ * Plain C, no torch types: every buffer is a raw pointer + sizes.  The caller owns
+ * all I/O buffers (for PyTorch-ROCm these are tensor.data_ptr()); the library owns
+ * weights and workspace.  All entry points return 0 on success or a negative
+ * DZN_E_* code; the message is available through dzn_last_error().  Nothing throws
+ * across the boundary.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * BUTSpeechFIT/DiariZen tree, PA/ = pyannote-audio/pyannote/audio/):
+ *
+ *   dzn_create + dzn_load_tensor + dzn_finalize_weights
+ *       <- PA/core/model.py:360-369   instantiate(config["model"]["path"], args) ;
+ *                                      model.load_state_dict(torch.load(ckpt))
+ *          diarizen/models/eend/model_wavlm_conformer.py:26-76 (Model.__init__)
+ *          PA/models/embedding/wespeaker/__init__.py:207-233 (WeSpeakerResNet34)
+ *   dzn_segment_forward
+ *       <- PA/core/inference.py:215       self.model(chunks.to(device))
+ *          diarizen/models/eend/model_wavlm_conformer.py:238-264 (Model.forward)
+ *          PA/core/inference.py:226 + PA/utils/powerset.py:103-128
+ *                                      (Powerset.to_multilabel, soft=False)
+ *   dzn_embed_forward
+ *       <- PA/pipelines/speaker_verification.py:693-705 (embedding __call__)
+ *          PA/models/embedding/wespeaker/__init__.py:190-204 (fbank -> resnet)
+ *          PA/models/embedding/wespeaker/resnet.py:344-376 ; PA/models/blocks/pooling.py:44-131
+ *   dzn_destroy            <- python object lifetime
+ *
+ * Threading: one handle per device; calls on one handle are not re-entrant.  Calls
+ * only ENQUEUE work on the given HIP stream; the caller synchronises (matching the
+ * reference's single-threaded, one-stream use).
+ */
+#ifndef DZN_H_
+#define DZN_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DZN_MAX_CONV 8
+#define DZN_MAX_LAYERS 32
+#define DZN_MAX_HEADS 16
+
+#define DZN_OK 0
+#define DZN_E_INVALID (-1)   /* bad argument / shape / config                  */
+#define DZN_E_NOMEM (-2)     /* device or host allocation failed (-> MemoryError, PA/core/inference.py:216-221) */
+#define DZN_E_HIP (-3)       /* HIP runtime error                              */
+#define DZN_E_STATE (-4)     /* call order violated (e.g. forward before finalize) */
+#define DZN_E_MISSING (-5)   /* a required state_dict key was never loaded     */
+
+/* element types accepted by dzn_load_tensor */
+#define DZN_F32 0
+#define DZN_F64 1
+#define DZN_I64 2
+
+/* arithmetic of the MFMA contractions */
+#define DZN_PREC_F32 0   /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 everywhere          */
+#define DZN_PREC_BF16 1  /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream / norms */
+
+/*
+ * Architecture description.  Mirrors the kwargs of
+ * diarizen/models/module/wav2vec2/model.py:779-913 (wavlm_model) as listed in
+ * diarizen/models/module/wavlm_config.py, plus Model.__init__ of
+ * diarizen/models/eend/model_wavlm_conformer.py:26-45.
+ */
+typedef struct dzn_config {
+  int32_t struct_size;         /* sizeof(dzn_config), ABI check */
+  int32_t precision;           /* DZN_PREC_* */
+  int32_t max_batch;           /* largest B passed to *_forward */
+  int32_t max_samples;         /* largest N (samples per window) */
+
+  /* ---- WavLM frontend ---- */
+  int32_t extractor_layer_norm;   /* 1: extractor_mode="layer_norm" (large), 0: "group_norm" (base) */
+  int32_t normalize_waveform;     /* W2V/model.py:113 */
+  int32_t n_conv;
+  int32_t conv_ch[DZN_MAX_CONV];
+  int32_t conv_k[DZN_MAX_CONV];
+  int32_t conv_s[DZN_MAX_CONV];
+
+  /* ---- WavLM encoder ---- */
+  int32_t embed_dim;
+  int32_t total_heads;
+  int32_t n_layers;
+  int32_t layer_norm_first;       /* encoder_layer_norm_first */
+  int32_t pos_conv_kernel;
+  int32_t pos_conv_groups;
+  int32_t num_buckets;
+  int32_t max_distance;
+  int32_t use_attention[DZN_MAX_LAYERS];
+  int32_t n_heads[DZN_MAX_LAYERS];                       /* len(remaining_heads[i]) */
+  int32_t head_idx[DZN_MAX_LAYERS][DZN_MAX_HEADS];       /* remaining_heads[i][j]   */
+  int32_t use_ffn[DZN_MAX_LAYERS];
+  int32_t ffn_dim[DZN_MAX_LAYERS];
+
+  /* ---- EEND Conformer head ---- */
+  int32_t attention_in;           /* 256 */
+  int32_t ffn_hidden;             /* 1024 */
+  int32_t conf_heads;             /* 4 */
+  int32_t conf_layers;            /* 4 */
+  int32_t conf_kernel;            /* 31 */
+  int32_t n_classes;              /* 11 powerset classes */
+  int32_t max_speakers_per_chunk; /* 4 */
+  int32_t max_speakers_per_frame; /* 2 */
+
+  /* ---- WeSpeaker ResNet34 embedding ---- */
+  int32_t has_embedding;          /* 0: segmentation only */
+  int32_t embed_out_dim;          /* 256 */
+  int32_t num_mel_bins;           /* 80 */
+  int32_t reserved[16];
+} dzn_config;
+
+typedef struct dzn_handle dzn_handle;
+
+/* Create an engine on the current HIP device. */
+int dzn_create(const dzn_config* cfg, dzn_handle** out);
+
+/*
+ * Hand one state_dict entry to the engine (host memory, copied before return).
+ * Keys are the reference's own:  segmentation keys as saved from Model
+ * ("wavlm_model.feature_extractor.conv_layers.0.conv.weight", ..., "classifier.bias"),
+ * embedding keys prefixed "embedding." + the WeSpeakerResNet34 key
+ * ("embedding.resnet.conv1.weight", ...).  Unknown keys are ignored
+ * (load_state_dict(strict=False) semantics) but counted; see dzn_num_ignored().
+ */
+int dzn_load_tensor(dzn_handle* h, const char* key, const void* host_ptr,
+                    const int64_t* shape, int32_t ndim, int32_t dtype);
+
+/* Fold weight-norm / BatchNorm / dummy_weight, pack + pad for MFMA tiles, upload,
+ * allocate workspace for (max_batch, max_samples). */
+int dzn_finalize_weights(dzn_handle* h);
+
+/* number of frames L for N samples (model_wavlm_conformer.py:98-124) */
+int dzn_num_frames(const dzn_handle* h, int32_t num_samples);
+
+/*
+ * Segmentation forward.  d_wave: device f32 [B, N] (channel already selected,
+ * inference.py:128 / model_wavlm_conformer.py:250).  Outputs (device, either may
+ * be NULL): d_logp f32 [B, L, n_classes] log-probabilities; d_multilabel u8
+ * [B, L, max_speakers_per_chunk] hard multilabel decisions.
+ */
+int dzn_segment_forward(dzn_handle* h, const float* d_wave, int32_t B, int32_t N,
+                        float* d_logp, uint8_t* d_multilabel, void* hip_stream);
+
+/*
+ * Embedding forward with the ResNet trunk shared by the S masks of a window.
+ * d_wave f32 [B, N]; d_masks f32 [B, S, L]; d_emb f32 [B, S, embed_out_dim].
+ */
+int dzn_embed_forward(dzn_handle* h, const float* d_wave, const float* d_masks,
+                      int32_t B, int32_t S, int32_t N, int32_t L, float* d_emb,
+                      void* hip_stream);
+
+/* Copy a named intermediate activation of the LAST forward to host (debug / parity
+ * tests).  *n_elems receives the element count; host_out may be NULL to query. */
+int dzn_debug_fetch(dzn_handle* h, const char* name, float* host_out, int64_t cap,
+                    int64_t* n_elems);
+
+int dzn_num_ignored(const dzn_handle* h);
+int64_t dzn_workspace_bytes(const dzn_handle* h);
+const char* dzn_last_error(const dzn_handle* h); /* h may be NULL: last create error */
+int dzn_destroy(dzn_handle* h);
+const char* dzn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DZN_H_ */

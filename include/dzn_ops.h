@@ -1,0 +1,101 @@
+/*
+ * dzn_ops.h — kernel-level entry points of libdzn_hip.so.
+ *
+ * These expose the individual gfx950 kernels the engine is built from, on raw device
+ * pointers, so that tests/ can check each kernel against a plain fp32 reference of the
+ * same op (torch on the host side) and bench.py can time a kernel in isolation.  They
+ * are not part of the drop-in surface (that is dzn.h); they have no reference-side
+ * counterpart other than the torch op named in each comment.
+ *
+ * All functions enqueue on `stream` and return 0 / negative DZN_E_* (see dzn.h).
+ */
+#ifndef DZN_OPS_H_
+#define DZN_OPS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activations applied to (acc + bias) */
+#define DZN_ACT_NONE 0
+#define DZN_ACT_GELU 1  /* exact erf GELU, torch.nn.functional.gelu */
+#define DZN_ACT_SWISH 2 /* x * sigmoid(x) */
+#define DZN_ACT_RELU 3
+
+/*
+ * Generic MFMA contraction  C[m,n] = epilogue( sum_k A(m,k) * W[n,k] ).
+ *
+ *   A(m,k)   = A[ zA + rowbase(m) + (k / kc) * ldk + (k % kc) ]
+ *   rowbase  = a_rowoff ? a_rowoff[m] : m * lda            (element offsets)
+ *   W[n,k]   = W[ zW + n * ldw + k ]                        (torch Linear / packed conv layout)
+ *   v        = act(acc + bias[zB + n]) * alpha
+ *   v       += R[ zC + crow(m) + n ]        if R            crow = c_rowoff ? c_rowoff[m] : m*ldc
+ *   v        = max(v, 0)                    if post_relu
+ *   C[ zC + crow(m) + n ] = v
+ *   WS[ m*ldws + n ] (+)= ws_w * v          if WS   ('=' when ws_init)
+ *
+ * The two-level K addressing (kc, ldk) turns 1-D / 2-D convolutions over channels-last
+ * activations into this same contraction without an im2col copy.  grid.z batches:
+ * z -> (z0 = z / zdiv, z1 = z % zdiv), zA = z0*a_z0 + z1*a_z1 etc.
+ * Requirements: K % 32 == 0, kc % 32 == 0, all strides/offsets multiples of 4 elements.
+ */
+typedef struct dzn_gemm_desc {
+  const float* A;
+  const float* W;        /* fp32 weights (precision f32) */
+  const void* W16;       /* bf16 weights, same layout (precision bf16); may be NULL */
+  float* C;
+  const float* bias;
+  const float* R;
+  float* WS;
+  const int32_t* a_rowoff;
+  const int32_t* c_rowoff;
+  int32_t M, N, K;
+  int64_t lda;
+  int32_t kc;
+  int64_t ldk;
+  int32_t ldw;
+  int64_t ldc;
+  int64_t ldws;
+  int32_t act;
+  float alpha;
+  int32_t post_relu;
+  float ws_w;
+  int32_t ws_init;
+  int32_t nz, zdiv;
+  int64_t a_z0, a_z1, w_z0, w_z1, c_z0, c_z1, b_z0, b_z1;
+  int32_t precision;     /* DZN_PREC_* */
+} dzn_gemm_desc;
+
+int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
+
+/* y[r,:] = LayerNorm(x[r,:C]) * gamma + beta (eps), optional fused erf-GELU; row strides
+ * ldx / ldy; columns [C, Cpad) of y are written as zero.  torch F.layer_norm. */
+int dzn_op_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
+                     const float* beta, int64_t rows, int32_t C, int32_t Cpad, float eps,
+                     int32_t gelu, void* stream);
+
+/* gate_a_1[row, H] of WavLM's gated relative position bias (W2V/components.py:702-710):
+ * y f32 [rows, ldy] (attention input, Htot*64 wide), Wg [8,64], bg [8], cst [Htot]. */
+int dzn_op_gate(const float* y, int64_t ldy, const float* Wg, const float* bg, const float* cst,
+                float* gate, int64_t rows, int32_t Htot, void* stream);
+
+/*
+ * Fused multi-head attention with optional WavLM gated relative-position bias
+ * (W2V/components.py:453-486, 690-725; conformer.py:47-71).
+ *   qkv   f32 [B*L, ldqkv]: q at col 0, k at col h*64, v at col 2*h*64 (head-major, 64 each)
+ *   out   f32 [B*L, ldo]  : head j at cols j*64..
+ *   gate  f32 [B*L, Htot] or NULL: gate_a_1 per (row, ORIGINAL head)
+ *   table f32 [Htot, 2L-1] or NULL: rel-pos bias by (key - query + L - 1)
+ *   head_idx i32 [h] device: original head index of kept head j
+ */
+int dzn_op_attention(const float* qkv, float* out, const float* gate, const float* table,
+                     const int32_t* head_idx, int32_t B, int32_t L, int32_t h,
+                     int32_t Htot, int32_t ldqkv, int32_t ldo, float scale,
+                     int32_t precision, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,33 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """Make sure libdzn_hip.so exists (cross-compiles on CPU boxes)."""
+    from diarizen_amd import _lib
+    if not _lib.lib_path().exists():
+        from diarizen_amd.build import build
+        build()
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("test marked gpu but no HIP device is visible")
+    return torch.device("cuda:0")

@@ -1,0 +1,196 @@
+"""Kernel-level parity: each gfx950 kernel vs a plain fp32/fp64 torch reference of the same op.
+
+Tolerances (fp32 mode): the MFMA f32 path is an fmaf chain, so it differs from a float64
+reference only by fp32 round-off: |err| <= 2e-5 * sqrt(K)-ish; we assert 1e-4 relative to the
+output scale.  bf16 mode: operands rounded to 8 bits of mantissa -> 2e-2 relative.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_err(a, b):
+    return (a.double() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-12)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 96), (257, 64, 64), (1000, 32, 288),
+                                   (77, 153, 1536), (513, 1770, 1024), (64, 11, 256)])
+def test_gemm_plain(built_lib, gpu, M, N, K):
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    # asymmetric, non-identity weights so a transposed C-write cannot pass
+    W = torch.randn(N, K, generator=g) * torch.linspace(0.5, 1.5, N)[:, None]
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T + bias.double()
+    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu))
+    torch.cuda.synchronize()
+    assert _rel_err(out.cpu(), ref) < 1e-5
+
+
+def test_gemm_epilogues(built_lib, gpu):
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 333, 160, 128
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    base = A.double() @ W.double().T + bias.double()
+    # gelu
+    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), act=1)
+    assert _rel_err(out.cpu(), torch.nn.functional.gelu(base)) < 1e-5
+    # swish * 0.5 + residual
+    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), act=2, alpha=0.5, R=R.to(gpu))
+    assert _rel_err(out.cpu(), R.double() + 0.5 * base * torch.sigmoid(base)) < 1e-5
+    # residual + post relu
+    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), R=R.to(gpu), post_relu=True)
+    assert _rel_err(out.cpu(), torch.relu(base + R.double())) < 1e-5
+    # weighted-sum accumulate
+    WS = torch.zeros(M, N, device=gpu)
+    ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), WS=WS, ws_w=0.3, ws_init=True, ldws=N)
+    ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), WS=WS, ws_w=-1.2, ws_init=False, ldws=N)
+    assert _rel_err(WS.cpu(), (0.3 - 1.2) * base) < 1e-5
+
+
+def test_gemm_conv1d_overlapping_rows(built_lib, gpu):
+    """conv1d(k=3, s=2) over channels-last rows == contraction with lda = s*C, K = k*C."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(5)
+    Bn, T, Ci, Co, k, s = 2, 101, 32, 48, 3, 2
+    x = torch.randn(Bn, Ci, T, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) * 0.1
+    ref = torch.nn.functional.conv1d(x.double(), w.double(), stride=s)  # [B, Co, To]
+    To = ref.shape[-1]
+    xcl = x.permute(0, 2, 1).contiguous()  # [B, T, Ci]
+    wp = w.permute(0, 2, 1).reshape(Co, k * Ci).contiguous()  # k index = j*Ci + ci
+    out = torch.empty(Bn, To, Co, device=gpu)
+    ops.gemm(xcl.to(gpu).view(-1), wp.to(gpu), M=To, N=Co, K=k * Ci, lda=s * Ci, C_out=out.view(-1),
+             ldc=Co, nz=Bn, zdiv=1, zs=dict(a_z0=T * Ci, c_z0=To * Co))
+    torch.cuda.synchronize()
+    assert _rel_err(out.cpu().permute(0, 2, 1), ref) < 1e-5
+
+
+def test_gemm_grouped_posconv_two_level_k(built_lib, gpu):
+    """grouped conv1d(k=16, groups=4, pad) via (kc, ldk) addressing and z-batching."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(6)
+    Bn, L, D, G, k = 2, 50, 128, 4, 16
+    cg = D // G
+    x = torch.randn(Bn, L, D, generator=g)
+    w = torch.randn(D, cg, k, generator=g) * 0.1
+    bias = torch.randn(D, generator=g)
+    ref = torch.nn.functional.conv1d(x.double().permute(0, 2, 1), w.double(), bias.double(),
+                                     padding=k // 2, groups=G)[..., :-1].permute(0, 2, 1)
+    Lp = L + k
+    xpad = torch.zeros(Bn, Lp, D)
+    xpad[:, k // 2:k // 2 + L] = x
+    wp = w.permute(0, 2, 1).reshape(D, k * cg).contiguous()  # [co][j*cg + ci]
+    out = torch.empty(Bn, L, D, device=gpu)
+    ops.gemm(xpad.to(gpu).view(-1), wp.to(gpu), M=L, N=cg, K=k * cg, lda=D, kc=cg, ldk=D,
+             ldw=k * cg, bias=bias.to(gpu), C_out=out.view(-1), ldc=D, nz=Bn * G, zdiv=G,
+             zs=dict(a_z0=Lp * D, a_z1=cg, w_z1=cg * k * cg, c_z0=L * D, c_z1=cg, b_z1=cg))
+    torch.cuda.synchronize()
+    assert _rel_err(out.cpu(), ref) < 1e-5
+
+
+def test_gemm_rowoff_tables(built_lib, gpu):
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(8)
+    M, N, K = 200, 64, 64
+    buf = torch.randn(4096, generator=g)
+    aoff = (torch.randperm(900, generator=g)[:M] * 4).to(torch.int32)
+    coff = (torch.randperm(M, generator=g) * N).to(torch.int32)
+    W = torch.randn(N, K, generator=g)
+    A = torch.stack([buf[o:o + K] for o in aoff.tolist()])
+    ref = A.double() @ W.double().T
+    out = torch.zeros(M * N, device=gpu)
+    ops.gemm(buf.to(gpu), W.to(gpu), M=M, N=N, K=K, lda=0, a_rowoff=aoff.to(gpu),
+             c_rowoff=coff.to(gpu), C_out=out, ldc=N)
+    got = out.cpu().view(M, N)[(coff // N).long()]
+    assert _rel_err(got, ref) < 1e-5
+
+
+def test_gemm_bf16(built_lib, gpu):
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 300, 200, 256
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    ref = A.bfloat16().double() @ W.bfloat16().double().T
+    out = ops.gemm(A.to(gpu), None, N=N, K=K, ldw=K, W16=W.bfloat16().to(gpu), precision=1)
+    torch.cuda.synchronize()
+    assert _rel_err(out.cpu(), ref) < 1e-4  # vs the same bf16-rounded operands
+    assert _rel_err(out.cpu(), A.double() @ W.double().T) < 2e-2
+
+
+@pytest.mark.parametrize("C,Cpad", [(153, 160), (1024, 1024), (256, 256), (211, 224), (512, 512)])
+def test_layernorm(built_lib, gpu, C, Cpad):
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = torch.zeros(77, Cpad)
+    x[:, :C] = torch.randn(77, C, generator=g) * 3 + 1
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = torch.nn.functional.layer_norm(x[:, :C].double(), (C,), gamma.double(), beta.double())
+    out = ops.layernorm(x.to(gpu), gamma.to(gpu), beta.to(gpu), C_true=C)
+    assert (out.cpu()[:, :C].double() - ref).abs().max() < 2e-5
+    assert (out.cpu()[:, C:] == 0).all()
+    outg = ops.layernorm(x.to(gpu), gamma.to(gpu), beta.to(gpu), C_true=C, gelu=True)
+    assert (outg.cpu()[:, :C].double() - torch.nn.functional.gelu(ref)).abs().max() < 2e-5
+
+
+def _attn_ref(q, k, v, bias=None):
+    s = (q.double() * 0.125) @ k.double().transpose(-1, -2)
+    if bias is not None:
+        s = s + bias.double()
+    return torch.softmax(s, -1) @ v.double()
+
+
+@pytest.mark.parametrize("L", [64, 99, 399])
+def test_attention_nobias(built_lib, gpu, L):
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(L)
+    B, h = 2, 4
+    qkv = torch.randn(B * L, 3 * h * 64, generator=g)
+    q, k, v = [qkv[:, i * h * 64:(i + 1) * h * 64].view(B, L, h, 64).permute(0, 2, 1, 3) for i in range(3)]
+    ref = _attn_ref(q, k, v).permute(0, 2, 1, 3).reshape(B * L, h * 64)
+    out = ops.attention(qkv.to(gpu), B, L, h)
+    assert (out.cpu().double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("L", [99, 399])
+def test_attention_gated_relpos(built_lib, gpu, L):
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(L + 1)
+    B, Htot = 2, 16
+    heads = [1, 4, 7, 12, 13]
+    h = len(heads)
+    qkv = torch.randn(B * L, 3 * h * 64, generator=g)
+    gate = torch.rand(B * L, Htot, generator=g) * 2
+    table = torch.randn(Htot, 2 * L - 1, generator=g)
+    q, k, v = [qkv[:, i * h * 64:(i + 1) * h * 64].view(B, L, h, 64).permute(0, 2, 1, 3) for i in range(3)]
+    idx = torch.arange(L)[None, :] - torch.arange(L)[:, None] + L - 1  # key - query + L - 1
+    P = table[:, idx]  # [Htot, L, L]
+    bias = gate.view(B, L, Htot).permute(0, 2, 1)[..., None] * P[None]  # [B, Htot, L, L]
+    bias = bias[:, heads]
+    ref = _attn_ref(q, k, v, bias).permute(0, 2, 1, 3).reshape(B * L, h * 64)
+    out = ops.attention(qkv.to(gpu), B, L, h, gate=gate.to(gpu), table=table.to(gpu),
+                        head_idx=torch.tensor(heads, dtype=torch.int32, device=gpu), Htot=Htot)
+    assert (out.cpu().double() - ref).abs().max() < 2e-5
+
+
+def test_gate(built_lib, gpu):
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rows, Htot = 101, 16
+    y = torch.randn(rows, Htot * 64, generator=g)
+    Wg, bg = torch.randn(8, 64, generator=g) * 0.2, torch.randn(8, generator=g)
+    cst = torch.rand(Htot, generator=g) + 0.5
+    t = (y.double().view(rows, Htot, 64) @ Wg.double().T + bg.double()).view(rows, Htot, 2, 4).sum(-1)
+    a, b = torch.sigmoid(t)[..., 0], torch.sigmoid(t)[..., 1]
+    ref = a * (b * cst.double() - 1.0) + 2.0
+    out = ops.gate(y.to(gpu), Wg.to(gpu), bg.to(gpu), cst.to(gpu))
+    assert (out.cpu().double() - ref).abs().max() < 1e-5
