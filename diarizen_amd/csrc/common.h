@@ -64,5 +64,31 @@ int launch_attention(const float* qkv, float* out, const float* gate, const floa
                      const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
                      float scale, int precision, hipStream_t s);
 
+// frontend.hip
+int launch_conv0(const float* wave, int B, int N, const float* stats, const float* w,
+                 const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
+                 int layer_norm, float eps, float* out, hipStream_t st);
+int launch_groupnorm_gelu(float* x, int B, int T, int C, int64_t ld, const float* gamma,
+                          const float* beta, float eps, float* stats, hipStream_t st);
+int launch_pad_rows(const float* x, float* xpad, int B, int L, int Lp, int pad, int D,
+                    hipStream_t st);
+int launch_ws_accum(const float* x, float* ws, float w, int init, int64_t n, hipStream_t st);
+int launch_col_scale(float* x, int64_t rows, int C, int64_t ld, const float* scale, hipStream_t st);
+// conformer.hip
+int launch_glu_dwconv(const float* u, int64_t ldu, const float* w, const float* bias, float* out,
+                      int64_t ldo, int B, int L, int A, int ks, hipStream_t st);
+int launch_classify(const float* z, int64_t ldz, const float* W, const float* bias,
+                    const uint8_t* mapping, int64_t rows, int A, int NC, int S, float* logp,
+                    uint8_t* multilabel, hipStream_t st);
+// embed.hip
+int launch_frame_prep(const float* wave, int B, int N, int T, int flen, int fshift, int Kp,
+                      const float* window, float preemph, float* frames, hipStream_t st);
+int launch_power(const float* spec, int64_t rows, int nb, float* pw, hipStream_t st);
+int launch_log_cmn(float* mel, int B, int T, int NB, float eps, hipStream_t st);
+int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* w, const float* bias,
+                     float* img, hipStream_t st);
+int launch_stats_pool(const float* img, int B, int H, int W, int C, const float* masks, int S, int L,
+                      float* stats, hipStream_t st);
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

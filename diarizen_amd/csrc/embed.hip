@@ -1,0 +1,214 @@
+// embed.hip — non-GEMM kernels of the WeSpeaker ResNet34 embedding path.
+//
+//  frame_prep_kernel : Kaldi framing of torchaudio.compliance.kaldi.fbank as called at
+//      PA/models/embedding/wespeaker/__init__.py:69-78,94-103 — x * 2^15, snip_edges frames of
+//      400 samples / shift 160, per-frame DC removal, pre-emphasis 0.97 (replicate pad),
+//      Hamming(400, periodic=False), zero pad (the 512-point transform is a contraction with a
+//      [512, Kp] cos/sin matrix on the MFMA kernel: 400 non-zero taps only).
+//  power_kernel      : |rfft|^2 for bins 0..255 (bin 256 has zero mel weight).
+//  log_cmn_kernel    : log(max(mel, eps)) and per-window mean subtraction over frames (:103).
+//  stem_conv_kernel  : ResNet conv1 3x3 (1 -> 32) + folded BN + ReLU (resnet.py:358), writes the
+//      zero-bordered NHWC image the 3x3 contractions read.
+//  stats_pool_kernel : TSTP / StatsPool weighted mean + std for ALL speaker masks of a window
+//      from one trunk pass (resnet.py:49-66, PA/models/blocks/pooling.py:44-75,107-131).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void frame_prep_kernel(const float* __restrict__ wave, int N,
+                                                         int T, int flen, int fshift, int Kp,
+                                                         const float* __restrict__ window,
+                                                         float preemph, float* __restrict__ frames) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 4 + wv;
+  if (t >= T) return;
+  const float* xp = wave + (int64_t)b * N + (int64_t)t * fshift;
+  float v[8];  // flen <= 512
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = lane + 64 * i;
+    v[i] = idx < flen ? xp[idx] * 32768.0f : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)flen;
+  float* op = frames + ((int64_t)b * T + t) * Kp;
+  // previous sample (idx-1) lives in lane-1, or in lane 63 of the previous register; x[-1] := x[0]
+  // (all cross-lane traffic happens here, in uniform control flow)
+  float pv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float prev = __shfl_up(v[i], 1, 64);
+    const float prev_reg = __shfl(v[i > 0 ? i - 1 : 0], 63, 64);
+    if (lane == 0) prev = i > 0 ? prev_reg : v[0];
+    pv[i] = prev;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < flen) {
+      const float cur = v[i] - mean;
+      const float prev = pv[i] - mean;
+      op[idx] = (cur - preemph * prev) * window[idx];
+    } else if (idx < Kp) {
+      op[idx] = 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void power_kernel(const float* __restrict__ spec, int64_t rows,
+                                                    int nb, float* __restrict__ pw) {
+  const int64_t n = rows * nb;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / nb;
+    const int f = (int)(i - r * nb);
+    const float re = spec[r * 2 * nb + f], im = spec[r * 2 * nb + nb + f];
+    const float a = sqrtf(re * re + im * im);  // torch: rfft(...).abs().pow(2.0)
+    pw[i] = a * a;
+  }
+}
+
+__global__ __launch_bounds__(256) void log_cmn_kernel(float* __restrict__ mel, int T, int NB,
+                                                      float eps) {
+  __shared__ float red[16][17];
+  const int b = blockIdx.y;
+  const int bin = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int ph = threadIdx.x >> 4;
+  float* mp = mel + (int64_t)b * T * NB;
+  float s = 0.f;
+  if (bin < NB)
+    for (int t = ph; t < T; t += 16) {
+      const float v = logf(fmaxf(mp[(int64_t)t * NB + bin], eps));
+      mp[(int64_t)t * NB + bin] = v;
+      s += v;
+    }
+  red[ph][threadIdx.x & 15] = s;
+  __syncthreads();
+  float tot = 0.f;
+  for (int i = 0; i < 16; ++i) tot += red[i][threadIdx.x & 15];
+  const float mean = tot / (float)T;
+  if (bin < NB)
+    for (int t = ph; t < T; t += 16) mp[(int64_t)t * NB + bin] -= mean;
+}
+
+// fb [B, T, NB]  ->  img [B, NB+2, T+2, C] (interior only; borders stay zero)
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ fb, int B, int T,
+                                                        int NB, int C,
+                                                        const float* __restrict__ w,  // [C, 9] folded
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ img) {
+  const int cq = C / 4;
+  const int64_t total = (int64_t)B * NB * T * cq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int q = (int)(i % cq);
+    int64_t p = i / cq;
+    const int wv = (int)(p % T);
+    p /= T;
+    const int h = (int)(p % NB);
+    const int b = (int)(p / NB);
+    float in[9];
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int hh = h + dh - 1, ww = wv + dw - 1;
+        in[dh * 3 + dw] = (hh >= 0 && hh < NB && ww >= 0 && ww < T)
+                              ? fb[((int64_t)b * T + ww) * NB + hh] : 0.f;
+      }
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ch = q * 4 + c;
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a = fmaf(in[k], w[ch * 9 + k], a);
+      o[c] = fmaxf(a + bias[ch], 0.f);
+    }
+    float* op = img + (((int64_t)b * (NB + 2) + h + 1) * (T + 2) + wv + 1) * C + q * 4;
+    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// img [B, H+2, W+2, C] (padded NHWC), masks [B, S, L]  ->  stats [B, S, 2*C*H]
+// feature index f = c*H + h (rearrange "b d c f -> b (d c) f" of resnet.py:49-66)
+__global__ __launch_bounds__(256) void stats_pool_kernel(const float* __restrict__ img, int H, int W,
+                                                         int C, const float* __restrict__ masks,
+                                                         int S, int L, float* __restrict__ stats) {
+  extern __shared__ float sw[];  // [S][W] interpolated weights
+  const int b = blockIdx.y, h = blockIdx.x;
+  // F.interpolate(mode="nearest"): src = min(floor(dst * (L / W)), L - 1)  (float32 scale)
+  const float scale = (float)L / (float)W;
+  for (int i = threadIdx.x; i < S * W; i += blockDim.x) {
+    const int s = i / W, t = i - s * W;
+    int src = (int)floorf((float)t * scale);
+    src = src < L - 1 ? src : L - 1;
+    sw[i] = (W == L) ? masks[((int64_t)b * S + s) * L + t] : masks[((int64_t)b * S + s) * L + src];
+  }
+  __syncthreads();
+  const float* base = img + (((int64_t)b * (H + 2) + h + 1) * (W + 2) + 1) * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int s = 0; s < S; ++s) {
+      const float* wt = sw + s * W;
+      float v1 = 0.f, v2 = 0.f, sx = 0.f;
+      for (int t = 0; t < W; ++t) {
+        const float wv = wt[t];
+        v1 += wv;
+        v2 += wv * wv;
+        sx += base[(int64_t)t * C + c] * wv;
+      }
+      v1 += 1e-8f;
+      const float mean = sx / v1;
+      float sq = 0.f;
+      for (int t = 0; t < W; ++t) {
+        const float d = base[(int64_t)t * C + c] - mean;
+        sq += d * d * wt[t];
+      }
+      const float var = sq / (v1 - v2 / v1 + 1e-8f);
+      float* op = stats + ((int64_t)b * S + s) * (2 * C * H);
+      op[c * H + h] = mean;
+      op[C * H + c * H + h] = sqrtf(var);
+    }
+  }
+}
+
+inline unsigned grid_for(int64_t n, int per = 256, int cap = 8192) {
+  int64_t g = cdiv64(n, per);
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+int launch_frame_prep(const float* wave, int B, int N, int T, int flen, int fshift, int Kp,
+                      const float* window, float preemph, float* frames, hipStream_t st) {
+  if (flen > 512 || T <= 0) return DZN_E_INVALID;
+  hipLaunchKernelGGL(frame_prep_kernel, dim3((T + 3) / 4, B), dim3(256), 0, st, wave, N, T, flen,
+                     fshift, Kp, window, preemph, frames);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_power(const float* spec, int64_t rows, int nb, float* pw, hipStream_t st) {
+  hipLaunchKernelGGL(power_kernel, dim3(grid_for(rows * nb)), dim3(256), 0, st, spec, rows, nb, pw);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_log_cmn(float* mel, int B, int T, int NB, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(log_cmn_kernel, dim3((NB + 15) / 16, B), dim3(256), 0, st, mel, T, NB, eps);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* w, const float* bias,
+                     float* img, hipStream_t st) {
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(grid_for((int64_t)B * NB * T * (C / 4))), dim3(256), 0,
+                     st, fb, B, T, NB, C, w, bias, img);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_stats_pool(const float* img, int B, int H, int W, int C, const float* masks, int S, int L,
+                      float* stats, hipStream_t st) {
+  const size_t lds = (size_t)S * W * sizeof(float);
+  hipLaunchKernelGGL(stats_pool_kernel, dim3(H, B), dim3(256), lds, st, img, H, W, C, masks, S, L,
+                     stats);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}

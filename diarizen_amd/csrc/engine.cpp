@@ -1,0 +1,1200 @@
+// engine.cpp — the C ABI of include/dzn.h: weight ingest (fold + pack + pad), workspace, and the
+// host-side orchestration of the gfx950 kernels for the two device stages of the DiariZen
+// pipeline: the WavLM + Conformer segmentation forward and the ResNet34 embedding forward.
+//
+// Data layout in HBM (all activations fp32, channels-last, feature dims zero-padded to
+// multiples of 32 so every contraction has K % 32 == 0 and 16-byte aligned rows):
+//   conv stack   [B, T_i, Cp_i]         — conv i reads conv i-1 as overlapping rows (lda = s*Cp)
+//   encoder      x, y, ws [B*L, D]      — residual stream, LN output, layer-weighted sum
+//   attention    qkv [B*L, 3*h*64], gate [B*L, H], bias table [H, 2L-1]
+//   ResNet       zero-bordered NHWC images [B, H+2, W+2, C]; 3x3 convs address them through
+//                per-geometry row-offset tables (no im2col)
+// Weights are folded on the host at finalize: weight-norm of the positional conv
+// (W2V/components.py:344), eval BatchNorm of the Conformer conv module (conformer.py:205) and of
+// every ResNet conv (resnet.py:139-144), q/k/v concatenation, conv weights re-ordered to
+// [out][tap][in].
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+#define HIPCHK(x)                                                                        \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      throw EngineError(e_ == hipErrorOutOfMemory ? DZN_E_NOMEM : DZN_E_HIP,             \
+                        std::string(#x) + ": " + hipGetErrorString(e_));                 \
+    }                                                                                    \
+  } while (0)
+
+namespace {
+
+struct EngineError : std::runtime_error {
+  int code;
+  EngineError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+struct HostT {
+  std::vector<float> v;
+  std::vector<int64_t> shape;
+};
+
+struct Lin {       // y = x W^T + b with W [N, K] (rows zero-padded to Np, cols to Kp)
+  float* W = nullptr;
+  u16* W16 = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0;  // padded sizes
+};
+
+struct LNp {
+  float* g = nullptr;
+  float* b = nullptr;
+  int C = 0;
+};
+
+struct EncLayer {
+  bool attn = false, ffn = false;
+  int h = 0, F = 0, Fp = 0;
+  LNp ln1, ln2;
+  Lin qkv, out, f1, f2;
+  float *Wg = nullptr, *bg = nullptr, *cst = nullptr;
+  int32_t* head_idx = nullptr;
+};
+
+struct ConfLayer {
+  LNp ffn1_ln, ffn2_ln, mha_ln, conv_ln, out_ln;
+  Lin ffn1_w1, ffn1_w2, ffn2_w1, ffn2_w2, qkv, o, pw1, pw2;
+  float *dw = nullptr, *dwb = nullptr;
+};
+
+struct ResConv {
+  Lin l;
+  int cin = 0, cout = 0, ksz = 3, stride = 1;
+};
+struct ResBlock {
+  ResConv c1, c2, sc;
+  bool has_sc = false;
+};
+
+std::string last_create_error;
+
+}  // namespace
+
+struct dzn_handle {
+  dzn_config cfg{};
+  std::string err;
+  std::map<std::string, HostT> sd;
+  std::set<std::string> used;
+  int ignored = 0;
+  bool finalized = false;
+  bool debug = false;
+  std::vector<void*> allocs;
+  int64_t bytes = 0;
+  std::map<std::string, std::vector<float>> taps;
+
+  // ---- segmentation: geometry ----
+  int nconv = 0;
+  int C[DZN_MAX_CONV]{}, Cp[DZN_MAX_CONV]{};
+  int D = 0, H = 0, A = 0, Fh = 0;
+  // ---- segmentation: weights ----
+  float* conv0_w = nullptr;
+  LNp conv_ln[DZN_MAX_CONV];
+  Lin conv[DZN_MAX_CONV];
+  float* dummy_w = nullptr;
+  LNp fp_ln, enc_ln;
+  Lin fp, posconv;
+  std::vector<EncLayer> layers;
+  std::vector<float> rel_embed;  // [num_buckets, H] host
+  std::vector<float> wsum_w;
+  Lin proj;
+  LNp lnorm;
+  std::vector<ConfLayer> conf;
+  float *cls_w = nullptr, *cls_b = nullptr;
+  uint8_t* mapping = nullptr;
+  // rel-pos table cache
+  int table_L = -1;
+  float* table = nullptr;
+  // ---- segmentation: workspace ----
+  int maxT[DZN_MAX_CONV]{};
+  int maxL = 0;
+  float *stats = nullptr, *gn_stats = nullptr, *bufA = nullptr, *bufB = nullptr;
+  float *x = nullptr, *xpad = nullptr, *y = nullptr, *ws = nullptr, *qkv = nullptr, *ao = nullptr,
+        *gate = nullptr, *mid = nullptr;
+  float *hz = nullptr, *ht = nullptr, *hmid = nullptr, *hv = nullptr;
+
+  // ---- embedding ----
+  bool has_emb = false;
+  float *hamming = nullptr;
+  Lin dft, mel, seg1;
+  float *stem_w = nullptr, *stem_b = nullptr;
+  std::vector<std::vector<ResBlock>> stages;
+  int emb_T = -1;  // geometry currently baked into tables / borders
+  int maxTf = 0;
+  int sH[4]{}, sW[4]{}, sC[4]{};
+  float* sbuf[4][3]{};
+  int64_t sbuf_elems[4]{};  // allocation per image at the largest geometry
+  int64_t simg[4]{};        // elements per image at the current geometry
+  int32_t* tab1[4]{};
+  int32_t* tab2[4]{};
+  float *frames = nullptr, *spec = nullptr, *pw = nullptr, *fb = nullptr, *pool = nullptr;
+};
+
+namespace {
+
+using H = dzn_handle;
+
+// ------------------------------------------------------------------ device memory helpers
+template <typename T>
+T* dalloc(H* h, int64_t n, bool zero = true) {
+  if (n <= 0) n = 1;
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, n * sizeof(T)));
+  h->allocs.push_back(p);
+  h->bytes += n * (int64_t)sizeof(T);
+  if (zero) HIPCHK(hipMemset(p, 0, n * sizeof(T)));
+  return reinterpret_cast<T*>(p);
+}
+
+float* upload(H* h, const std::vector<float>& v) {
+  float* p = dalloc<float>(h, (int64_t)v.size(), false);
+  if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  return p;
+}
+
+u16* upload_bf16(H* h, const std::vector<float>& v) {
+  std::vector<u16> t(v.size());
+  for (size_t i = 0; i < v.size(); ++i) t[i] = f32_to_bf16_host(v[i]);
+  u16* p = dalloc<u16>(h, (int64_t)t.size(), false);
+  if (!t.empty()) HIPCHK(hipMemcpy(p, t.data(), t.size() * sizeof(u16), hipMemcpyHostToDevice));
+  return p;
+}
+
+int pad32(int v) { return round_up(v, 32); }
+
+const HostT& need(H* h, const std::string& key) {
+  auto it = h->sd.find(key);
+  if (it == h->sd.end()) throw EngineError(DZN_E_MISSING, "missing state_dict key: " + key);
+  h->used.insert(key);
+  return it->second;
+}
+
+void expect_numel(const HostT& t, int64_t n, const std::string& key) {
+  if ((int64_t)t.v.size() != n)
+    throw EngineError(DZN_E_INVALID, "shape mismatch for " + key + ": got " +
+                                         std::to_string(t.v.size()) + " elements, expected " +
+                                         std::to_string(n));
+}
+
+// W given as [N][K] row-major (already in the contraction's k order); pads to [Np][Kp]
+Lin make_lin(H* h, const std::vector<float>& W, const float* bias, int N, int K, int Np, int Kp) {
+  std::vector<float> wp((size_t)Np * Kp, 0.f);
+  for (int n = 0; n < N; ++n)
+    std::copy(W.begin() + (size_t)n * K, W.begin() + (size_t)(n + 1) * K, wp.begin() + (size_t)n * Kp);
+  Lin l;
+  l.N = Np;
+  l.K = Kp;
+  l.W = upload(h, wp);
+  if (h->cfg.precision == DZN_PREC_BF16) l.W16 = upload_bf16(h, wp);
+  if (bias) {
+    std::vector<float> bp(Np, 0.f);
+    std::copy(bias, bias + N, bp.begin());
+    l.b = upload(h, bp);
+  }
+  return l;
+}
+
+Lin linear_from_sd(H* h, const std::string& prefix, int N, int K, int Np, int Kp, bool bias = true) {
+  const HostT& w = need(h, prefix + ".weight");
+  expect_numel(w, (int64_t)N * K, prefix + ".weight");
+  const float* b = nullptr;
+  if (bias) {
+    const HostT& bt = need(h, prefix + ".bias");
+    expect_numel(bt, N, prefix + ".bias");
+    b = bt.v.data();
+  }
+  return make_lin(h, w.v, b, N, K, Np, Kp);
+}
+
+LNp ln_from_sd(H* h, const std::string& prefix, int Cn) {
+  const HostT& g = need(h, prefix + ".weight");
+  const HostT& b = need(h, prefix + ".bias");
+  expect_numel(g, Cn, prefix + ".weight");
+  expect_numel(b, Cn, prefix + ".bias");
+  LNp l;
+  l.C = Cn;
+  l.g = upload(h, g.v);
+  l.b = upload(h, b.v);
+  return l;
+}
+
+int conv_out(int n, int k, int s) { return n < k ? 0 : (n - k) / s + 1; }
+
+// W2V/components.py:641-666
+int relpos_bucket(int rel, int num_buckets, int max_distance) {
+  const int nb = num_buckets / 2;
+  int ret = rel > 0 ? nb : 0;
+  const int a = rel < 0 ? -rel : rel;
+  const int max_exact = nb / 2;
+  if (a < max_exact) return ret + a;
+  const float v = logf((float)a / (float)max_exact) /
+                  (float)std::log((double)max_distance / (double)max_exact) *
+                  (float)(nb - max_exact);
+  long large = max_exact + (long)v;
+  if (large > nb - 1) large = nb - 1;
+  return ret + (int)large;
+}
+
+// ------------------------------------------------------------------ segmentation: finalize
+void finalize_seg(H* h) {
+  const dzn_config& c = h->cfg;
+  const std::string P = "wavlm_model.";
+  h->nconv = c.n_conv;
+  h->D = c.embed_dim;
+  h->H = c.total_heads;
+  h->A = c.attention_in;
+  h->Fh = c.ffn_hidden;
+  if (c.n_conv < 1 || c.n_conv > DZN_MAX_CONV || c.n_layers < 1 || c.n_layers > DZN_MAX_LAYERS ||
+      c.total_heads > DZN_MAX_HEADS || c.embed_dim != c.total_heads * 64 || (c.attention_in % 32) ||
+      (c.ffn_hidden % 32) || c.attention_in != c.conf_heads * 64 ||
+      c.embed_dim % c.pos_conv_groups || ((c.embed_dim / c.pos_conv_groups) % 8))
+    throw EngineError(DZN_E_INVALID, "unsupported architecture (head_dim must be 64, dims % 32)");
+  if (c.max_speakers_per_chunk > 8 || c.n_classes > 16)
+    throw EngineError(DZN_E_INVALID, "powerset too large");
+  for (int i = 0; i < c.n_conv; ++i) {
+    h->C[i] = c.conv_ch[i];
+    h->Cp[i] = pad32(c.conv_ch[i]);
+  }
+  // conv0
+  {
+    const std::string pre = P + "feature_extractor.conv_layers.0";
+    const HostT& w = need(h, pre + ".conv.weight");
+    expect_numel(w, (int64_t)h->C[0] * c.conv_k[0], pre + ".conv.weight");
+    h->conv0_w = upload(h, w.v);
+    h->conv_ln[0] = ln_from_sd(h, pre + ".layer_norm", h->C[0]);
+  }
+  for (int i = 1; i < c.n_conv; ++i) {
+    const std::string pre = P + "feature_extractor.conv_layers." + std::to_string(i);
+    const HostT& w = need(h, pre + ".conv.weight");
+    const int ci = h->C[i - 1], co = h->C[i], k = c.conv_k[i], cip = h->Cp[i - 1];
+    expect_numel(w, (int64_t)co * ci * k, pre + ".conv.weight");
+    std::vector<float> wp((size_t)co * k * cip, 0.f);  // [co][j*cip + ci] = w[co][ci][j]
+    for (int o = 0; o < co; ++o)
+      for (int ii = 0; ii < ci; ++ii)
+        for (int j = 0; j < k; ++j)
+          wp[((size_t)o * k + j) * cip + ii] = w.v[((size_t)o * ci + ii) * k + j];
+    h->conv[i] = make_lin(h, wp, nullptr, co, k * cip, h->Cp[i], k * cip);
+    if (c.extractor_layer_norm) h->conv_ln[i] = ln_from_sd(h, pre + ".layer_norm", co);
+  }
+  const int last = c.n_conv - 1;
+  {
+    const HostT& dw = need(h, P + "feature_extractor.dummy_weight");
+    expect_numel(dw, h->C[last], "dummy_weight");
+    h->dummy_w = upload(h, dw.v);
+  }
+  const int D = h->D;
+  h->fp_ln = ln_from_sd(h, P + "encoder.feature_projection.layer_norm", h->C[last]);
+  h->fp = linear_from_sd(h, P + "encoder.feature_projection.projection", D, h->C[last], D,
+                         h->Cp[last]);
+  // positional conv: fold weight norm  W = g * v / ||v||_{dims 0,1}   (components.py:344)
+  {
+    const std::string pc = P + "encoder.transformer.pos_conv_embed.conv";
+    const HostT& g = need(h, pc + ".parametrizations.weight.original0");
+    const HostT& v = need(h, pc + ".parametrizations.weight.original1");
+    const HostT& b = need(h, pc + ".bias");
+    const int K = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G;
+    expect_numel(g, K, pc + ".original0");
+    expect_numel(v, (int64_t)D * cg * K, pc + ".original1");
+    expect_numel(b, D, pc + ".bias");
+    std::vector<double> nrm(K, 0.0);
+    for (int o = 0; o < D; ++o)
+      for (int ii = 0; ii < cg; ++ii)
+        for (int j = 0; j < K; ++j) {
+          const double t = v.v[((size_t)o * cg + ii) * K + j];
+          nrm[j] += t * t;
+        }
+    std::vector<float> wp((size_t)D * K * cg);
+    for (int o = 0; o < D; ++o)
+      for (int ii = 0; ii < cg; ++ii)
+        for (int j = 0; j < K; ++j) {
+          const float nj = (float)std::sqrt(nrm[j]);
+          wp[((size_t)o * K + j) * cg + ii] = g.v[j] * v.v[((size_t)o * cg + ii) * K + j] / nj;
+        }
+    h->posconv = make_lin(h, wp, b.v.data(), D, K * cg, D, K * cg);
+  }
+  if (!c.layer_norm_first) h->enc_ln = ln_from_sd(h, P + "encoder.transformer.layer_norm", D);
+  h->layers.resize(c.n_layers);
+  int maxQ = 64, maxF = 32;
+  for (int i = 0; i < c.n_layers; ++i) {
+    EncLayer& L = h->layers[i];
+    const std::string lp = P + "encoder.transformer.layers." + std::to_string(i);
+    L.attn = c.use_attention[i] && c.n_heads[i] > 0;
+    L.ffn = c.use_ffn[i] != 0;
+    L.ln1 = ln_from_sd(h, lp + ".layer_norm", D);
+    L.ln2 = ln_from_sd(h, lp + ".final_layer_norm", D);
+    if (L.attn) {
+      L.h = c.n_heads[i];
+      const int hd = L.h * 64;
+      maxQ = std::max(maxQ, hd);
+      std::vector<float> wq((size_t)3 * hd * D), bq((size_t)3 * hd);
+      const char* names[3] = {".attention.q_proj", ".attention.k_proj", ".attention.v_proj"};
+      for (int t = 0; t < 3; ++t) {
+        const HostT& w = need(h, lp + names[t] + ".weight");
+        const HostT& b = need(h, lp + names[t] + ".bias");
+        expect_numel(w, (int64_t)hd * D, lp + names[t] + ".weight");
+        expect_numel(b, hd, lp + names[t] + ".bias");
+        std::copy(w.v.begin(), w.v.end(), wq.begin() + (size_t)t * hd * D);
+        std::copy(b.v.begin(), b.v.end(), bq.begin() + (size_t)t * hd);
+      }
+      L.qkv = make_lin(h, wq, bq.data(), 3 * hd, D, 3 * hd, D);
+      L.out = linear_from_sd(h, lp + ".attention.out_proj", D, hd, D, hd);
+      const HostT& wg = need(h, lp + ".attention.gru_rel_pos_linear.weight");
+      const HostT& bg = need(h, lp + ".attention.gru_rel_pos_linear.bias");
+      const HostT& cs = need(h, lp + ".attention.gru_rel_pos_const");
+      expect_numel(wg, 8 * 64, "gru_rel_pos_linear.weight");
+      expect_numel(bg, 8, "gru_rel_pos_linear.bias");
+      expect_numel(cs, h->H, "gru_rel_pos_const");
+      L.Wg = upload(h, wg.v);
+      L.bg = upload(h, bg.v);
+      L.cst = upload(h, cs.v);
+      std::vector<int32_t> hi(c.head_idx[i], c.head_idx[i] + L.h);
+      for (int v : hi)
+        if (v < 0 || v >= h->H) throw EngineError(DZN_E_INVALID, "head index out of range");
+      L.head_idx = dalloc<int32_t>(h, L.h, false);
+      HIPCHK(hipMemcpy(L.head_idx, hi.data(), L.h * sizeof(int32_t), hipMemcpyHostToDevice));
+      if (i == 0) {
+        const HostT& e = need(h, lp + ".attention.rel_attn_embed.weight");
+        expect_numel(e, (int64_t)c.num_buckets * h->H, "rel_attn_embed.weight");
+        h->rel_embed = e.v;
+      }
+    }
+    if (L.ffn) {
+      L.F = c.ffn_dim[i];
+      L.Fp = pad32(L.F);
+      maxF = std::max(maxF, L.Fp);
+      L.f1 = linear_from_sd(h, lp + ".feed_forward.intermediate_dense", L.F, D, L.Fp, D);
+      L.f2 = linear_from_sd(h, lp + ".feed_forward.output_dense", D, L.F, D, L.Fp);
+    }
+  }
+  if (h->rel_embed.empty())
+    throw EngineError(DZN_E_INVALID, "layer 0 must carry attention (rel_attn_embed lives there)");
+  {
+    const HostT& w = need(h, "weight_sum.weight");
+    expect_numel(w, c.n_layers + 1, "weight_sum.weight");
+    h->wsum_w = w.v;
+  }
+  const int A = h->A, Fh = h->Fh;
+  h->proj = linear_from_sd(h, "proj", A, D, A, D);
+  h->lnorm = ln_from_sd(h, "lnorm", A);
+  h->conf.resize(c.conf_layers);
+  for (int i = 0; i < c.conf_layers; ++i) {
+    ConfLayer& L = h->conf[i];
+    const std::string cp = "conformer.conformer_layer." + std::to_string(i);
+    L.ffn1_ln = ln_from_sd(h, cp + ".ffn1.ln_norm", A);
+    L.ffn1_w1 = linear_from_sd(h, cp + ".ffn1.w_1", Fh, A, Fh, A);
+    L.ffn1_w2 = linear_from_sd(h, cp + ".ffn1.w_2", A, Fh, A, Fh);
+    L.ffn2_ln = ln_from_sd(h, cp + ".ffn2.ln_norm", A);
+    L.ffn2_w1 = linear_from_sd(h, cp + ".ffn2.w_1", Fh, A, Fh, A);
+    L.ffn2_w2 = linear_from_sd(h, cp + ".ffn2.w_2", A, Fh, A, Fh);
+    L.mha_ln = ln_from_sd(h, cp + ".mha.ln_norm", A);
+    {
+      std::vector<float> wq((size_t)3 * A * A), bq((size_t)3 * A);
+      const char* names[3] = {".mha.mha.linearQ", ".mha.mha.linearK", ".mha.mha.linearV"};
+      for (int t = 0; t < 3; ++t) {
+        const HostT& w = need(h, cp + names[t] + ".weight");
+        const HostT& b = need(h, cp + names[t] + ".bias");
+        expect_numel(w, (int64_t)A * A, cp + names[t] + ".weight");
+        expect_numel(b, A, cp + names[t] + ".bias");
+        std::copy(w.v.begin(), w.v.end(), wq.begin() + (size_t)t * A * A);
+        std::copy(b.v.begin(), b.v.end(), bq.begin() + (size_t)t * A);
+      }
+      L.qkv = make_lin(h, wq, bq.data(), 3 * A, A, 3 * A, A);
+    }
+    L.o = linear_from_sd(h, cp + ".mha.mha.linearO", A, A, A, A);
+    L.conv_ln = ln_from_sd(h, cp + ".conv.ln_norm", A);
+    L.pw1 = linear_from_sd(h, cp + ".conv.pointwise_conv1", 2 * A, A, 2 * A, A);
+    L.pw2 = linear_from_sd(h, cp + ".conv.pointwise_conv2", A, A, A, A);
+    {
+      // fold eval BatchNorm1d into the depthwise taps (conformer.py:205)
+      const int ks = c.conf_kernel;
+      const HostT& w = need(h, cp + ".conv.depthwise_conv.weight");
+      const HostT& b = need(h, cp + ".conv.depthwise_conv.bias");
+      const HostT& g = need(h, cp + ".conv.bn_norm.weight");
+      const HostT& be = need(h, cp + ".conv.bn_norm.bias");
+      const HostT& rm = need(h, cp + ".conv.bn_norm.running_mean");
+      const HostT& rv = need(h, cp + ".conv.bn_norm.running_var");
+      expect_numel(w, (int64_t)A * ks, cp + ".conv.depthwise_conv.weight");
+      std::vector<float> wf((size_t)A * ks), bf(A);
+      for (int ch = 0; ch < A; ++ch) {
+        const float s = g.v[ch] / std::sqrt(rv.v[ch] + 1e-5f);
+        for (int j = 0; j < ks; ++j) wf[(size_t)ch * ks + j] = w.v[(size_t)ch * ks + j] * s;
+        bf[ch] = (b.v[ch] - rm.v[ch]) * s + be.v[ch];
+      }
+      L.dw = upload(h, wf);
+      L.dwb = upload(h, bf);
+    }
+    L.out_ln = ln_from_sd(h, cp + ".ln_norm", A);
+  }
+  {
+    const HostT& w = need(h, "classifier.weight");
+    const HostT& b = need(h, "classifier.bias");
+    expect_numel(w, (int64_t)c.n_classes * A, "classifier.weight");
+    expect_numel(b, c.n_classes, "classifier.bias");
+    h->cls_w = upload(h, w.v);
+    h->cls_b = upload(h, b.v);
+    // PA/utils/powerset.py:68-97: classes ordered by set size, then lexicographic combinations
+    const int S = c.max_speakers_per_chunk;
+    std::vector<uint8_t> map;
+    int rows = 0;
+    for (int size = 0; size <= c.max_speakers_per_frame; ++size) {
+      std::vector<int> idx(size);
+      for (int i = 0; i < size; ++i) idx[i] = i;
+      while (true) {
+        std::vector<uint8_t> r(S, 0);
+        for (int v : idx) r[v] = 1;
+        map.insert(map.end(), r.begin(), r.end());
+        ++rows;
+        int i = size - 1;
+        while (i >= 0 && idx[i] == S - size + i) --i;
+        if (i < 0) break;
+        ++idx[i];
+        for (int j = i + 1; j < size; ++j) idx[j] = idx[j - 1] + 1;
+      }
+    }
+    if (rows != c.n_classes) throw EngineError(DZN_E_INVALID, "n_classes != powerset size");
+    h->mapping = dalloc<uint8_t>(h, (int64_t)map.size(), false);
+    HIPCHK(hipMemcpy(h->mapping, map.data(), map.size(), hipMemcpyHostToDevice));
+  }
+
+  // ---- workspace for (max_batch, max_samples) ----
+  const int64_t B = c.max_batch;
+  int n = c.max_samples;
+  int64_t maxbuf = 0;
+  for (int i = 0; i < c.n_conv; ++i) {
+    n = conv_out(n, c.conv_k[i], c.conv_s[i]);
+    h->maxT[i] = n;
+    maxbuf = std::max(maxbuf, (int64_t)B * n * h->Cp[i]);
+  }
+  h->maxL = n;
+  if (n < 1) throw EngineError(DZN_E_INVALID, "max_samples too short");
+  const int64_t ML = B * n;
+  h->stats = dalloc<float>(h, B * 2);
+  if (!c.extractor_layer_norm) h->gn_stats = dalloc<float>(h, B * h->C[0] * 2);
+  h->bufA = dalloc<float>(h, maxbuf);
+  {
+    // bufB holds every odd conv output (and the feature-projection LN output)
+    int64_t need_b = B * n * h->Cp[c.n_conv - 1];
+    for (int i = 1; i < c.n_conv; i += 2) need_b = std::max(need_b, B * h->maxT[i] * h->Cp[i]);
+    h->bufB = dalloc<float>(h, need_b);
+  }
+  h->x = dalloc<float>(h, ML * D);
+  h->xpad = dalloc<float>(h, B * (n + c.pos_conv_kernel) * D);
+  h->y = dalloc<float>(h, ML * D);
+  h->ws = dalloc<float>(h, ML * D);
+  h->qkv = dalloc<float>(h, ML * 3 * maxQ);
+  h->ao = dalloc<float>(h, ML * maxQ);
+  h->gate = dalloc<float>(h, ML * h->H);
+  h->mid = dalloc<float>(h, ML * maxF);
+  h->hz = dalloc<float>(h, ML * A);
+  h->ht = dalloc<float>(h, ML * A);
+  h->hmid = dalloc<float>(h, ML * std::max(Fh, 3 * A));
+  h->hv = dalloc<float>(h, ML * A);
+}
+
+// ------------------------------------------------------------------ embedding: finalize
+void fold_bn(H* h, const std::string& bn, int Cn, std::vector<float>& scale, std::vector<float>& shift) {
+  const HostT& g = need(h, bn + ".weight");
+  const HostT& b = need(h, bn + ".bias");
+  const HostT& rm = need(h, bn + ".running_mean");
+  const HostT& rv = need(h, bn + ".running_var");
+  expect_numel(g, Cn, bn + ".weight");
+  scale.resize(Cn);
+  shift.resize(Cn);
+  for (int i = 0; i < Cn; ++i) {
+    scale[i] = g.v[i] / std::sqrt(rv.v[i] + 1e-5f);
+    shift[i] = b.v[i] - rm.v[i] * scale[i];
+  }
+}
+
+ResConv make_resconv(H* h, const std::string& conv, const std::string& bn, int cin, int cout, int ksz,
+                     int stride) {
+  const HostT& w = need(h, conv + ".weight");
+  expect_numel(w, (int64_t)cout * cin * ksz * ksz, conv + ".weight");
+  std::vector<float> sc, sh;
+  fold_bn(h, bn, cout, sc, sh);
+  const int K = ksz * ksz * cin;
+  std::vector<float> wp((size_t)cout * K);
+  for (int o = 0; o < cout; ++o)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int dh = 0; dh < ksz; ++dh)
+        for (int dw = 0; dw < ksz; ++dw)
+          wp[(size_t)o * K + (dh * ksz + dw) * cin + ci] =
+              w.v[(((size_t)o * cin + ci) * ksz + dh) * ksz + dw] * sc[o];
+  ResConv r;
+  r.cin = cin;
+  r.cout = cout;
+  r.ksz = ksz;
+  r.stride = stride;
+  r.l = make_lin(h, wp, sh.data(), cout, K, cout, K);
+  return r;
+}
+
+void finalize_emb(H* h) {
+  const dzn_config& c = h->cfg;
+  const std::string E = "embedding.resnet.";
+  const int NB = c.num_mel_bins;
+  if (NB != 80 || c.embed_out_dim <= 0) throw EngineError(DZN_E_INVALID, "embedding config");
+  const int flen = 400, NFFT = 512, Kp = 416;
+  {
+    // torch.hamming_window(400, periodic=False): 0.54 - 0.46 cos(2 pi n / (N-1))
+    std::vector<float> wdw(flen);
+    for (int i = 0; i < flen; ++i)
+      wdw[i] = (float)(0.54 - 0.46 * std::cos(2.0 * M_PI * (double)i / (double)(flen - 1)));
+    h->hamming = upload(h, wdw);
+    // real DFT as a contraction: rows 0..255 cos, 256..511 sin, bins 0..255 (bin 256 unused)
+    std::vector<float> dft((size_t)512 * Kp, 0.f);
+    for (int f = 0; f < 256; ++f)
+      for (int t = 0; t < flen; ++t) {
+        const double ang = 2.0 * M_PI * (double)((int64_t)f * t % NFFT) / (double)NFFT;
+        dft[(size_t)f * Kp + t] = (float)std::cos(ang);
+        dft[(size_t)(256 + f) * Kp + t] = (float)(-std::sin(ang));
+      }
+    h->dft = make_lin(h, dft, nullptr, 512, Kp, 512, Kp);
+    // Kaldi mel banks (torchaudio.compliance.kaldi.get_mel_banks, float32 arithmetic):
+    // low 20 Hz, high = Nyquist, 80 triangles in mel(f) = 1127 ln(1 + f/700), bins 0..255
+    const float mel_low = 1127.0f * logf(1.0f + 20.0f / 700.0f);
+    const float mel_high = 1127.0f * logf(1.0f + 8000.0f / 700.0f);
+    const float delta = (mel_high - mel_low) / (float)(NB + 1);
+    std::vector<float> mw((size_t)NB * 256, 0.f);
+    for (int b = 0; b < NB; ++b) {
+      const float left = mel_low + (float)b * delta;
+      const float center = mel_low + ((float)b + 1.0f) * delta;
+      const float right = mel_low + ((float)b + 2.0f) * delta;
+      for (int f = 0; f < 256; ++f) {
+        const float mel = 1127.0f * logf(1.0f + (31.25f * (float)f) / 700.0f);
+        const float up = (mel - left) / (center - left);
+        const float down = (right - mel) / (right - center);
+        mw[(size_t)b * 256 + f] = std::max(0.0f, std::min(up, down));
+      }
+    }
+    h->mel = make_lin(h, mw, nullptr, NB, 256, NB, 256);
+  }
+  const int m = 32;
+  {
+    const HostT& w = need(h, E + "conv1.weight");
+    expect_numel(w, (int64_t)m * 9, E + "conv1.weight");
+    std::vector<float> sc, sh;
+    fold_bn(h, E + "bn1", m, sc, sh);
+    std::vector<float> wf(w.v);
+    for (int o = 0; o < m; ++o)
+      for (int k = 0; k < 9; ++k) wf[(size_t)o * 9 + k] *= sc[o];
+    h->stem_w = upload(h, wf);
+    h->stem_b = upload(h, sh);
+  }
+  const int nblocks[4] = {3, 4, 6, 3};
+  h->stages.resize(4);
+  int cin = m;
+  for (int s = 0; s < 4; ++s) {
+    const int cout = m << s;
+    h->sC[s] = cout;
+    h->stages[s].resize(nblocks[s]);
+    for (int j = 0; j < nblocks[s]; ++j) {
+      const std::string bp = E + "layer" + std::to_string(s + 1) + "." + std::to_string(j);
+      ResBlock& rb = h->stages[s][j];
+      const int stride = (j == 0 && s > 0) ? 2 : 1;
+      rb.c1 = make_resconv(h, bp + ".conv1", bp + ".bn1", cin, cout, 3, stride);
+      rb.c2 = make_resconv(h, bp + ".conv2", bp + ".bn2", cout, cout, 3, 1);
+      rb.has_sc = (stride != 1 || cin != cout);
+      if (rb.has_sc) rb.sc = make_resconv(h, bp + ".shortcut.0", bp + ".shortcut.1", cin, cout, 1, stride);
+      cin = cout;
+    }
+  }
+  const int feat = (m << 3) * (NB / 8) * 2;  // 256 * 10 * 2 = 5120
+  h->seg1 = linear_from_sd(h, E + "seg_1", c.embed_out_dim, feat, c.embed_out_dim, feat);
+
+  // workspace
+  const int64_t B = c.max_batch;
+  const int Tmax = c.max_samples < flen ? 0 : 1 + (c.max_samples - flen) / 160;
+  if (Tmax < 8) throw EngineError(DZN_E_INVALID, "max_samples too short for the embedding model");
+  h->maxTf = Tmax;
+  h->frames = dalloc<float>(h, B * Tmax * Kp);
+  h->spec = dalloc<float>(h, B * Tmax * 512);
+  h->pw = dalloc<float>(h, B * Tmax * 256);
+  h->fb = dalloc<float>(h, B * Tmax * NB);
+  int Hs = NB, Ws = Tmax;
+  for (int s = 0; s < 4; ++s) {
+    if (s > 0) {
+      Hs = (Hs - 1) / 2 + 1;
+      Ws = (Ws - 1) / 2 + 1;
+    }
+    h->sbuf_elems[s] = (int64_t)(Hs + 2) * (Ws + 2) * h->sC[s];
+    for (int k = 0; k < 3; ++k) h->sbuf[s][k] = dalloc<float>(h, B * h->sbuf_elems[s]);
+    h->tab1[s] = dalloc<int32_t>(h, (int64_t)Hs * Ws);
+    h->tab2[s] = dalloc<int32_t>(h, (int64_t)Hs * Ws);
+  }
+  h->pool = dalloc<float>(h, B * 8 * feat);
+}
+
+// bake the geometry of T fbank frames into the row-offset tables and re-zero image borders
+void emb_set_geometry(H* h, int T, hipStream_t st) {
+  if (T == h->emb_T) return;
+  HIPCHK(hipStreamSynchronize(st));
+  const int64_t B = h->cfg.max_batch;
+  int Hs = h->cfg.num_mel_bins, Ws = T;
+  int Hp = 0, Wp = 0;
+  for (int s = 0; s < 4; ++s) {
+    if (s > 0) {
+      Hp = Hs;
+      Wp = Ws;
+      Hs = (Hs - 1) / 2 + 1;
+      Ws = (Ws - 1) / 2 + 1;
+    }
+    h->sH[s] = Hs;
+    h->sW[s] = Ws;
+    const int Cc = h->sC[s];
+    h->simg[s] = (int64_t)(Hs + 2) * (Ws + 2) * Cc;
+    std::vector<int32_t> t1((size_t)Hs * Ws), t2((size_t)Hs * Ws, 0);
+    for (int y = 0; y < Hs; ++y)
+      for (int x = 0; x < Ws; ++x) {
+        t1[(size_t)y * Ws + x] = (y * (Ws + 2) + x) * Cc;  // top-left of the 3x3 patch
+        if (s > 0) t2[(size_t)y * Ws + x] = ((2 * y) * (Wp + 2) + 2 * x) * h->sC[s - 1];
+      }
+    HIPCHK(hipMemcpy(h->tab1[s], t1.data(), t1.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->tab2[s], t2.data(), t2.size() * 4, hipMemcpyHostToDevice));
+    for (int k = 0; k < 3; ++k)
+      HIPCHK(hipMemset(h->sbuf[s][k], 0, B * h->sbuf_elems[s] * sizeof(float)));
+  }
+  h->emb_T = T;
+}
+
+// ------------------------------------------------------------------ forward helpers
+void chk(int rc, const char* what) {
+  if (rc != DZN_OK) throw EngineError(rc, std::string("kernel launch failed: ") + what);
+}
+
+void tap(H* h, const char* name, const float* p, int64_t rows, int cols, int64_t ld, hipStream_t st) {
+  if (!h->debug) return;
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<float>& v = h->taps[name];
+  v.resize((size_t)rows * cols);
+  HIPCHK(hipMemcpy2D(v.data(), (size_t)cols * 4, p, (size_t)ld * 4, (size_t)cols * 4, (size_t)rows,
+                     hipMemcpyDeviceToHost));
+}
+
+dzn_gemm_desc gd(H* h, const float* A, const Lin& l, float* C, int64_t M, int64_t lda, int64_t ldc) {
+  dzn_gemm_desc d{};
+  d.A = A;
+  d.W = l.W;
+  d.W16 = l.W16;
+  d.C = C;
+  d.bias = l.b;
+  d.M = (int)M;
+  d.N = l.N;
+  d.K = l.K;
+  d.lda = lda;
+  d.kc = l.K;
+  d.ldk = 0;
+  d.ldw = l.K;
+  d.ldc = ldc;
+  d.alpha = 1.f;
+  d.nz = 1;
+  d.zdiv = 1;
+  d.precision = h->cfg.precision;
+  return d;
+}
+
+void layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const LNp& p, int64_t rows, int Cpad,
+               int gelu, hipStream_t st) {
+  chk(launch_layernorm(x, ldx, y, ldy, p.g, p.b, rows, p.C, Cpad, 1e-5f, gelu, st), "layernorm");
+}
+
+void ensure_table(H* h, int L, hipStream_t st) {
+  if (L == h->table_L) return;
+  HIPCHK(hipStreamSynchronize(st));
+  const int Hn = h->H, W = 2 * L - 1;
+  std::vector<float> t((size_t)Hn * W);
+  for (int r = -(L - 1); r <= L - 1; ++r) {
+    const int bk = relpos_bucket(r, h->cfg.num_buckets, h->cfg.max_distance);
+    for (int hh = 0; hh < Hn; ++hh) t[(size_t)hh * W + (r + L - 1)] = h->rel_embed[(size_t)bk * Hn + hh];
+  }
+  if (!h->table) h->table = dalloc<float>(h, (int64_t)Hn * (2 * h->maxL - 1), false);
+  HIPCHK(hipMemcpy(h->table, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  h->table_L = L;
+}
+
+// ------------------------------------------------------------------ segmentation forward
+void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* d_ml, hipStream_t st) {
+  const dzn_config& c = h->cfg;
+  int T[DZN_MAX_CONV];
+  {
+    int n = N;
+    for (int i = 0; i < c.n_conv; ++i) {
+      n = conv_out(n, c.conv_k[i], c.conv_s[i]);
+      T[i] = n;
+    }
+  }
+  const int L = T[c.n_conv - 1];
+  if (L < 1) throw EngineError(DZN_E_INVALID, "window too short");
+  const int D = h->D, A = h->A, Fh = h->Fh;
+  const int64_t ML = (int64_t)B * L;
+
+  // ---- conv feature extractor ----
+  const float* stats = nullptr;
+  if (c.normalize_waveform) {
+    chk(launch_wave_stats(wave, B, N, 1e-5f, h->stats, st), "wave_stats");
+    stats = h->stats;
+  }
+  chk(launch_conv0(wave, B, N, stats, h->conv0_w, h->conv_ln[0].g, h->conv_ln[0].b, h->C[0], h->Cp[0],
+                   c.conv_k[0], c.conv_s[0], T[0], c.extractor_layer_norm, 1e-5f, h->bufA, st),
+      "conv0");
+  if (!c.extractor_layer_norm)
+    chk(launch_groupnorm_gelu(h->bufA, B, T[0], h->C[0], h->Cp[0], h->conv_ln[0].g, h->conv_ln[0].b,
+                              1e-5f, h->gn_stats, st),
+        "groupnorm");
+  tap(h, "conv0", h->bufA, (int64_t)B * T[0], h->C[0], h->Cp[0], st);
+  float* cur = h->bufA;
+  float* nxt = h->bufB;
+  for (int i = 1; i < c.n_conv; ++i) {
+    // conv1d(k, s) over channels-last rows: row t of the contraction starts at (t*s)*Cp_in
+    dzn_gemm_desc d = gd(h, cur, h->conv[i], nxt, T[i], (int64_t)c.conv_s[i] * h->Cp[i - 1], h->Cp[i]);
+    d.nz = B;
+    d.a_z0 = (int64_t)T[i - 1] * h->Cp[i - 1];
+    d.c_z0 = (int64_t)T[i] * h->Cp[i];
+    if (!c.extractor_layer_norm) d.act = DZN_ACT_GELU;
+    chk(launch_gemm(d, st), "conv gemm");
+    if (c.extractor_layer_norm)
+      layernorm(nxt, h->Cp[i], nxt, h->Cp[i], h->conv_ln[i], (int64_t)B * T[i], h->Cp[i], 1, st);
+    std::swap(cur, nxt);
+  }
+  const int last = c.n_conv - 1;
+  chk(launch_col_scale(cur, ML, h->C[last], h->Cp[last], h->dummy_w, st), "dummy_weight");
+  tap(h, "features", cur, ML, h->C[last], h->Cp[last], st);
+
+  // ---- feature projection (components.py:305-306) ----
+  layernorm(cur, h->Cp[last], nxt, h->Cp[last], h->fp_ln, ML, h->Cp[last], 0, st);
+  {
+    dzn_gemm_desc d = gd(h, nxt, h->fp, h->x, ML, h->Cp[last], D);
+    chk(launch_gemm(d, st), "feature projection");
+  }
+  tap(h, "featproj", h->x, ML, D, D, st);
+
+  // ---- positional conv: x = x + gelu(conv_pos(x))  (components.py:980-987, 366-380) ----
+  {
+    const int Kc = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G, Lp = L + Kc;
+    chk(launch_pad_rows(h->x, h->xpad, B, L, Lp, Kc / 2, D, st), "pad_rows");
+    dzn_gemm_desc d = gd(h, h->xpad, h->posconv, h->x, L, D, D);
+    d.N = cg;
+    d.kc = cg;
+    d.ldk = D;
+    d.act = DZN_ACT_GELU;
+    d.R = h->x;
+    d.nz = B * G;
+    d.zdiv = G;
+    d.a_z0 = (int64_t)Lp * D;
+    d.a_z1 = cg;
+    d.w_z1 = (int64_t)cg * h->posconv.K;
+    d.c_z0 = (int64_t)L * D;
+    d.c_z1 = cg;
+    d.b_z1 = cg;
+    chk(launch_gemm(d, st), "pos conv");
+  }
+  if (!c.layer_norm_first) layernorm(h->x, D, h->x, D, h->enc_ln, ML, D, 0, st);
+  chk(launch_ws_accum(h->x, h->ws, h->wsum_w[0], 1, ML * D, st), "ws_accum");
+  tap(h, "rep0", h->x, ML, D, D, st);
+
+  // ---- transformer layers (components.py:920-942) ----
+  ensure_table(h, L, st);
+  for (int i = 0; i < c.n_layers; ++i) {
+    EncLayer& Ly = h->layers[i];
+    const float wl = h->wsum_w[i + 1];
+    if (Ly.attn) {
+      const float* yin = h->x;
+      if (c.layer_norm_first) {
+        layernorm(h->x, D, h->y, D, Ly.ln1, ML, D, 0, st);
+        yin = h->y;
+      }
+      chk(launch_gate(yin, D, Ly.Wg, Ly.bg, Ly.cst, h->gate, ML, h->H, st), "gate");
+      const int hd = Ly.h * 64;
+      dzn_gemm_desc d = gd(h, yin, Ly.qkv, h->qkv, ML, D, 3 * hd);
+      chk(launch_gemm(d, st), "qkv");
+      chk(launch_attention(h->qkv, h->ao, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd, hd,
+                           0.125f, c.precision, st),
+          "attention");
+      dzn_gemm_desc o = gd(h, h->ao, Ly.out, h->x, ML, hd, D);
+      o.R = h->x;
+      chk(launch_gemm(o, st), "out_proj");
+    }
+    if (c.layer_norm_first) {
+      if (Ly.ffn) {
+        layernorm(h->x, D, h->y, D, Ly.ln2, ML, D, 0, st);
+        dzn_gemm_desc f1 = gd(h, h->y, Ly.f1, h->mid, ML, D, Ly.Fp);
+        f1.act = DZN_ACT_GELU;
+        chk(launch_gemm(f1, st), "ffn1");
+        dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, h->x, ML, Ly.Fp, D);
+        f2.R = h->x;
+        f2.WS = h->ws;
+        f2.ldws = D;
+        f2.ws_w = wl;
+        chk(launch_gemm(f2, st), "ffn2");
+      } else {
+        chk(launch_ws_accum(h->x, h->ws, wl, 0, ML * D, st), "ws_accum");
+      }
+    } else {
+      layernorm(h->x, D, h->x, D, Ly.ln1, ML, D, 0, st);
+      if (Ly.ffn) {
+        dzn_gemm_desc f1 = gd(h, h->x, Ly.f1, h->mid, ML, D, Ly.Fp);
+        f1.act = DZN_ACT_GELU;
+        chk(launch_gemm(f1, st), "ffn1");
+        dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, h->x, ML, Ly.Fp, D);
+        f2.R = h->x;
+        chk(launch_gemm(f2, st), "ffn2");
+      }
+      layernorm(h->x, D, h->x, D, Ly.ln2, ML, D, 0, st);
+      chk(launch_ws_accum(h->x, h->ws, wl, 0, ML * D, st), "ws_accum");
+    }
+    if (h->debug) {
+      const std::string nm = "layer" + std::to_string(i);
+      tap(h, nm.c_str(), h->x, ML, D, D, st);
+    }
+  }
+  tap(h, "wsum", h->ws, ML, D, D, st);
+
+  // ---- head: proj + LN, Conformer x conf_layers, classifier (model_wavlm_conformer.py:256-262) ----
+  {
+    dzn_gemm_desc d = gd(h, h->ws, h->proj, h->hz, ML, D, A);
+    chk(launch_gemm(d, st), "proj");
+    layernorm(h->hz, A, h->hz, A, h->lnorm, ML, A, 0, st);
+  }
+  tap(h, "head_in", h->hz, ML, A, A, st);
+  for (int i = 0; i < c.conf_layers; ++i) {
+    ConfLayer& Cl = h->conf[i];
+    auto half_ffn = [&](const LNp& ln, const Lin& w1, const Lin& w2) {
+      layernorm(h->hz, A, h->ht, A, ln, ML, A, 0, st);
+      dzn_gemm_desc a = gd(h, h->ht, w1, h->hmid, ML, A, Fh);
+      a.act = DZN_ACT_SWISH;
+      chk(launch_gemm(a, st), "conf ffn w1");
+      dzn_gemm_desc b = gd(h, h->hmid, w2, h->hz, ML, Fh, A);
+      b.alpha = 0.5f;
+      b.R = h->hz;
+      chk(launch_gemm(b, st), "conf ffn w2");
+    };
+    half_ffn(Cl.ffn1_ln, Cl.ffn1_w1, Cl.ffn1_w2);
+    // MHSA
+    layernorm(h->hz, A, h->ht, A, Cl.mha_ln, ML, A, 0, st);
+    {
+      dzn_gemm_desc q = gd(h, h->ht, Cl.qkv, h->hmid, ML, A, 3 * A);
+      chk(launch_gemm(q, st), "conf qkv");
+      chk(launch_attention(h->hmid, h->hv, nullptr, nullptr, nullptr, B, L, c.conf_heads, 0, 3 * A, A,
+                           0.125f, c.precision, st),
+          "conf attention");
+      dzn_gemm_desc o = gd(h, h->hv, Cl.o, h->hz, ML, A, A);
+      o.R = h->hz;
+      chk(launch_gemm(o, st), "conf out");
+    }
+    // conv module
+    layernorm(h->hz, A, h->ht, A, Cl.conv_ln, ML, A, 0, st);
+    {
+      dzn_gemm_desc p1 = gd(h, h->ht, Cl.pw1, h->hmid, ML, A, 2 * A);
+      chk(launch_gemm(p1, st), "conf pw1");
+      chk(launch_glu_dwconv(h->hmid, 2 * A, Cl.dw, Cl.dwb, h->hv, A, B, L, A, c.conf_kernel, st),
+          "glu_dwconv");
+      dzn_gemm_desc p2 = gd(h, h->hv, Cl.pw2, h->hz, ML, A, A);
+      p2.R = h->hz;
+      chk(launch_gemm(p2, st), "conf pw2");
+    }
+    half_ffn(Cl.ffn2_ln, Cl.ffn2_w1, Cl.ffn2_w2);
+    layernorm(h->hz, A, h->hz, A, Cl.out_ln, ML, A, 0, st);
+    if (h->debug) {
+      const std::string nm = "conf" + std::to_string(i);
+      tap(h, nm.c_str(), h->hz, ML, A, A, st);
+    }
+  }
+  chk(launch_classify(h->hz, A, h->cls_w, h->cls_b, h->mapping, ML, A, c.n_classes,
+                      c.max_speakers_per_chunk, d_logp, d_ml, st),
+      "classify");
+}
+
+// ------------------------------------------------------------------ embedding forward
+void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int N, int L, float* d_emb,
+                 hipStream_t st) {
+  const dzn_config& c = h->cfg;
+  const int flen = 400, fshift = 160, Kp = 416, NB = c.num_mel_bins;
+  if (N < flen) throw EngineError(DZN_E_INVALID, "waveform shorter than one fbank frame (400 samples)");
+  const int T = 1 + (N - flen) / fshift;
+  if (T > h->maxTf) throw EngineError(DZN_E_INVALID, "N exceeds max_samples");
+  if (S < 1 || S > 8) throw EngineError(DZN_E_INVALID, "S must be in [1, 8]");
+  emb_set_geometry(h, T, st);
+  const int64_t MT = (int64_t)B * T;
+  // ---- kaldi fbank ----
+  chk(launch_frame_prep(wave, B, N, T, flen, fshift, Kp, h->hamming, 0.97f, h->frames, st), "frame_prep");
+  {
+    dzn_gemm_desc d = gd(h, h->frames, h->dft, h->spec, MT, Kp, 512);
+    d.precision = DZN_PREC_F32;  // the spectrum spans ~9 decades: keep the transform in fp32
+    chk(launch_gemm(d, st), "dft");
+    chk(launch_power(h->spec, MT, 256, h->pw, st), "power");
+    dzn_gemm_desc m = gd(h, h->pw, h->mel, h->fb, MT, 256, NB);
+    m.precision = DZN_PREC_F32;
+    chk(launch_gemm(m, st), "mel");
+    chk(launch_log_cmn(h->fb, B, T, NB, 1.1920928955078125e-07f, st), "log_cmn");
+  }
+  tap(h, "fbank", h->fb, MT, NB, NB, st);
+  // ---- ResNet34 trunk ----
+  chk(launch_stem_conv(h->fb, B, T, NB, h->sC[0], h->stem_w, h->stem_b, h->sbuf[0][0], st), "stem");
+  const float* prev = nullptr;  // output image of the previous stage
+  int cur = 0;
+  for (int s = 0; s < 4; ++s) {
+    const int Hs = h->sH[s], Ws = h->sW[s], Cc = h->sC[s];
+    const int64_t img = h->simg[s];
+    const int64_t interior = ((int64_t)(Ws + 2) + 1) * Cc;
+    const int M = Hs * Ws;
+    auto conv3 = [&](const float* in, const ResConv& rc, float* out, const float* R, int act,
+                     int post_relu) {
+      // stride-1 3x3 inside stage s: patch rows via tab1, two-level K = (dh | dw*C + ci)
+      dzn_gemm_desc d = gd(h, in, rc.l, out + interior, M, 0, 0);
+      d.a_rowoff = h->tab1[s];
+      d.c_rowoff = h->tab1[s];
+      d.kc = 3 * rc.cin;
+      d.ldk = (int64_t)(Ws + 2) * rc.cin;
+      d.act = act;
+      d.R = R ? R + interior : nullptr;
+      d.post_relu = post_relu;
+      d.nz = B;
+      d.a_z0 = img;
+      d.c_z0 = img;
+      chk(launch_gemm(d, st), "resnet conv3x3");
+    };
+    for (size_t j = 0; j < h->stages[s].size(); ++j) {
+      ResBlock& rb = h->stages[s][j];
+      if (rb.has_sc) {
+        // down-sampling block: reads the previous stage's image with stride 2 (tab2)
+        const int Wp = h->sW[s - 1], Cpv = h->sC[s - 1];
+        const int64_t pimg = h->simg[s - 1];
+        float* midb = h->sbuf[s][0];
+        float* outb = h->sbuf[s][1];
+        float* scb = h->sbuf[s][2];
+        dzn_gemm_desc d = gd(h, prev, rb.c1.l, midb + interior, M, 0, 0);
+        d.a_rowoff = h->tab2[s];
+        d.c_rowoff = h->tab1[s];
+        d.kc = 3 * Cpv;
+        d.ldk = (int64_t)(Wp + 2) * Cpv;
+        d.act = DZN_ACT_RELU;
+        d.nz = B;
+        d.a_z0 = pimg;
+        d.c_z0 = img;
+        chk(launch_gemm(d, st), "resnet conv3x3 s2");
+        dzn_gemm_desc e = gd(h, prev + ((int64_t)(Wp + 2) + 1) * Cpv, rb.sc.l, scb + interior, M, 0, 0);
+        e.a_rowoff = h->tab2[s];
+        e.c_rowoff = h->tab1[s];
+        e.nz = B;
+        e.a_z0 = pimg;
+        e.c_z0 = img;
+        chk(launch_gemm(e, st), "resnet shortcut");
+        conv3(midb, rb.c2, outb, scb, DZN_ACT_NONE, 1);
+        cur = 1;
+      } else {
+        float* inb = h->sbuf[s][cur];
+        float* midb = h->sbuf[s][(cur + 1) % 3];
+        float* outb = h->sbuf[s][(cur + 2) % 3];
+        conv3(inb, rb.c1, midb, nullptr, DZN_ACT_RELU, 0);
+        conv3(midb, rb.c2, outb, inb, DZN_ACT_NONE, 1);
+        cur = (cur + 2) % 3;
+      }
+    }
+    prev = h->sbuf[s][cur];
+    if (s == 0 && h->debug) {
+      // interior of stage-1 output of image 0 as [H*W, C] is not contiguous; tap a row strip
+      tap(h, "stage1_row1", prev + interior, h->sW[0], h->sC[0], h->sC[0], st);
+    }
+  }
+  // ---- TSTP pooling for all S masks + seg_1 ----
+  const int feat = h->sC[3] * h->sH[3];
+  chk(launch_stats_pool(prev, B, h->sH[3], h->sW[3], h->sC[3], masks, S, L, h->pool, st), "stats_pool");
+  tap(h, "pool", h->pool, (int64_t)B * S, 2 * feat, 2 * feat, st);
+  {
+    dzn_gemm_desc d = gd(h, h->pool, h->seg1, d_emb, (int64_t)B * S, 2 * feat, c.embed_out_dim);
+    d.precision = DZN_PREC_F32;
+    chk(launch_gemm(d, st), "seg_1");
+  }
+}
+
+template <typename F>
+int guarded(H* h, F&& f) {
+  try {
+    f();
+    return DZN_OK;
+  } catch (const EngineError& e) {
+    if (h) h->err = e.what();
+    else last_create_error = e.what();
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    if (h) h->err = "host allocation failed";
+    return DZN_E_NOMEM;
+  } catch (const std::exception& e) {
+    if (h) h->err = e.what();
+    return DZN_E_INVALID;
+  }
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+int dzn_create(const dzn_config* cfg, dzn_handle** out) {
+  if (!cfg || !out) return DZN_E_INVALID;
+  if (cfg->struct_size != (int32_t)sizeof(dzn_config)) {
+    last_create_error = "dzn_config.struct_size mismatch (ABI)";
+    return DZN_E_INVALID;
+  }
+  if (cfg->max_batch < 1 || cfg->max_samples < 400 ||
+      (cfg->precision != DZN_PREC_F32 && cfg->precision != DZN_PREC_BF16)) {
+    last_create_error = "bad max_batch / max_samples / precision";
+    return DZN_E_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    last_create_error = "no HIP device visible (libdzn_hip has no CPU fallback)";
+    return DZN_E_HIP;
+  }
+  dzn_handle* h = new (std::nothrow) dzn_handle();
+  if (!h) return DZN_E_NOMEM;
+  h->cfg = *cfg;
+  const char* dbg = getenv("DZN_DEBUG_TAPS");
+  h->debug = dbg && dbg[0] == '1';
+  *out = h;
+  return DZN_OK;
+}
+
+int dzn_load_tensor(dzn_handle* h, const char* key, const void* host_ptr, const int64_t* shape,
+                    int32_t ndim, int32_t dtype) {
+  if (!h || !key || (!host_ptr && ndim > 0) || ndim < 0 || ndim > 8) return DZN_E_INVALID;
+  if (h->finalized) {
+    h->err = "dzn_load_tensor after dzn_finalize_weights";
+    return DZN_E_STATE;
+  }
+  return guarded(h, [&] {
+    HostT t;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+      if (shape[i] < 0) throw EngineError(DZN_E_INVALID, "negative dimension");
+      t.shape.push_back(shape[i]);
+      n *= shape[i];
+    }
+    t.v.resize((size_t)n);
+    if (dtype == DZN_F32) {
+      memcpy(t.v.data(), host_ptr, (size_t)n * 4);
+    } else if (dtype == DZN_F64) {
+      const double* p = static_cast<const double*>(host_ptr);
+      for (int64_t i = 0; i < n; ++i) t.v[(size_t)i] = (float)p[i];
+    } else if (dtype == DZN_I64) {
+      const int64_t* p = static_cast<const int64_t*>(host_ptr);
+      for (int64_t i = 0; i < n; ++i) t.v[(size_t)i] = (float)p[i];
+    } else {
+      throw EngineError(DZN_E_INVALID, "unsupported dtype");
+    }
+    h->sd[key] = std::move(t);
+  });
+}
+
+int dzn_finalize_weights(dzn_handle* h) {
+  if (!h) return DZN_E_INVALID;
+  if (h->finalized) {
+    h->err = "already finalized";
+    return DZN_E_STATE;
+  }
+  int rc = guarded(h, [&] {
+    finalize_seg(h);
+    h->has_emb = h->cfg.has_embedding != 0;
+    if (h->has_emb) finalize_emb(h);
+    HIPCHK(hipDeviceSynchronize());
+  });
+  if (rc == DZN_OK) {
+    h->finalized = true;
+    h->ignored = (int)h->sd.size() - (int)h->used.size();
+    h->sd.clear();
+  }
+  return rc;
+}
+
+int dzn_num_frames(const dzn_handle* h, int32_t num_samples) {
+  if (!h) return DZN_E_INVALID;
+  int n = num_samples;
+  for (int i = 0; i < h->cfg.n_conv; ++i) n = conv_out(n, h->cfg.conv_k[i], h->cfg.conv_s[i]);
+  return n;
+}
+
+int dzn_segment_forward(dzn_handle* h, const float* d_wave, int32_t B, int32_t N, float* d_logp,
+                        uint8_t* d_multilabel, void* hip_stream) {
+  if (!h) return DZN_E_INVALID;
+  if (!h->finalized) {
+    h->err = "dzn_segment_forward before dzn_finalize_weights";
+    return DZN_E_STATE;
+  }
+  if (!d_wave || B < 1 || B > h->cfg.max_batch || N > h->cfg.max_samples || N < 1) {
+    h->err = "bad B / N (exceeds max_batch / max_samples?)";
+    return DZN_E_INVALID;
+  }
+  return guarded(h, [&] {
+    seg_forward(h, d_wave, B, N, d_logp, d_multilabel, reinterpret_cast<hipStream_t>(hip_stream));
+  });
+}
+
+int dzn_embed_forward(dzn_handle* h, const float* d_wave, const float* d_masks, int32_t B, int32_t S,
+                      int32_t N, int32_t L, float* d_emb, void* hip_stream) {
+  if (!h) return DZN_E_INVALID;
+  if (!h->finalized || !h->has_emb) {
+    h->err = "embedding model not loaded / not finalized";
+    return DZN_E_STATE;
+  }
+  if (!d_wave || !d_masks || !d_emb || B < 1 || B > h->cfg.max_batch || N > h->cfg.max_samples ||
+      L < 1) {
+    h->err = "bad arguments to dzn_embed_forward";
+    return DZN_E_INVALID;
+  }
+  return guarded(h, [&] {
+    emb_forward(h, d_wave, d_masks, B, S, N, L, d_emb, reinterpret_cast<hipStream_t>(hip_stream));
+  });
+}
+
+int dzn_debug_fetch(dzn_handle* h, const char* name, float* host_out, int64_t cap, int64_t* n_elems) {
+  if (!h || !name) return DZN_E_INVALID;
+  auto it = h->taps.find(name);
+  if (it == h->taps.end()) {
+    h->err = std::string("no such tap (set DZN_DEBUG_TAPS=1 before dzn_create): ") + name;
+    return DZN_E_INVALID;
+  }
+  if (n_elems) *n_elems = (int64_t)it->second.size();
+  if (host_out) {
+    if (cap < (int64_t)it->second.size()) return DZN_E_INVALID;
+    memcpy(host_out, it->second.data(), it->second.size() * 4);
+  }
+  return DZN_OK;
+}
+
+int dzn_num_ignored(const dzn_handle* h) { return h ? h->ignored : 0; }
+int64_t dzn_workspace_bytes(const dzn_handle* h) { return h ? h->bytes : 0; }
+
+const char* dzn_last_error(const dzn_handle* h) {
+  return h ? h->err.c_str() : last_create_error.c_str();
+}
+
+int dzn_destroy(dzn_handle* h) {
+  if (!h) return DZN_OK;
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+  return DZN_OK;
+}
+
+const char* dzn_version(void) { return "dzn-hip 0.1.0 (gfx950, MFMA f32/bf16)"; }
+
+int dzn_op_relpos_bucket(int32_t rel, int32_t num_buckets, int32_t max_distance) {
+  return relpos_bucket(rel, num_buckets, max_distance);
+}
+
+}  // extern "C"

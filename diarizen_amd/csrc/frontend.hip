@@ -1,0 +1,240 @@
+// frontend.hip — first layer of the WavLM convolutional feature extractor, plus the small
+// glue kernels around the encoder.
+//
+// conv0 (W2V/components.py:119-122 with Conv1d(1 -> C0, k=10, s=5, bias=False)):
+//   large : [waveform LayerNorm over the window, W2V/model.py:113] -> conv -> LayerNorm over the
+//           C0 channels of every frame (components.py:63-70) -> erf-GELU   (all fused here)
+//   base  : conv (raw) ; GroupNorm(C0, C0) = per-channel norm over TIME (components.py:1248-1253)
+//           needs whole-window statistics -> col_stats_kernel + gn_gelu_kernel
+// The stage is HBM-write bound (0.5 MB in, C0*T0*4 B out per window).  Layout: channels-last
+// [B, T0, Cp] so that the next conv is a plain contraction over overlapping rows.  A workgroup
+// stages a run of normalised samples in LDS (coalesced), every lane keeps its channels' 10 taps
+// in registers, a wavefront produces one frame per iteration and stores 256 contiguous bytes
+// per channel group.
+#include "common.h"
+
+namespace {
+
+constexpr int FR_PER_BLOCK = 64;   // frames per workgroup (16 per wavefront)
+
+template <int CPL, bool LN>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wave, int N,
+                                                    const float* __restrict__ stats,  // [B,2] or null
+                                                    const float* __restrict__ w,      // [C0, k]
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int C0, int Cp,
+                                                    int k, int s, int T0, float eps,
+                                                    float* __restrict__ out) {
+  __shared__ float sx[FR_PER_BLOCK * 8 + 32];
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * FR_PER_BLOCK;
+  const int tid = threadIdx.x, lane = tid & 63, wave_id = tid >> 6;
+  const float mean = stats ? stats[2 * b] : 0.f;
+  const float rstd = stats ? stats[2 * b + 1] : 1.f;
+  const int nfr = min(FR_PER_BLOCK, T0 - f0);
+  const int nsamp = (nfr - 1) * s + k;
+  const float* wp = wave + (int64_t)b * N + (int64_t)f0 * s;
+  for (int i = tid; i < nsamp; i += 256) sx[i] = (wp[i] - mean) * rstd;
+
+  float wr[CPL][10];
+  float gr[CPL], br[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int c = lane + 64 * j;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) wr[j][t] = (c < C0 && t < k) ? w[c * k + t] : 0.f;
+    gr[j] = (LN && c < C0) ? gamma[c] : 1.f;
+    br[j] = (LN && c < C0) ? beta[c] : 0.f;
+  }
+  __syncthreads();
+
+  for (int f = wave_id; f < nfr; f += 4) {
+    float xv[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) xv[t] = t < k ? sx[f * s + t] : 0.f;
+    float acc[CPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < 10; ++t) a = fmaf(xv[t], wr[j][t], a);
+      acc[j] = a;
+      sum += a;  // channels >= C0 have zero taps -> contribute 0
+    }
+    float* op = out + ((int64_t)b * T0 + f0 + f) * Cp;
+    if constexpr (LN) {
+      const float mu = wave_sum(sum) / (float)C0;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const float d = (lane + 64 * j < C0) ? acc[j] - mu : 0.f;
+        sq += d * d;
+      }
+      const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)C0 + eps);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C0)
+          op[c] = gelu_erf((acc[j] - mu) * rs * gr[j] + br[j]);
+        else if (c < Cp)
+          op[c] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C0)
+          op[c] = acc[j];
+        else if (c < Cp)
+          op[c] = 0.f;
+      }
+    }
+  }
+}
+
+// per (b, channel) mean / rstd over the T rows of x [B, T, ld]  (GroupNorm(C, C) statistics)
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, int T, int C,
+                                                        int64_t ld, float eps,
+                                                        float* __restrict__ stats /* [B, C, 2] */) {
+  // block = 64 channels x 4 row-phases
+  __shared__ float red[4][64];
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ph = threadIdx.x >> 6;
+  const float* xp = x + (int64_t)b * T * ld;
+  float s = 0.f;
+  if (c < C)
+    for (int t = ph; t < T; t += 4) s += xp[(int64_t)t * ld + c];
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] +
+                      red[3][threadIdx.x & 63]) / (float)T;
+  __syncthreads();
+  float q = 0.f;
+  if (c < C)
+    for (int t = ph; t < T; t += 4) {
+      const float d = xp[(int64_t)t * ld + c] - mean;
+      q += d * d;
+    }
+  red[ph][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (ph == 0 && c < C) {
+    const float var = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                       red[3][threadIdx.x]) / (float)T;
+    stats[((int64_t)b * C + c) * 2] = mean;
+    stats[((int64_t)b * C + c) * 2 + 1] = 1.0f / sqrtf(var + eps);
+  }
+}
+
+// x[b,t,c] = gelu((x - mean[b,c]) * rstd[b,c] * gamma[c] + beta[c]) in place
+__global__ __launch_bounds__(256) void gn_gelu_kernel(float* __restrict__ x, int T, int C, int64_t ld,
+                                                      const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta) {
+  const int b = blockIdx.y;
+  const int64_t n = (int64_t)T * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i / C), c = (int)(i - (int64_t)t * C);
+    float* p = x + ((int64_t)b * T + t) * ld + c;
+    const float mu = stats[((int64_t)b * C + c) * 2], rs = stats[((int64_t)b * C + c) * 2 + 1];
+    *p = gelu_erf((*p - mu) * rs * gamma[c] + beta[c]);
+  }
+}
+
+// xpad[b, t + pad, :] = x[b, t, :], zero borders (input of the positional conv)
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ x,
+                                                       float* __restrict__ xpad, int L, int Lp,
+                                                       int pad, int D4) {
+  const int b = blockIdx.y;
+  const int64_t n = (int64_t)Lp * D4;
+  const float4* xs = reinterpret_cast<const float4*>(x) + (int64_t)b * L * D4;
+  float4* xd = reinterpret_cast<float4*>(xpad) + (int64_t)b * Lp * D4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i / D4) - pad;
+    const int c = (int)(i % D4);
+    xd[i] = (t >= 0 && t < L) ? xs[(int64_t)t * D4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// ws = (init ? 0 : ws) + w * x   (layer-weighted sum, model_wavlm_conformer.py:236,253-254)
+__global__ __launch_bounds__(256) void ws_accum_kernel(const float* __restrict__ x,
+                                                       float* __restrict__ ws, float w, int init,
+                                                       int64_t n4) {
+  const float4* xs = reinterpret_cast<const float4*>(x);
+  float4* wd = reinterpret_cast<float4*>(ws);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = xs[i];
+    float4 a = init ? make_float4(0.f, 0.f, 0.f, 0.f) : wd[i];
+    a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
+    wd[i] = a;
+  }
+}
+
+// y[r, c] = x[r, c] * scale[c]  (dummy_weight, components.py:208), columns >= C untouched
+__global__ __launch_bounds__(256) void col_scale_kernel(float* __restrict__ x, int64_t rows, int C,
+                                                        int64_t ld, const float* __restrict__ scale) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    x[r * ld + c] *= scale[c];
+  }
+}
+
+inline unsigned grid_for(int64_t n, int per = 256, int cap = 4096) {
+  int64_t g = cdiv64(n, per);
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+int launch_conv0(const float* wave, int B, int N, const float* stats, const float* w,
+                 const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
+                 int layer_norm, float eps, float* out, hipStream_t st) {
+  if (k > 10 || C0 > 512 || s > 8) return DZN_E_INVALID;
+  dim3 grid((T0 + FR_PER_BLOCK - 1) / FR_PER_BLOCK, B);
+  const int cpl = (max(C0, Cp) + 63) / 64;
+#define DZN_C0(CPLV)                                                                              \
+  do {                                                                                            \
+    if (layer_norm)                                                                               \
+      hipLaunchKernelGGL((conv0_kernel<CPLV, true>), grid, dim3(256), 0, st, wave, N, stats, w,   \
+                         gamma, beta, C0, Cp, k, s, T0, eps, out);                                \
+    else                                                                                          \
+      hipLaunchKernelGGL((conv0_kernel<CPLV, false>), grid, dim3(256), 0, st, wave, N, stats, w,  \
+                         gamma, beta, C0, Cp, k, s, T0, eps, out);                                \
+  } while (0)
+  if (cpl <= 1) DZN_C0(1);
+  else if (cpl <= 2) DZN_C0(2);
+  else if (cpl <= 4) DZN_C0(4);
+  else DZN_C0(8);
+#undef DZN_C0
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_groupnorm_gelu(float* x, int B, int T, int C, int64_t ld, const float* gamma,
+                          const float* beta, float eps, float* stats, hipStream_t st) {
+  hipLaunchKernelGGL(col_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, T, C, ld, eps,
+                     stats);
+  hipLaunchKernelGGL(gn_gelu_kernel, dim3(grid_for((int64_t)T * C), B), dim3(256), 0, st, x, T, C,
+                     ld, stats, gamma, beta);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_pad_rows(const float* x, float* xpad, int B, int L, int Lp, int pad, int D,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for((int64_t)Lp * (D / 4)), B), dim3(256), 0, st, x,
+                     xpad, L, Lp, pad, D / 4);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_ws_accum(const float* x, float* ws, float w, int init, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(ws_accum_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, ws, w, init, n / 4);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_col_scale(float* x, int64_t rows, int C, int64_t ld, const float* scale, hipStream_t st) {
+  hipLaunchKernelGGL(col_scale_kernel, dim3(grid_for(rows * C)), dim3(256), 0, st, x, rows, C, ld,
+                     scale);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}

@@ -1,0 +1,148 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+Generates the golden fixtures under tests/golden/ by running the REFERENCE's own modules
+(imported from /root/reference, CPU fp32) on seeded inputs and seeded random weights.
+Run in the build container only (the GPU box has no /root/reference):
+
+    python oracle/gen_golden.py            # all fixtures
+    python oracle/gen_golden.py seg emb    # a subset
+
+What imports and what does not: the arithmetic modules import
+(diarizen.models.module.wav2vec2, conformer, wespeaker/resnet.py, pooling.py, powerset.py,
+VBx.py); the wrappers that need pyannote.core / lightning / torchaudio do not, so the few
+glue lines around them (Model.forward, model_wavlm_conformer.py:250-262) are restated here
+and cited.  The fixtures pin oracle/*.py; the HIP path is then checked against the oracle
+and, at the fixture sizes, directly against these files.
+"""
+from __future__ import annotations
+
+import importlib.util
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference")
+GOLD = ROOT / "tests" / "golden"
+sys.path.insert(0, str(ROOT))
+
+from diarizen_amd.configs import get_seg_config  # noqa: E402
+from oracle import seg_model  # noqa: E402
+
+
+def _ref_path():
+    if not REF.exists():
+        raise SystemExit("/root/reference not present: golden fixtures can only be generated "
+                         "in the build container")
+    if str(REF) not in sys.path:
+        sys.path.insert(0, str(REF))
+
+
+def _load_by_path(name: str, path: Path, stubs: dict | None = None):
+    """import a reference file by path with stub parent packages (pyannote.* is not installed)."""
+    for k, v in (stubs or {}).items():
+        sys.modules.setdefault(k, v)
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def synth_wave(B: int, N: int, seed: int) -> torch.Tensor:
+    """deterministic speech-like test signal: amplitude-modulated noise + tones, |x| < 1"""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(N) / 16000.0
+    x = 0.05 * torch.randn(B, N, generator=g)
+    for b in range(B):
+        f0 = 90.0 + 40.0 * b
+        env = (torch.sin(2 * np.pi * (0.7 + 0.3 * b) * t) > -0.2).float()
+        x[b] += 0.2 * env * torch.sin(2 * np.pi * f0 * t) + 0.1 * env * torch.sin(2 * np.pi * 3.1 * f0 * t)
+    return x.clamp(-1, 1)
+
+
+# ------------------------------------------------------------------ segmentation model
+def build_reference_seg(cfg, sd):
+    """Reference modules wired as Model.__init__ does (model_wavlm_conformer.py:58-76)."""
+    _ref_path()
+    from diarizen.models.module.wav2vec2.model import wav2vec2_model
+    from diarizen.models.module.wavlm_config import get_config
+    from diarizen.models.module.conformer import ConformerEncoder
+    import torch.nn as nn
+
+    if cfg.name.startswith("tiny"):
+        rc = dict(get_config("wavlm_large_s80_md" if cfg.extractor_layer_norm else "wavlm_base_s80_md"))
+        rc["extractor_conv_layer_config"] = [(c, k, s) for c, k, s in
+                                             zip(cfg.conv_channels, cfg.conv_kernels, cfg.conv_strides)]
+        rc["encoder_embed_dim"] = cfg.embed_dim
+        rc["encoder_pos_conv_kernel"] = cfg.pos_conv_kernel
+        rc["encoder_pos_conv_groups"] = cfg.pos_conv_groups
+        rc["encoder_num_layers"] = cfg.n_layers
+        rc["encoder_use_attention"] = list(cfg.use_attention)
+        rc["encoder_use_feed_forward"] = [True] * cfg.n_layers
+        rc["encoder_total_num_heads"] = [cfg.total_heads] * cfg.n_layers
+        rc["encoder_remaining_heads"] = [list(h) for h in cfg.remaining_heads]
+        rc["encoder_ff_interm_features"] = list(cfg.ffn_dims)
+    else:
+        rc = get_config(cfg.name)
+    wavlm = wav2vec2_model(**rc)
+    conformer = ConformerEncoder(attention_in=cfg.attention_in, ffn_hidden=cfg.ffn_hidden,
+                                 num_head=cfg.conf_heads, num_layer=cfg.conf_layers,
+                                 kernel_size=cfg.conf_kernel, dropout=0.1, use_posi=False,
+                                 output_activate_function=False)
+    weight_sum = nn.Linear(cfg.wavlm_layer_num, 1, bias=False)
+    proj = nn.Linear(cfg.embed_dim, cfg.attention_in)
+    lnorm = nn.LayerNorm(cfg.attention_in)
+    classifier = nn.Linear(cfg.attention_in, cfg.n_classes)
+
+    def sub(prefix):
+        return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+    wavlm.load_state_dict(sub("wavlm_model."), strict=True)
+    conformer.load_state_dict(sub("conformer."), strict=True)
+    weight_sum.load_state_dict(sub("weight_sum."), strict=True)
+    proj.load_state_dict(sub("proj."), strict=True)
+    lnorm.load_state_dict(sub("lnorm."), strict=True)
+    classifier.load_state_dict(sub("classifier."), strict=True)
+    for m in (wavlm, conformer, weight_sum, proj, lnorm, classifier):
+        m.eval()
+
+    @torch.inference_mode()
+    def forward(wave):  # model_wavlm_conformer.py:250-262, waveforms[:, selected_channel, :] already applied
+        layer_reps, _ = wavlm.extract_features(wave)
+        feat = torch.stack(layer_reps, dim=-1)
+        feat = torch.squeeze(weight_sum(feat), -1)
+        out = lnorm(proj(feat))
+        out = conformer(out)
+        out = classifier(out)
+        return torch.log_softmax(out, dim=-1), layer_reps
+
+    return forward
+
+
+def gen_seg():
+    cases = [("tiny_ln", 2, 8000, 0, 11), ("tiny_gn", 2, 8000, 0, 12),
+             ("wavlm_large_s80_md", 1, 16000, 0, 13), ("wavlm_base_s80_md", 1, 16000, 0, 14)]
+    for name, B, N, wseed, xseed in cases:
+        cfg = get_seg_config(name)
+        sd = seg_model.seg_state_dict(cfg, wseed)
+        fwd = build_reference_seg(cfg, sd)
+        wave = synth_wave(B, N, xseed)
+        logp, reps = fwd(wave)
+        np.savez_compressed(GOLD / f"seg_{name}.npz", B=B, N=N, weight_seed=wseed, wave_seed=xseed,
+                            logp=logp.numpy(), rep0=reps[0].numpy(), rep_last=reps[-1].numpy())
+        print(f"seg_{name}: logp {tuple(logp.shape)} argmax hist "
+              f"{np.bincount(logp.argmax(-1).flatten().numpy(), minlength=cfg.n_classes).tolist()}")
+
+
+GENERATORS = {"seg": gen_seg}
+
+if __name__ == "__main__":
+    GOLD.mkdir(parents=True, exist_ok=True)
+    todo = sys.argv[1:] or list(GENERATORS)
+    torch.set_num_threads(8)
+    for k in todo:
+        GENERATORS[k]()

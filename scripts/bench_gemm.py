@@ -6,7 +6,7 @@ import torch
 from diarizen_amd import ops
 
 dev = torch.device("cuda:0")
-shapes = [(12768, 1024, 1024), (12768, 1770, 1024), (12768, 1024, 1770), (12768, 192, 1024),
+shapes = [(12768, 1024, 1024), (12768, 1770, 1024), (12768, 1024, 1792), (12768, 192, 1024),
           (12768, 96, 1024), (409568, 160, 1536), (2042880, 32, 288), (12768, 64, 8192)]
 for prec in (0, 1):
     for (M, N, K) in shapes:

@@ -1,0 +1,111 @@
+"""Segmentation forward through the C ABI vs (a) the golden outputs of the reference's own
+modules (tests/golden/seg_*.npz, made by oracle/gen_golden.py) and (b) the oracle restatement,
+on the same seeded weights + inputs.
+
+Tolerance, fp32 engine ("strict" mode of SURVEY.md §8d): max |d logp| <= 1e-3 and identical
+argmax (hence identical hard multilabel) on these fixtures.  bf16 engine: max |d logp| <= 5e-2,
+argmax agreement >= 99.5 %.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TAPS = ["conv0", "features", "featproj", "rep0", "layer0", "layer1", "layer2", "layer3", "wsum",
+        "head_in", "conf0", "conf1"]
+
+
+def _run_case(name, gpu, precision, want_taps=False):
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from oracle import seg_model
+    from oracle.gen_golden import synth_wave
+    cfg = get_seg_config(name)
+    g = np.load(os.path.join(GOLD, f"seg_{name}.npz"))
+    sd = seg_model.seg_state_dict(cfg, int(g["weight_seed"]))
+    wave = synth_wave(int(g["B"]), int(g["N"]), int(g["wave_seed"]))
+    if want_taps:
+        os.environ["DZN_DEBUG_TAPS"] = "1"
+    try:
+        eng = Engine(cfg, sd, max_batch=int(g["B"]), max_samples=int(g["N"]), precision=precision,
+                     device=gpu)
+    finally:
+        os.environ.pop("DZN_DEBUG_TAPS", None)
+    logp, ml = eng.segment(wave.to(gpu))
+    torch.cuda.synchronize()
+    return cfg, sd, wave, g, eng, logp.cpu(), ml.cpu()
+
+
+def _tap_report(cfg, sd, wave, eng):
+    from oracle import seg_model
+    taps = {}
+    seg_model.seg_forward(sd, cfg, wave, taps)
+    taps["rep0"] = None
+    lines = []
+    for k in TAPS:
+        if k not in taps or taps[k] is None:
+            continue
+        try:
+            got = eng.debug_fetch(k)
+        except Exception as e:  # noqa
+            lines.append(f"{k}: <no tap> {e}")
+            continue
+        ref = taps[k].numpy().reshape(-1)
+        if got.size != ref.size:
+            lines.append(f"{k}: size {got.size} vs {ref.size}")
+            continue
+        lines.append(f"{k}: max|d|={np.abs(got - ref).max():.3e} ref max={np.abs(ref).max():.3e}")
+    return "\n".join(lines)
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
+def test_seg_fp32_matches_reference_golden(built_lib, gpu, name):
+    cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, "f32", want_taps=True)
+    ref = torch.from_numpy(g["logp"])
+    err = (logp - ref).abs().max().item()
+    report = _tap_report(cfg, sd, wave, eng) if err > 1e-3 else ""
+    assert err <= 1e-3, f"max |dlogp| = {err}\n{report}"
+    assert torch.equal(logp.argmax(-1), ref.argmax(-1))
+    # hard multilabel == Powerset.to_multilabel(soft=False) of the reference log-probs
+    from oracle import seg_model
+    exp_ml = seg_model.to_multilabel(ref, cfg).to(torch.uint8)
+    assert torch.equal(ml, exp_ml)
+    assert eng.num_ignored_keys <= cfg.conf_layers  # only BatchNorm.num_batches_tracked is unused
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "wavlm_large_s80_md"])
+def test_seg_bf16_within_tolerance(built_lib, gpu, name):
+    cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, "bf16")
+    ref = torch.from_numpy(g["logp"])
+    err = (logp - ref).abs().max().item()
+    agree = (logp.argmax(-1) == ref.argmax(-1)).float().mean().item()
+    assert err <= 5e-2, f"max |dlogp| = {err}"
+    assert agree >= 0.995
+
+
+def test_seg_batch_and_ragged_lengths(built_lib, gpu):
+    """windows are independent: a batch equals its items run alone; shorter N re-uses the engine."""
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from oracle import seg_model
+    from oracle.gen_golden import synth_wave
+    cfg = get_seg_config("tiny_ln")
+    sd = seg_model.seg_state_dict(cfg, 0)
+    eng = Engine(cfg, sd, max_batch=5, max_samples=12000, precision="f32", device=gpu)
+    wave = synth_wave(5, 12000, 3).to(gpu)
+    full, _ = eng.segment(wave)
+    one, _ = eng.segment(wave[2:3].contiguous())
+    torch.cuda.synchronize()
+    assert (full[2:3] - one).abs().max().item() < 1e-5
+    short = wave[:, :7000].contiguous()
+    lp, ml = eng.segment(short)
+    torch.cuda.synchronize()
+    ref = seg_model.seg_forward(sd, cfg, short.cpu())
+    assert lp.shape == ref.shape
+    assert (lp.cpu() - ref).abs().max().item() < 1e-3
+    with pytest.raises(Exception):
+        eng.segment(torch.zeros(6, 12000, device=gpu))  # B > max_batch must fail loudly
