@@ -95,6 +95,9 @@ int dzn_op_attention(const float* qkv, float* out, const float* gate, const floa
                      int32_t Htot, int32_t ldqkv, int32_t ldo, float scale,
                      int32_t precision, void* stream);
 
+/* host-side relative-position bucket of WavLM (W2V/components.py:629-666), exposed for tests */
+int dzn_op_relpos_bucket(int32_t rel, int32_t num_buckets, int32_t max_distance);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,7 +138,80 @@ def gen_seg():
               f"{np.bincount(logp.argmax(-1).flatten().numpy(), minlength=cfg.n_classes).tolist()}")
 
 
-GENERATORS = {"seg": gen_seg}
+# ------------------------------------------------------------------ embedding model
+def load_reference_resnet():
+    """wespeaker/resnet.py + blocks/pooling.py + utils/receptive_field.py by file path, with
+    stub parent packages (pyannote.* is not installed here)."""
+    _ref_path()
+    PA = REF / "pyannote-audio" / "pyannote" / "audio"
+    for pkg in ("pyannote", "pyannote.audio", "pyannote.audio.models", "pyannote.audio.models.blocks",
+                "pyannote.audio.utils", "pyannote.audio.models.embedding",
+                "pyannote.audio.models.embedding.wespeaker"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+    _load_by_path("pyannote.audio.utils.receptive_field", PA / "utils" / "receptive_field.py")
+    pooling = _load_by_path("pyannote.audio.models.blocks.pooling", PA / "models" / "blocks" / "pooling.py")
+    resnet = _load_by_path("pyannote.audio.models.embedding.wespeaker.resnet",
+                           PA / "models" / "embedding" / "wespeaker" / "resnet.py")
+    return resnet, pooling
+
+
+def gen_emb():
+    import warnings
+    from oracle import emb_model
+    resnet, pooling = load_reference_resnet()
+    sd = emb_model.emb_state_dict(0)
+    net = resnet.ResNet34(80, 256, pooling_func="TSTP", two_emb_layer=False)
+    net.load_state_dict({k[len("resnet."):]: v for k, v in sd.items()}, strict=True)
+    net.eval()
+    B, N = 2, 24000
+    wave = synth_wave(B, N, 31)
+    fb = emb_model.compute_fbank(wave)              # fbank is third-party (torchaudio): oracle's own
+    L = 74                                          # frames of a 1.5 s window in the seg model
+    g = torch.Generator().manual_seed(5)
+    masks = (torch.rand(B, 4, L, generator=g) > 0.5).float()
+    masks[0, 2] = 0.0                               # inactive speaker -> embedding == seg_1.bias
+    masks[1, 3, 5:] = 0.0                           # very few frames
+    with torch.inference_mode(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        embs = torch.stack([net(fb.clone(), weights=masks[:, s])[1] for s in range(4)], dim=1)
+        multi = net(fb.clone(), weights=masks)[1]  # (batch, speakers, frames) path of StatsPool
+    np.savez_compressed(GOLD / "emb_resnet.npz", B=B, N=N, L=L, wave_seed=31, weight_seed=0,
+                        masks=masks.numpy(), fbank=fb.numpy(), emb=embs.numpy(), emb_multi=multi.numpy())
+    print("emb_resnet:", tuple(embs.shape), "multi-vs-single max diff",
+          (embs - multi).abs().max().item(), "zero-mask == bias:",
+          (embs[0, 2] - sd["resnet.seg_1.bias"]).abs().max().item())
+
+
+def gen_statspool_powerset():
+    """Known answers from the reference's OWN unit tests, evaluated through the reference's own
+    modules: pyannote-audio/tests/test_stats_pool.py:28-131, tests/utils/test_powerset.py:29-76."""
+    _, pooling = load_reference_resnet()
+    PA = REF / "pyannote-audio" / "pyannote" / "audio"
+    sp = pooling.StatsPool()
+    x = torch.Tensor([[[2.0, 4.0], [2.0, 4.0]], [[1.0, 1.0], [1.0, 1.0]]])
+    w1 = torch.Tensor([[0.5, 0.01], [0.2, 0.1]])
+    w2 = torch.Tensor([[[0.1, 0.2], [0.2, 0.3]], [[0.001, 0.001], [0.2, 0.3]]])
+    w3 = torch.Tensor([[[0.1, 0.2, 0.3], [0.2, 0.3, 0.4]], [[0.001, 0.001, 0.002], [0.2, 0.3, 0.4]]])  # frame mismatch
+    w0 = torch.zeros(2, 2)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        outs = dict(x=x.numpy(), w1=w1.numpy(), w2=w2.numpy(), w3=w3.numpy(), w0=w0.numpy(),
+                    y_none=sp(x).numpy(), y_w1=sp(x, weights=w1).numpy(), y_w2=sp(x, weights=w2).numpy(),
+                    y_w3=sp(x, weights=w3).numpy(), y_w0=sp(x, weights=w0).numpy())
+    # powerset mapping of the reference (scipy.special + itertools inside)
+    stubs = {}
+    pw = _load_by_path("pyannote.audio.utils.powerset", PA / "utils" / "powerset.py", stubs)
+    for nc, ms in [(4, 2), (3, 2), (5, 3), (2, 1)]:
+        outs[f"mapping_{nc}_{ms}"] = pw.Powerset(nc, ms).mapping.numpy()
+    np.savez_compressed(GOLD / "statspool_powerset.npz", **outs)
+    print("statspool/powerset known answers:", {k: v.shape for k, v in outs.items() if k.startswith("y_")})
+
+
+GENERATORS = {"seg": gen_seg, "emb": gen_emb, "kat": gen_statspool_powerset}
 
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)

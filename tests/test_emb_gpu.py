@@ -1,0 +1,82 @@
+"""Embedding forward (kaldi fbank -> ResNet34 -> multi-mask TSTP -> seg_1) through the C ABI vs
+the reference's own ResNet34/StatsPool outputs (tests/golden/emb_resnet.npz) and the oracle.
+
+Tolerance (fp32 engine): fbank max |d| <= 2e-3 log-mel units (fp32 direct-DFT contraction vs fp32
+FFT; the absolute level is ~20), embedding cosine >= 0.9999 and max |d| <= 1e-4 * max|emb|; an all-zero
+mask reproduces seg_1.bias exactly (pyannote-audio/tests/test_stats_pool.py:111-131).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _engine(gpu, B, N, precision="f32", taps=False):
+    from diarizen_amd.configs import RESNET34, get_seg_config
+    from diarizen_amd.engine import Engine
+    from oracle import emb_model, seg_model
+    cfg = get_seg_config("tiny_ln")
+    if taps:
+        os.environ["DZN_DEBUG_TAPS"] = "1"
+    try:
+        return Engine(cfg, seg_model.seg_state_dict(cfg, 0), RESNET34, emb_model.emb_state_dict(0),
+                      max_batch=B, max_samples=N, precision=precision, device=gpu)
+    finally:
+        os.environ.pop("DZN_DEBUG_TAPS", None)
+
+
+def test_embedding_matches_reference_golden(built_lib, gpu):
+    from oracle import emb_model
+    from oracle.gen_golden import synth_wave
+    g = np.load(os.path.join(GOLD, "emb_resnet.npz"))
+    B, N = int(g["B"]), int(g["N"])
+    wave = synth_wave(B, N, int(g["wave_seed"]))
+    masks = torch.from_numpy(g["masks"])
+    eng = _engine(gpu, B, N, taps=True)
+    emb = eng.embed(wave.to(gpu), masks.to(gpu))
+    torch.cuda.synchronize()
+    emb = emb.cpu()
+    fb = eng.debug_fetch("fbank").reshape(g["fbank"].shape)
+    fb_err = np.abs(fb - g["fbank"]).max()
+    assert fb_err < 2e-3, f"fbank max err {fb_err}"
+    ref = torch.from_numpy(g["emb"])
+    err = (emb - ref).abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(emb.reshape(-1, 256), ref.reshape(-1, 256), dim=-1)
+    pool_ref = {}
+    emb_model.emb_forward(emb_model.emb_state_dict(0), wave, masks, pool_ref)
+    pool = eng.debug_fetch("pool").reshape(pool_ref["pool"].shape)
+    perr = np.abs(pool - pool_ref["pool"].numpy()).max()
+    rel = err / ref.abs().max().item()   # seeded He-init weights give |emb| ~ 1e3
+    assert rel < 1e-4 and cos.min().item() > 0.9999, \
+        f"emb rel err {rel}, min cos {cos.min().item()}, pool err {perr}"
+    # inactive speaker: exactly the bias
+    assert torch.equal(emb[0, 2], emb_model.emb_state_dict(0)["resnet.seg_1.bias"])
+
+
+def test_embedding_single_mask_equals_multi_mask(built_lib, gpu):
+    """drop-in form (one mask per item, PA/pipelines/speaker_verification.py:693-705) == shared trunk"""
+    from oracle.gen_golden import synth_wave
+    B, N, L = 3, 32000, 99
+    wave = synth_wave(B, N, 77).to(gpu)
+    g = torch.Generator().manual_seed(1)
+    masks = (torch.rand(B, 4, L, generator=g) > 0.4).float().to(gpu)
+    eng = _engine(gpu, B, N)
+    multi = eng.embed(wave, masks)
+    singles = torch.stack([eng.embed(wave, masks[:, s:s + 1].contiguous())[:, 0] for s in range(4)], dim=1)
+    torch.cuda.synchronize()
+    assert torch.equal(multi, singles)
+
+
+def test_embedding_rejects_too_short_waveform(built_lib, gpu):
+    """kaldi fbank asserts >= one 400-sample frame; min_num_samples' bisection relies on the raise
+    (PA/pipelines/speaker_verification.py:677-691)"""
+    eng = _engine(gpu, 1, 16000)
+    with pytest.raises(Exception):
+        eng.embed(torch.zeros(1, 399, device=gpu), torch.ones(1, 1, 10, device=gpu))
+    out = eng.embed(torch.randn(1, 1600, device=gpu) * 0.1, torch.ones(1, 1, 4, device=gpu))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()

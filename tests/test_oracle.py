@@ -1,0 +1,124 @@
+"""Pin the oracle (CPU, no GPU): the restatements under oracle/ must reproduce
+ (a) the outputs of the reference's own nn.Modules stored in tests/golden/ by oracle/gen_golden.py,
+ (b) the known-answer unit tests the reference ships for this path
+     (pyannote-audio/tests/test_stats_pool.py:28-131, tests/utils/test_powerset.py:29-76),
+ (c) for kaldi fbank (third-party torchaudio, absent here): an independent implementation
+     (transformers.audio_utils) — "parity unpinned" against torchaudio itself.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
+def test_seg_oracle_matches_reference_modules(name):
+    from diarizen_amd.configs import get_seg_config
+    from oracle import seg_model
+    from oracle.gen_golden import synth_wave
+    cfg = get_seg_config(name)
+    g = np.load(os.path.join(GOLD, f"seg_{name}.npz"))
+    sd = seg_model.seg_state_dict(cfg, int(g["weight_seed"]))
+    wave = synth_wave(int(g["B"]), int(g["N"]), int(g["wave_seed"]))
+    taps = {}
+    logp = seg_model.seg_forward(sd, cfg, wave, taps)
+    assert np.abs(logp.numpy() - g["logp"]).max() < 5e-5
+    assert np.abs(taps[f"layer{cfg.n_layers - 1}"].numpy() - g["rep_last"]).max() < 2e-4
+    assert logp.shape[1] == cfg.num_frames(int(g["N"]))
+
+
+def test_emb_oracle_matches_reference_resnet_and_pooling():
+    from oracle import emb_model
+    g = np.load(os.path.join(GOLD, "emb_resnet.npz"))
+    sd = emb_model.emb_state_dict(int(g["weight_seed"]))
+    fb = torch.from_numpy(g["fbank"])
+    masks = torch.from_numpy(g["masks"])
+    with torch.inference_mode():
+        out = emb_model.resnet_trunk(sd, fb)
+        B, C, H, T = out.shape
+        stats = emb_model.stats_pool(out.reshape(B, C * H, T), masks)
+        emb = torch.nn.functional.linear(stats, sd["resnet.seg_1.weight"], sd["resnet.seg_1.bias"])
+    assert np.abs(emb.numpy() - g["emb"]).max() < 2e-4
+    assert np.abs(emb.numpy() - g["emb_multi"]).max() < 2e-4
+    # all-zero mask -> exactly seg_1.bias (pyannote-audio/tests/test_stats_pool.py:111-131)
+    assert torch.equal(emb[0, 2], sd["resnet.seg_1.bias"])
+
+
+def test_stats_pool_known_answers_of_reference_tests():
+    """Values asserted by pyannote-audio/tests/test_stats_pool.py (literal expected tensors) and
+    the same inputs pushed through the reference StatsPool (golden)."""
+    from oracle.emb_model import stats_pool
+    g = np.load(os.path.join(GOLD, "statspool_powerset.npz"))
+    x = torch.from_numpy(g["x"])
+    for key, w in [("y_none", None), ("y_w1", g["w1"]), ("y_w2", g["w2"]), ("y_w3", g["w3"]), ("y_w0", g["w0"])]:
+        y = stats_pool(x, None if w is None else torch.from_numpy(w))
+        assert torch.allclose(y, torch.from_numpy(g[key]), atol=1e-6), key
+    # literals from test_stats_pool.py:28-52 (unweighted) and :111-131 (all-zero weights)
+    assert torch.allclose(stats_pool(x, None),
+                          torch.Tensor([[3.0, 3.0, 1.4142, 1.4142], [1.0, 1.0, 0.0, 0.0]]), atol=1e-4)
+    assert torch.equal(stats_pool(x, torch.zeros(2, 2)), torch.zeros(2, 4))
+    # :54-76 single-speaker weights
+    assert torch.allclose(stats_pool(x, torch.from_numpy(g["w1"])),
+                          torch.Tensor([[2.0392, 2.0392, 1.4142, 1.4142], [1.0, 1.0, 0.0, 0.0]]), atol=1e-4)
+
+
+def test_powerset_mapping_matches_reference():
+    from oracle.seg_model import powerset_mapping
+    g = np.load(os.path.join(GOLD, "statspool_powerset.npz"))
+    for nc, ms in [(4, 2), (3, 2), (5, 3), (2, 1)]:
+        assert np.array_equal(powerset_mapping(nc, ms).numpy(), g[f"mapping_{nc}_{ms}"])
+    m = powerset_mapping(4, 2)
+    assert m.shape == (11, 4)
+    # class order: {}, {0},{1},{2},{3},{0,1},{0,2},{0,3},{1,2},{1,3},{2,3}
+    assert m[7].tolist() == [1, 0, 0, 1] and m[10].tolist() == [0, 0, 1, 1]
+
+
+def test_fbank_cross_check_transformers():
+    """kaldi fbank restatement vs transformers.audio_utils (independent code path)."""
+    au = pytest.importorskip("transformers.audio_utils")
+    from oracle import emb_model
+    from oracle.gen_golden import synth_wave
+    wave = synth_wave(1, 16000, 5)[0] * (1 << 15)
+    mine = emb_model.kaldi_fbank(wave).numpy()
+    filt = au.mel_filter_bank(num_frequency_bins=257, num_mel_filters=80, min_frequency=20.0,
+                              max_frequency=8000.0, sampling_rate=16000, norm=None, mel_scale="kaldi",
+                              triangularize_in_mel_space=True)
+    win = au.window_function(400, "hamming", periodic=False)
+    other = au.spectrogram(wave.numpy().astype(np.float64), win, frame_length=400, hop_length=160,
+                           fft_length=512, power=2.0, center=False, preemphasis=0.97,
+                           mel_filters=filt, log_mel="log", mel_floor=1.192092955078125e-07,
+                           remove_dc_offset=True).T
+    assert mine.shape == other.shape == (98, 80)
+    assert np.abs(mine - other).max() < 5e-3      # log-mel units; fp32 vs fp64 pipeline
+
+
+def test_relpos_bucket_c_matches_torch(built_lib):
+    """host C++ bucket function (engine.cpp) vs the reference formula evaluated by torch."""
+    import ctypes as C
+    from oracle.seg_model import relpos_bucket
+    fn = built_lib.dzn_op_relpos_bucket
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_int32] * 3
+    rel = torch.arange(-1700, 1701)
+    ref = relpos_bucket(rel, 320, 800).tolist()
+    got = [fn(int(r), 320, 800) for r in rel.tolist()]
+    assert got == ref
+
+
+def test_c_abi_exports_every_declared_symbol(built_lib):
+    import re
+    from diarizen_amd import _lib
+    root = os.path.join(os.path.dirname(__file__), "..", "include")
+    names = set()
+    for hdr in ("dzn.h", "dzn_ops.h"):
+        txt = open(os.path.join(root, hdr)).read()
+        names |= set(re.findall(r"\b(dzn_[a-z0-9_]+)\s*\(", txt))
+    names -= {"dzn_handle", "dzn_config", "dzn_gemm_desc"}
+    assert names, "no declarations parsed"
+    for n in sorted(names):
+        assert hasattr(built_lib, n), f"{n} declared in include/ but not exported"
+    assert set(_lib.EXPORTED) <= names
+    assert built_lib.dzn_version().startswith(b"dzn-hip")
