@@ -83,7 +83,13 @@ class DznGemmDesc(C.Structure):
         ("a_z0", C.c_int64), ("a_z1", C.c_int64), ("w_z0", C.c_int64), ("w_z1", C.c_int64),
         ("c_z0", C.c_int64), ("c_z1", C.c_int64), ("b_z0", C.c_int64), ("b_z1", C.c_int64),
         ("precision", C.c_int32),
+        ("alg_flops", C.c_double),
     ]
+
+
+class DznProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
 
 
 def lib_path() -> Path:
@@ -124,12 +130,16 @@ def load() -> C.CDLL:
     sig("dzn_num_frames", i32, [vp, i32])
     sig("dzn_segment_forward", i32, [vp, vp, i32, i32, vp, vp, vp])
     sig("dzn_embed_forward", i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp])
+    sig("dzn_prepare_masks", i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp])
     sig("dzn_debug_fetch", i32, [vp, C.c_char_p, vp, i64, C.POINTER(i64)])
     sig("dzn_num_ignored", i32, [vp])
     sig("dzn_workspace_bytes", i64, [vp])
     sig("dzn_last_error", C.c_char_p, [vp])
     sig("dzn_destroy", i32, [vp])
     sig("dzn_version", C.c_char_p, [])
+    sig("dzn_profile_enable", i32, [i32])
+    sig("dzn_profile_collect", i32, [C.POINTER(DznProfEntry), i32, C.POINTER(i32)])
+    sig("dzn_op_relpos_bucket", i32, [i32, i32, i32])
     sig("dzn_op_gemm", i32, [C.POINTER(DznGemmDesc), vp])
     sig("dzn_op_layernorm", i32, [vp, i64, vp, i64, vp, vp, i64, i32, i32, f32, i32, vp])
     sig("dzn_op_gate", i32, [vp, i64, vp, vp, vp, vp, i64, i32, vp])
@@ -140,10 +150,25 @@ def load() -> C.CDLL:
 
 EXPORTED = [
     "dzn_create", "dzn_load_tensor", "dzn_finalize_weights", "dzn_num_frames",
-    "dzn_segment_forward", "dzn_embed_forward", "dzn_debug_fetch", "dzn_num_ignored",
+    "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_debug_fetch", "dzn_num_ignored",
     "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version",
     "dzn_op_gemm", "dzn_op_layernorm", "dzn_op_gate", "dzn_op_attention",
+    "dzn_profile_enable", "dzn_profile_collect", "dzn_op_relpos_bucket",
 ]
+
+
+def profile_enable(on: bool) -> None:
+    check(load().dzn_profile_enable(int(on)), None, "dzn_profile_enable")
+
+
+def profile_collect() -> list:
+    """[{name, launches, ms, flops, bytes}] aggregated per kernel class since the last collect."""
+    lib = load()
+    arr = (DznProfEntry * 64)()
+    n = C.c_int32(0)
+    check(lib.dzn_profile_collect(arr, 64, C.byref(n)), None, "dzn_profile_collect")
+    return [dict(name=arr[i].name.decode(), launches=arr[i].launches, ms=arr[i].ms,
+                 flops=arr[i].flops, bytes=arr[i].bytes) for i in range(min(n.value, 64))]
 
 
 def check(rc: int, handle=None, what: str = "") -> None:

@@ -255,12 +255,16 @@ int launch_attention(const float* qkv, float* out, const float* gate, const floa
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  // algorithmic flops: QK^T and PV, 2*L*L*64 each per (batch, head)
+  const int pid = prof_begin(s, bias ? "attention_relpos_f32" : "attention_f32",
+                             4.0 * B * h * (double)L * L * 64.0, 0.0);
   if (bias)
     hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), lds, s, qkv, out, gate, table,
                        head_idx, B, L, h, Htot, ldqkv, ldo, scale);
   else
     hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), lds, s, qkv, out, gate, table,
                        head_idx, B, L, h, Htot, ldqkv, ldo, scale);
+  prof_end(pid, s);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 

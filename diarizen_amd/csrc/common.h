@@ -90,5 +90,14 @@ int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* 
 int launch_stats_pool(const float* img, int B, int H, int W, int C, const float* masks, int S, int L,
                       float* stats, hipStream_t st);
 
+// post.hip
+int launch_prepare_masks(const uint8_t* ml, int B, int L, int S, int median, int exclude_overlap,
+                         int min_num_frames, uint8_t* filtered, float* masks, hipStream_t st);
+
+// prof.cpp
+bool prof_enabled();
+int prof_begin(hipStream_t st, const char* cls, double flops, double bytes);
+void prof_end(int id, hipStream_t st);
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

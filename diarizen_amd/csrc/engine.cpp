@@ -50,7 +50,8 @@ struct Lin {       // y = x W^T + b with W [N, K] (rows zero-padded to Np, cols 
   float* W = nullptr;
   u16* W16 = nullptr;
   float* b = nullptr;
-  int N = 0, K = 0;  // padded sizes
+  int N = 0, K = 0;    // padded sizes
+  int Nt = 0, Kt = 0;  // reference (un-padded) sizes, for algorithmic flop accounting
 };
 
 struct LNp {
@@ -200,6 +201,8 @@ Lin make_lin(H* h, const std::vector<float>& W, const float* bias, int N, int K,
   Lin l;
   l.N = Np;
   l.K = Kp;
+  l.Nt = N;
+  l.Kt = K;
   l.W = upload(h, wp);
   if (h->cfg.precision == DZN_PREC_BF16) l.W16 = upload_bf16(h, wp);
   if (bias) {
@@ -290,6 +293,7 @@ void finalize_seg(H* h) {
         for (int j = 0; j < k; ++j)
           wp[((size_t)o * k + j) * cip + ii] = w.v[((size_t)o * ci + ii) * k + j];
     h->conv[i] = make_lin(h, wp, nullptr, co, k * cip, h->Cp[i], k * cip);
+    h->conv[i].Kt = k * ci;
     if (c.extractor_layer_norm) h->conv_ln[i] = ln_from_sd(h, pre + ".layer_norm", co);
   }
   const int last = c.n_conv - 1;
@@ -706,6 +710,7 @@ dzn_gemm_desc gd(H* h, const float* A, const Lin& l, float* C, int64_t M, int64_
   d.nz = 1;
   d.zdiv = 1;
   d.precision = h->cfg.precision;
+  d.alg_flops = 2.0 * (double)M * l.Nt * l.Kt;  // per z
   return d;
 }
 
@@ -802,6 +807,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     d.c_z0 = (int64_t)L * D;
     d.c_z1 = cg;
     d.b_z1 = cg;
+    d.alg_flops = 2.0 * (double)L * cg * h->posconv.Kt;
     chk(launch_gemm(d, st), "pos conv");
   }
   if (!c.layer_norm_first) layernorm(h->x, D, h->x, D, h->enc_ln, ML, D, 0, st);
@@ -1159,6 +1165,18 @@ int dzn_embed_forward(dzn_handle* h, const float* d_wave, const float* d_masks, 
   }
   return guarded(h, [&] {
     emb_forward(h, d_wave, d_masks, B, S, N, L, d_emb, reinterpret_cast<hipStream_t>(hip_stream));
+  });
+}
+
+int dzn_prepare_masks(dzn_handle* h, const uint8_t* d_multilabel, int32_t B, int32_t L,
+                      int32_t median_size, int32_t exclude_overlap, int32_t min_num_frames,
+                      uint8_t* d_filtered, float* d_masks, void* hip_stream) {
+  if (!h || !d_multilabel) return DZN_E_INVALID;
+  return guarded(h, [&] {
+    chk(launch_prepare_masks(d_multilabel, B, L, h->cfg.max_speakers_per_chunk, median_size,
+                             exclude_overlap, min_num_frames, d_filtered, d_masks,
+                             reinterpret_cast<hipStream_t>(hip_stream)),
+        "prepare_masks");
   });
 }
 

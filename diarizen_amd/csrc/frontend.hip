@@ -195,6 +195,9 @@ int launch_conv0(const float* wave, int B, int N, const float* stats, const floa
   if (k > 10 || C0 > 512 || s > 8) return DZN_E_INVALID;
   dim3 grid((T0 + FR_PER_BLOCK - 1) / FR_PER_BLOCK, B);
   const int cpl = (max(C0, Cp) + 63) / 64;
+  // algorithmic HBM bytes: read the waveform once, write the fp32 [T0, C0] activations once
+  const int pid = prof_begin(st, layer_norm ? "conv0_ln_gelu" : "conv0_raw",
+                             2.0 * B * (double)T0 * C0 * k, 4.0 * B * ((double)N + (double)T0 * C0));
 #define DZN_C0(CPLV)                                                                              \
   do {                                                                                            \
     if (layer_norm)                                                                               \
@@ -209,6 +212,7 @@ int launch_conv0(const float* wave, int B, int N, const float* stats, const floa
   else if (cpl <= 4) DZN_C0(4);
   else DZN_C0(8);
 #undef DZN_C0
+  prof_end(pid, st);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 

@@ -21,6 +21,8 @@
 // of the staging pass stays conflict free too.  Global->register->LDS double buffering
 // with one barrier per K tile; workgroup ids are remapped so each XCD (private L2)
 // walks a contiguous run of tiles.
+#include <cstdio>
+
 #include "common.h"
 
 namespace {
@@ -250,7 +252,15 @@ int launch_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(tilesM * tilesN, d.nz > 0 ? d.nz : 1, 1);
+  int pid = -1;
+  if (prof_enabled()) {
+    char cls[64];
+    snprintf(cls, sizeof(cls), "gemm_%s_%dx%d", LOWP ? "bf16" : "f32", BM, BN);
+    const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
+    pid = prof_begin(s, cls, fl, 0.0);
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
+  prof_end(pid, s);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 

@@ -149,6 +149,22 @@ class Engine:
               self._h, "dzn_embed_forward")
         return out
 
+    def prepare_masks(self, multilabel: torch.Tensor, median_size: int = 11,
+                      exclude_overlap: bool = True, min_num_frames: int = -1,
+                      want_masks: bool = True):
+        """multilabel u8 [B, L, S] (device) -> (filtered u8 [B, L, S], masks f32 [B, S, L])."""
+        assert multilabel.is_cuda and multilabel.dtype == torch.uint8 and multilabel.is_contiguous()
+        B, L, S = multilabel.shape
+        filt = torch.empty_like(multilabel)
+        masks = (torch.empty((B, S, L), device=multilabel.device, dtype=torch.float32)
+                 if want_masks else None)
+        check(self.lib.dzn_prepare_masks(self._h, C.c_void_p(multilabel.data_ptr()), B, L,
+                                         int(median_size), int(exclude_overlap), int(min_num_frames),
+                                         C.c_void_p(filt.data_ptr()),
+                                         C.c_void_p(masks.data_ptr()) if masks is not None else None,
+                                         self._stream()), self._h, "dzn_prepare_masks")
+        return filt, masks
+
     def debug_fetch(self, name: str) -> np.ndarray:
         n = C.c_int64(0)
         check(self.lib.dzn_debug_fetch(self._h, name.encode(), None, 0, C.byref(n)), self._h,

@@ -1,0 +1,101 @@
+"""Sliding-window runtime: the device half of `Inference.slide` + `get_embeddings`.
+
+Mirrors (reference, PA/ = pyannote-audio/pyannote/audio/):
+  * PA/core/inference.py:237-409 `Inference.slide` with skip_aggregation=True — window
+    arithmetic :265-299 (W = floor(dur*sr), S = round(step*sr), zero-padded last window),
+    batching :316-343, powerset hard conversion :226;
+  * diarizen/pipelines/inference.py:131-132 median filter;
+  * PA/pipelines/speaker_diarization.py:268-360 `get_embeddings` (overlap-excluded masks, one
+    embedding per (window, local speaker)).
+Differences by design (MI355X-first): the recording is uploaded once and windows are strided
+views of it in HBM; segmentation -> masks -> embedding run back-to-back on the device for each
+batch of windows (no host round trip, no per-(window,speaker) crop loop), and the ResNet trunk is
+computed once per window for its 4 speaker masks.  Only u8 decisions [C, L, 4] and f32 embeddings
+[C, 4, 256] ever leave the device.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from .engine import Engine
+
+
+def window_plan(num_samples: int, window: int, step: int) -> Tuple[int, bool]:
+    """(number of full windows, has_zero_padded_last)  — PA/core/inference.py:285-299."""
+    if num_samples >= window:
+        num_chunks = (num_samples - window) // step + 1
+        has_last = (num_samples - window) % step > 0
+    else:
+        num_chunks = 0
+        has_last = True
+    return num_chunks, has_last
+
+
+@dataclass
+class SlideResult:
+    segmentations: torch.Tensor            # u8 [C, L, S] (median-filtered hard decisions), device
+    embeddings: Optional[torch.Tensor]     # f32 [C, S, dim] or None, device
+    window: int
+    step: int
+    num_frames: int
+
+
+class WindowRunner:
+    def __init__(self, engine: Engine, duration: float, step_ratio: float = 0.1, batch_size: int = 32,
+                 median_size: int = 11, exclude_overlap: bool = True, sample_rate: int = 16000):
+        self.engine = engine
+        self.sample_rate = sample_rate
+        self.duration = duration
+        self.window = int(math.floor(duration * sample_rate))               # inference.py:265
+        self.step = int(round(step_ratio * duration * sample_rate))         # :266
+        self.batch_size = min(batch_size, engine.max_batch)
+        self.median_size = median_size
+        self.exclude_overlap = exclude_overlap
+        if self.window > engine.max_samples:
+            raise ValueError("window longer than the engine's max_samples")
+        self.num_frames = engine.num_frames(self.window)
+        # minimum number of frames for the clean mask (speaker_diarization.py:274-278); the
+        # embedding model needs one 400-sample fbank frame (speaker_verification.py:677-691)
+        self.min_num_samples = 400
+        self.min_num_frames = math.ceil(self.num_frames * self.min_num_samples / self.window)
+
+    def num_windows(self, num_samples: int) -> int:
+        n, last = window_plan(num_samples, self.window, self.step)
+        return n + int(last)
+
+    def windows_view(self, wave: torch.Tensor) -> torch.Tensor:
+        """[C, W] strided view over the zero-extended recording (no copy of the samples)."""
+        assert wave.dim() == 1
+        C = self.num_windows(wave.numel())
+        need = (C - 1) * self.step + self.window
+        if need > wave.numel():
+            wave = torch.cat([wave, wave.new_zeros(need - wave.numel())])
+        return torch.as_strided(wave, (C, self.window), (self.step, 1))
+
+    def run(self, wave: torch.Tensor, with_embeddings: bool = True,
+            window_range: Optional[Tuple[int, int]] = None) -> SlideResult:
+        """wave: f32 [N_total] on the device.  window_range=(c0, c1) restricts to a contiguous
+        run of windows (multi-GPU sharding).  Enqueue only; results are device tensors."""
+        eng = self.engine
+        views = self.windows_view(wave)
+        c0, c1 = window_range if window_range is not None else (0, views.shape[0])
+        C = max(c1 - c0, 0)
+        S = eng.seg.max_speakers_per_chunk
+        seg = torch.empty((C, self.num_frames, S), device=wave.device, dtype=torch.uint8)
+        emb = (torch.empty((C, S, eng.emb.embed_dim), device=wave.device, dtype=torch.float32)
+               if with_embeddings else None)
+        for s0 in range(c0, c1, self.batch_size):
+            s1 = min(s0 + self.batch_size, c1)
+            chunk = views[s0:s1].contiguous()
+            _, ml = eng.segment(chunk, want_logp=False)
+            filt, masks = eng.prepare_masks(ml, self.median_size, self.exclude_overlap,
+                                            self.min_num_frames if self.exclude_overlap else -1,
+                                            want_masks=with_embeddings)
+            seg[s0 - c0:s1 - c0] = filt
+            if with_embeddings:
+                emb[s0 - c0:s1 - c0] = eng.embed(chunk, masks)
+        return SlideResult(seg, emb, self.window, self.step, self.num_frames)

@@ -153,6 +153,19 @@ int dzn_embed_forward(dzn_handle* h, const float* d_wave, const float* d_masks,
                       int32_t B, int32_t S, int32_t N, int32_t L, float* d_emb,
                       void* hip_stream);
 
+/*
+ * On-device glue between the two stages (keeps a window in HBM):
+ *   median filter (odd `median_size`, 0/1 = off) along frames of d_multilabel u8 [B, L, S]
+ *       <- diarizen/pipelines/inference.py:131-132 (scipy median_filter size=(1,11,1), "reflect")
+ *   embedding masks f32 [B, S, L]: overlap excluded, fallback to the full mask when the clean
+ *   mask has <= min_num_frames frames
+ *       <- PA/pipelines/speaker_diarization.py:268-322
+ * d_filtered u8 [B, L, S] (may be NULL) receives the filtered decisions, d_masks may be NULL.
+ */
+int dzn_prepare_masks(dzn_handle* h, const uint8_t* d_multilabel, int32_t B, int32_t L,
+                      int32_t median_size, int32_t exclude_overlap, int32_t min_num_frames,
+                      uint8_t* d_filtered, float* d_masks, void* hip_stream);
+
 /* Copy a named intermediate activation of the LAST forward to host (debug / parity
  * tests).  *n_elems receives the element count; host_out may be NULL to query. */
 int dzn_debug_fetch(dzn_handle* h, const char* name, float* host_out, int64_t cap,

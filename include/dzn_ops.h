@@ -66,6 +66,7 @@ typedef struct dzn_gemm_desc {
   int32_t nz, zdiv;
   int64_t a_z0, a_z1, w_z0, w_z1, c_z0, c_z1, b_z0, b_z1;
   int32_t precision;     /* DZN_PREC_* */
+  double alg_flops;      /* algorithmic flops of this launch for profiling (0 -> 2*M*N*K*nz) */
 } dzn_gemm_desc;
 
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
@@ -94,6 +95,21 @@ int dzn_op_attention(const float* qkv, float* out, const float* gate, const floa
                      const int32_t* head_idx, int32_t B, int32_t L, int32_t h,
                      int32_t Htot, int32_t ldqkv, int32_t ldo, float scale,
                      int32_t precision, void* stream);
+
+/*
+ * In-situ kernel timing (HIP events on the launch stream).  Enable, run forwards, then collect:
+ * one entry per kernel class with the number of launches, the summed event time and the summed
+ * ALGORITHMIC flops / HBM bytes declared by the launch sites (un-padded reference shapes).
+ */
+typedef struct dzn_prof_entry {
+  char name[64];
+  int64_t launches;
+  double ms;
+  double flops;
+  double bytes;
+} dzn_prof_entry;
+int dzn_profile_enable(int32_t on);
+int dzn_profile_collect(dzn_prof_entry* out, int32_t cap, int32_t* n);
 
 /* host-side relative-position bucket of WavLM (W2V/components.py:629-666), exposed for tests */
 int dzn_op_relpos_bucket(int32_t rel, int32_t num_buckets, int32_t max_distance);

@@ -27,46 +27,7 @@ EPS = torch.finfo(torch.float32).eps   # torchaudio _get_epsilon
 
 
 # --------------------------------------------------------------------------- weights
-def emb_state_dict(seed: int = 0, m: int = 32, feat_dim: int = 80, embed_dim: int = 256,
-                   num_blocks=(3, 4, 6, 3)) -> Dict[str, torch.Tensor]:
-    """Seeded random WeSpeaker-ResNet34 state_dict (keys of resnet.py:ResNet/BasicBlock)."""
-    g = torch.Generator().manual_seed(1000 + seed)
-
-    def rn(*shape, scale=1.0):
-        return torch.randn(*shape, generator=g) * scale
-
-    sd: Dict[str, torch.Tensor] = {}
-
-    def conv(name, co, ci, k):
-        sd[name + ".weight"] = rn(co, ci, k, k, scale=math.sqrt(2.0 / (ci * k * k)))
-
-    def bn(name, c):
-        sd[name + ".weight"] = 1.0 + rn(c, scale=0.1)
-        sd[name + ".bias"] = rn(c, scale=0.1)
-        sd[name + ".running_mean"] = rn(c, scale=0.1)
-        sd[name + ".running_var"] = 0.5 + torch.rand(c, generator=g)
-        sd[name + ".num_batches_tracked"] = torch.tensor(3, dtype=torch.long)
-
-    conv("resnet.conv1", m, 1, 3)
-    bn("resnet.bn1", m)
-    cin = m
-    for s, nb in enumerate(num_blocks):
-        cout = m << s
-        for j in range(nb):
-            p = f"resnet.layer{s + 1}.{j}"
-            stride = 2 if (j == 0 and s > 0) else 1
-            conv(p + ".conv1", cout, cin, 3)
-            bn(p + ".bn1", cout)
-            conv(p + ".conv2", cout, cout, 3)
-            bn(p + ".bn2", cout)
-            if stride != 1 or cin != cout:
-                conv(p + ".shortcut.0", cout, cin, 1)
-                bn(p + ".shortcut.1", cout)
-            cin = cout
-    stats_dim = (feat_dim // 8) * m * 8
-    sd["resnet.seg_1.weight"] = rn(embed_dim, stats_dim * 2, scale=1.0 / math.sqrt(stats_dim * 2))
-    sd["resnet.seg_1.bias"] = rn(embed_dim, scale=0.1)
-    return sd
+from diarizen_amd.weights import emb_state_dict  # noqa: E402,F401
 
 
 # --------------------------------------------------------------------------- kaldi fbank

@@ -21,87 +21,7 @@ P = "wavlm_model."
 
 
 # --------------------------------------------------------------------------- weights
-def seg_state_dict(cfg: SegConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """Seeded random state_dict with the exact keys/shapes of the reference Model
-    (key list: SURVEY.md §8c).  BatchNorm running stats are randomised so that BN folding
-    is exercised; LayerNorm affine params are non-trivial."""
-    g = torch.Generator().manual_seed(seed)
-
-    def rn(*shape, scale=1.0):
-        return torch.randn(*shape, generator=g) * scale
-
-    def lin(prefix, out_f, in_f, sd, bias=True, gain=1.0):
-        sd[prefix + ".weight"] = rn(out_f, in_f, scale=gain / math.sqrt(in_f))
-        if bias:
-            sd[prefix + ".bias"] = rn(out_f, scale=0.1)
-
-    def ln(prefix, n, sd):
-        sd[prefix + ".weight"] = 1.0 + rn(n, scale=0.1)
-        sd[prefix + ".bias"] = rn(n, scale=0.1)
-
-    sd: Dict[str, torch.Tensor] = {}
-    cin = 1
-    for i, (c, k) in enumerate(zip(cfg.conv_channels, cfg.conv_kernels)):
-        pre = f"{P}feature_extractor.conv_layers.{i}"
-        sd[pre + ".conv.weight"] = rn(c, cin, k, scale=1.6 / math.sqrt(cin * k))
-        if cfg.extractor_layer_norm or i == 0:
-            ln(pre + ".layer_norm", c, sd)
-        cin = c
-    sd[P + "feature_extractor.dummy_weight"] = 1.0 + rn(cin, scale=0.05)
-    D = cfg.embed_dim
-    ln(P + "encoder.feature_projection.layer_norm", cin, sd)
-    lin(P + "encoder.feature_projection.projection", D, cin, sd)
-    cg = D // cfg.pos_conv_groups
-    pc = P + "encoder.transformer.pos_conv_embed.conv"
-    sd[pc + ".bias"] = rn(D, scale=0.1)
-    sd[pc + ".parametrizations.weight.original0"] = 1.0 + 0.2 * torch.rand(1, 1, cfg.pos_conv_kernel, generator=g)
-    sd[pc + ".parametrizations.weight.original1"] = rn(D, cg, cfg.pos_conv_kernel, scale=1.0)
-    ln(P + "encoder.transformer.layer_norm", D, sd)
-    for i in range(cfg.n_layers):
-        lp = f"{P}encoder.transformer.layers.{i}"
-        heads = cfg.remaining_heads[i]
-        if heads:
-            hd = len(heads) * 64
-            for nm in ("q_proj", "k_proj", "v_proj"):
-                lin(f"{lp}.attention.{nm}", hd, D, sd, gain=1.5)
-            lin(f"{lp}.attention.out_proj", D, hd, sd, gain=0.7)
-            lin(f"{lp}.attention.gru_rel_pos_linear", 8, 64, sd)
-            sd[f"{lp}.attention.gru_rel_pos_const"] = 1.0 + rn(1, cfg.total_heads, 1, 1, scale=0.3)
-            if i == 0:
-                sd[f"{lp}.attention.rel_attn_embed.weight"] = rn(cfg.num_buckets, cfg.total_heads)
-        ln(f"{lp}.layer_norm", D, sd)
-        lin(f"{lp}.feed_forward.intermediate_dense", cfg.ffn_dims[i], D, sd)
-        lin(f"{lp}.feed_forward.output_dense", D, cfg.ffn_dims[i], sd, gain=0.7)
-        ln(f"{lp}.final_layer_norm", D, sd)
-    # head
-    sd["weight_sum.weight"] = rn(1, cfg.wavlm_layer_num, scale=1.0 / cfg.wavlm_layer_num) + 1.0 / cfg.wavlm_layer_num
-    A = cfg.attention_in
-    lin("proj", A, D, sd)
-    ln("lnorm", A, sd)
-    for i in range(cfg.conf_layers):
-        cp = f"conformer.conformer_layer.{i}"
-        for f_ in ("ffn1", "ffn2"):
-            ln(f"{cp}.{f_}.ln_norm", A, sd)
-            lin(f"{cp}.{f_}.w_1", cfg.ffn_hidden, A, sd)
-            lin(f"{cp}.{f_}.w_2", A, cfg.ffn_hidden, sd)
-        ln(f"{cp}.mha.ln_norm", A, sd)
-        for nm in ("linearQ", "linearK", "linearV", "linearO"):
-            lin(f"{cp}.mha.mha.{nm}", A, A, sd, gain=1.3)
-        ln(f"{cp}.conv.ln_norm", A, sd)
-        sd[f"{cp}.conv.pointwise_conv1.weight"] = rn(2 * A, A, 1, scale=1.0 / math.sqrt(A))
-        sd[f"{cp}.conv.pointwise_conv1.bias"] = rn(2 * A, scale=0.1)
-        sd[f"{cp}.conv.depthwise_conv.weight"] = rn(A, 1, cfg.conf_kernel, scale=1.0 / math.sqrt(cfg.conf_kernel))
-        sd[f"{cp}.conv.depthwise_conv.bias"] = rn(A, scale=0.1)
-        sd[f"{cp}.conv.bn_norm.weight"] = 1.0 + rn(A, scale=0.1)
-        sd[f"{cp}.conv.bn_norm.bias"] = rn(A, scale=0.1)
-        sd[f"{cp}.conv.bn_norm.running_mean"] = rn(A, scale=0.1)
-        sd[f"{cp}.conv.bn_norm.running_var"] = 0.5 + torch.rand(A, generator=g)
-        sd[f"{cp}.conv.bn_norm.num_batches_tracked"] = torch.tensor(7, dtype=torch.long)
-        sd[f"{cp}.conv.pointwise_conv2.weight"] = rn(A, A, 1, scale=1.0 / math.sqrt(A))
-        sd[f"{cp}.conv.pointwise_conv2.bias"] = rn(A, scale=0.1)
-        ln(f"{cp}.ln_norm", A, sd)
-    lin("classifier", cfg.n_classes, A, sd, gain=3.0)
-    return sd
+from diarizen_amd.weights import seg_state_dict  # noqa: E402,F401  (seeded random init lives in the product)
 
 
 # --------------------------------------------------------------------------- pieces
