@@ -1,0 +1,252 @@
+"""Host-side clustering of the per-(window, local speaker) embeddings.
+
+Own implementation of the behaviour of (PA/ = pyannote-audio/pyannote/audio/):
+  * BaseClustering.filter_embeddings / constrained_argmax / assign_embeddings
+        PA/pipelines/clustering.py:111-245, filter_embeddings_by_frames :47-73
+  * AgglomerativeClustering.cluster (centroid linkage on unit-normalised embeddings, distance
+    threshold, small clusters merged into the nearest large one)      :363-513
+  * VBxClustering.__call__ (AHC init -> PLDA-space VB-GMM -> constrained assignment) :632-700
+  * diarizen/clustering/VBx.py:27-194 (VBx with loopProb = 0 => GMM update branch; vbx_setup)
+This stays on the host by design (BASELINE.json north_star); scipy does linkage / Hungarian
+assignment exactly as in the reference so that cluster ids — hence RTTM labels — are equal.
+"""
+from __future__ import annotations
+
+import random
+from typing import Optional, Tuple
+
+import numpy as np
+from scipy.cluster.hierarchy import fcluster, linkage
+from scipy.linalg import eigh
+from scipy.optimize import linear_sum_assignment
+from scipy.spatial.distance import cdist
+from scipy.special import logsumexp, softmax
+
+
+# --------------------------------------------------------------------------- shared pieces
+def single_speaker_frame_mask(seg: np.ndarray, min_frames: int) -> np.ndarray:
+    """[C, L, S] -> bool [C, S]: speaker has >= min_frames frames where it is the ONLY one active."""
+    alone = np.sum(seg, axis=2, keepdims=True) == 1
+    return np.sum(seg * alone, axis=1) >= min_frames
+
+
+def filter_embeddings(embeddings: np.ndarray, seg: np.ndarray, min_frames_ratio: float = 0.1,
+                      max_num_embeddings: float = np.inf):
+    active = np.sum(seg, axis=1) > 0
+    valid = ~np.any(np.isnan(embeddings), axis=2)
+    min_frames = round(min_frames_ratio * seg.shape[1])
+    keep = active * valid * single_speaker_frame_mask(seg, min_frames)
+    ci, si = np.where(keep)
+    if len(ci) < 2:                       # too short / fully overlapped input: relax the frame rule
+        ci, si = np.where(active * valid * single_speaker_frame_mask(seg, 0))
+    n = len(ci)
+    if n > max_num_embeddings:
+        idx = list(range(n))
+        random.shuffle(idx)
+        idx = sorted(idx[: int(max_num_embeddings)])
+        ci, si = ci[idx], si[idx]
+    return embeddings[ci, si], ci, si
+
+
+def constrained_argmax(soft: np.ndarray) -> np.ndarray:
+    """per window: Hungarian assignment of local speakers to clusters (maximise similarity)."""
+    soft = np.nan_to_num(soft, nan=np.nanmin(soft))
+    C, S, _ = soft.shape
+    hard = -2 * np.ones((C, S), dtype=np.int8)
+    for c in range(C):
+        spk, clu = linear_sum_assignment(soft[c], maximize=True)
+        hard[c, spk] = clu
+    return hard
+
+
+def _soft_clusters(embeddings: np.ndarray, centroids: np.ndarray, metric: str) -> np.ndarray:
+    C, S, D = embeddings.shape
+    return 2 - cdist(embeddings.reshape(C * S, D), centroids, metric=metric).reshape(C, S, -1)
+
+
+def _set_num_clusters(n, num_clusters, min_clusters, max_clusters):
+    lo = num_clusters or min_clusters or 1
+    lo = max(1, min(n, lo))
+    hi = num_clusters or max_clusters or n
+    hi = max(1, min(n, hi))
+    if lo > hi:
+        raise ValueError(f"min_clusters must be smaller than (or equal to) max_clusters "
+                         f"(here: min_clusters={lo:g} and max_clusters={hi:g}).")
+    if lo == hi:
+        num_clusters = lo
+    return num_clusters, lo, hi
+
+
+# --------------------------------------------------------------------------- AHC
+class AgglomerativeClustering:
+    def __init__(self, metric: str = "cosine", max_num_embeddings: float = np.inf,
+                 constrained_assignment: bool = True, method: str = "centroid", threshold: float = 0.6,
+                 min_cluster_size: int = 13):
+        self.metric, self.max_num_embeddings = metric, max_num_embeddings
+        self.constrained_assignment = constrained_assignment
+        self.method, self.threshold, self.min_cluster_size = method, threshold, min_cluster_size
+
+    def cluster(self, emb: np.ndarray, min_clusters: int, max_clusters: int,
+                num_clusters: Optional[int] = None) -> np.ndarray:
+        n = emb.shape[0]
+        min_size = min(self.min_cluster_size, max(1, round(0.1 * n)))
+        if n == 1:
+            return np.zeros((1,), dtype=np.uint8)
+        if self.metric == "cosine" and self.method in ("centroid", "median", "ward"):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                emb /= np.linalg.norm(emb, axis=-1, keepdims=True)      # in place, like the reference
+            dendro = linkage(emb, method=self.method, metric="euclidean")
+        else:
+            dendro = linkage(emb, method=self.method, metric=self.metric)
+        clusters = fcluster(dendro, self.threshold, criterion="distance") - 1
+
+        def large_of(cl):
+            ids, cnt = np.unique(cl, return_counts=True)
+            return ids, cnt, ids[cnt >= min_size]
+
+        ids, cnt, large = large_of(clusters)
+        n_large = len(large)
+        if n_large < min_clusters:
+            num_clusters = min_clusters
+        elif n_large > max_clusters:
+            num_clusters = max_clusters
+        if num_clusters is not None and n_large != num_clusters:
+            # walk the dendrogram away from the threshold until the number of large clusters fits
+            by_iter = np.copy(dendro)
+            by_iter[:, 2] = np.arange(n - 1)
+            best_it, best_n = n - 1, 1
+            for it in np.argsort(np.abs(dendro[:, 2] - self.threshold)):
+                if by_iter[it, 3] < min_size:
+                    continue
+                clusters = fcluster(by_iter, it, criterion="distance") - 1
+                ids, cnt, large = large_of(clusters)
+                n_large = len(large)
+                if abs(n_large - num_clusters) < abs(best_n - num_clusters):
+                    best_it, best_n = it, n_large
+                if n_large == num_clusters:
+                    break
+            if best_n != num_clusters:
+                clusters = fcluster(by_iter, best_it, criterion="distance") - 1
+                ids, cnt, large = large_of(clusters)
+                n_large = len(large)
+        if n_large == 0:
+            clusters[:] = 0
+            return clusters
+        small = ids[cnt < min_size]
+        if len(small) == 0:
+            return clusters
+        big_c = np.vstack([np.mean(emb[clusters == k], axis=0) for k in large])
+        small_c = np.vstack([np.mean(emb[clusters == k], axis=0) for k in small])
+        nearest = np.argmin(cdist(big_c, small_c, metric=self.metric), axis=0)
+        for j, b in enumerate(nearest):
+            clusters[clusters == small[j]] = large[b]
+        _, clusters = np.unique(clusters, return_inverse=True)
+        return clusters
+
+    def __call__(self, embeddings: np.ndarray, segmentations: np.ndarray,
+                 num_clusters: Optional[int] = None, min_clusters: Optional[int] = None,
+                 max_clusters: Optional[int] = None):
+        train, ci, si = filter_embeddings(embeddings, segmentations,
+                                          max_num_embeddings=self.max_num_embeddings)
+        C, S, _ = embeddings.shape
+        num_clusters, lo, hi = _set_num_clusters(train.shape[0], num_clusters, min_clusters, max_clusters)
+        if hi < 2:
+            return (np.zeros((C, S), dtype=np.int8), np.ones((C, S, 1)),
+                    np.mean(train, axis=0, keepdims=True))
+        train_clusters = self.cluster(train, lo, hi, num_clusters=num_clusters)
+        K = int(np.max(train_clusters)) + 1
+        train = embeddings[ci, si]
+        centroids = np.vstack([np.mean(train[train_clusters == k], axis=0) for k in range(K)])
+        soft = _soft_clusters(embeddings, centroids, self.metric)
+        hard = constrained_argmax(soft) if self.constrained_assignment else np.argmax(soft, axis=2)
+        return hard, soft, centroids
+
+
+# --------------------------------------------------------------------------- VBx
+def vb_gmm(X: np.ndarray, Phi: np.ndarray, gamma: np.ndarray, Fa: float, Fb: float, max_iters: int,
+           epsilon: float = 1e-4):
+    """VBx with loopProb = 0 (the only branch the pipeline exercises, VBx.py:99-107): variational
+    Bayes mixture over speakers in PLDA space; returns responsibilities and speaker priors."""
+    D = X.shape[1]
+    pi = np.ones(gamma.shape[1]) / gamma.shape[1]
+    G = -0.5 * (np.sum(X ** 2, axis=1, keepdims=True) + D * np.log(2 * np.pi))
+    rho = X * np.sqrt(Phi)
+    prev = None
+    for it in range(max_iters):
+        invL = 1.0 / (1 + Fa / Fb * gamma.sum(axis=0, keepdims=True).T * Phi)
+        alpha = Fa / Fb * invL * gamma.T.dot(rho)
+        log_p = Fa * (rho.dot(alpha.T) - 0.5 * (invL + alpha ** 2).dot(Phi) + G)
+        lpi = np.log(pi + 1e-8)
+        log_px = logsumexp(log_p + lpi, axis=-1)
+        total = np.sum(log_px, axis=0)
+        gamma = np.exp(log_p + lpi - log_px[:, None])
+        pi = np.sum(gamma, axis=0)
+        pi = pi / pi.sum()
+        elbo = total + Fb * 0.5 * np.sum(np.log(invL) - invL - alpha ** 2 + 1)
+        if it > 0 and elbo - prev < epsilon:
+            break
+        prev = elbo
+    return gamma, pi
+
+
+def _l2n(x):
+    return x / np.linalg.norm(x, axis=1, ord=2)[:, np.newaxis]
+
+
+def load_plda(plda_dir: str):
+    """vbx_setup (VBx.py:158-194): x-vector transform + PLDA simultaneous diagonalisation."""
+    x = np.load(f"{plda_dir}/xvec_transform.npz")
+    mean1, mean2, lda = x["mean1"], x["mean2"], x["lda"]
+    p = np.load(f"{plda_dir}/plda.npz")
+    mu, tr, psi = p["mu"], p["tr"], p["psi"]
+    W = np.linalg.inv(tr.T.dot(tr))
+    Bm = np.linalg.inv((tr.T / psi).dot(tr))
+    acvar, wccn = eigh(Bm, W)
+    psi = acvar[::-1]
+    tr = wccn.T[::-1]
+
+    def xvec_tf(v):
+        return np.sqrt(lda.shape[1]) * _l2n(lda.T.dot(np.sqrt(lda.shape[0]) * _l2n(v - mean1).T).T - mean2)
+
+    def plda_tf(v, lda_dim=lda.shape[1]):
+        return (v - mu).dot(tr.T)[:, :lda_dim]
+
+    return xvec_tf, plda_tf, psi
+
+
+class VBxClustering:
+    def __init__(self, metric: str = "cosine", max_num_embeddings: float = np.inf,
+                 constrained_assignment: bool = True, plda_dir: str = "", lda_dim: int = 128,
+                 max_iters: int = 20, ahc_criterion: str = "distance", ahc_threshold: float = 0.6,
+                 Fa: float = 0.07, Fb: float = 0.8):
+        self.metric, self.max_num_embeddings = metric, max_num_embeddings
+        self.constrained_assignment = constrained_assignment
+        self.plda_dir, self.lda_dim, self.max_iters = plda_dir, lda_dim, max_iters
+        self.ahc_criterion, self.ahc_threshold, self.Fa, self.Fb = ahc_criterion, ahc_threshold, Fa, Fb
+        self._plda = None
+
+    def __call__(self, embeddings: np.ndarray, segmentations: np.ndarray, num_clusters=None,
+                 min_clusters=None, max_clusters=None):
+        train, _, _ = filter_embeddings(embeddings, segmentations, 0.1, self.max_num_embeddings)
+        C, S, D = embeddings.shape
+        if train.shape[0] < 2:
+            return (np.zeros((C, S), dtype=np.int8), np.ones((C, S, 1)),
+                    np.mean(train, axis=0, keepdims=True))
+        normed = train / np.linalg.norm(train, axis=1, keepdims=True)
+        dendro = linkage(normed, method="centroid", metric="euclidean")
+        ahc = fcluster(dendro, self.ahc_threshold, criterion=self.ahc_criterion) - 1
+        _, ahc = np.unique(ahc, return_inverse=True)
+        if self._plda is None:
+            self._plda = load_plda(self.plda_dir)
+        xvec_tf, plda_tf, psi = self._plda
+        fea = plda_tf(xvec_tf(train), lda_dim=self.lda_dim)
+        Phi = psi[: self.lda_dim]
+        q0 = np.zeros((len(ahc), ahc.max() + 1))
+        q0[range(len(ahc)), ahc.astype(int)] = 1.0
+        q0 = softmax(q0 * 7.0, axis=1)                                  # init_smoothing = 7
+        q, sp = vb_gmm(fea, Phi, q0, self.Fa, self.Fb, self.max_iters)
+        centroids = q[:, sp > 1e-7].T @ train.reshape(-1, D)            # unnormalised: cosine follows
+        soft = _soft_clusters(embeddings, centroids, self.metric)
+        hard = constrained_argmax(soft) if self.constrained_assignment else np.argmax(soft, axis=2)
+        _, hard = np.unique(hard, return_inverse=True)
+        return hard.reshape(C, S), soft, centroids

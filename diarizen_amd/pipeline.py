@@ -1,0 +1,187 @@
+"""DiariZenPipeline — drop-in for diarizen/pipelines/inference.py:26-192.
+
+Same public surface: `DiariZenPipeline.from_pretrained(repo_id, cache_dir=None, rttm_out_dir=None)`
+and `pipeline(in_wav, sess_name=None) -> Annotation` (+ RTTM file), same hub directory layout
+(`config.toml`, `pytorch_model.bin`, `plda/`), same `[inference.args]` / `[clustering.args]` keys.
+What changes is where the time goes: the recording is uploaded once, every window runs
+segmentation -> masks -> embeddings on the MI355X through libdzn_hip.so (diarizen_amd/inference.py),
+windows can be sharded over the GPUs of a node (diarizen_amd/dist.py), and the host only sees
+u8 decisions + f32 embeddings for counting / clustering / reconstruction (diarizen_amd/postprocess.py,
+diarizen_amd/clustering.py), which follow the reference arithmetic so the RTTM is equal.
+"""
+from __future__ import annotations
+
+import os
+from io import BytesIO
+from pathlib import Path
+from typing import Any, Dict, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import audio as audio_io
+from .clustering import AgglomerativeClustering, VBxClustering
+from .configs import RESNET34
+from .core import Annotation, SlidingWindow
+from .engine import Engine
+from .inference import WindowRunner
+from .models import SpeakerEmbedding, WavLMConformer, instantiate
+from .postprocess import binarize, receptive_field, reconstruct, speaker_count
+
+try:
+    import tomllib as _toml  # py311+
+except ImportError:  # pragma: no cover
+    import tomli as _toml
+
+EMBEDDING_REPO = "pyannote/wespeaker-voxceleb-resnet34-LM"
+
+
+def _load_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    if isinstance(ckpt, dict) and "state_dict" in ckpt and isinstance(ckpt["state_dict"], dict):
+        ckpt = ckpt["state_dict"]          # Lightning checkpoint (PA/core/model.py:459-473)
+    return ckpt
+
+
+class DiariZenPipeline:
+    def __init__(self, diarizen_hub, embedding_model, config_parse: Optional[Dict[str, Any]] = None,
+                 rttm_out_dir: Optional[str] = None, *, device: Optional[torch.device] = None,
+                 precision: str = "f32", seg_state: Optional[Mapping[str, torch.Tensor]] = None,
+                 emb_state: Optional[Mapping[str, torch.Tensor]] = None,
+                 config: Optional[Dict[str, Any]] = None):
+        """diarizen_hub: directory with config.toml / pytorch_model.bin / plda ; embedding_model: path of
+        the WeSpeaker checkpoint.  `seg_state` / `emb_state` / `config` let callers (tests, bench)
+        inject in-memory weights instead of files."""
+        hub = Path(diarizen_hub) if diarizen_hub is not None else None
+        if config is None:
+            with open(hub / "config.toml", "rb") as f:
+                config = _toml.load(f)
+        if config_parse is not None:
+            config["inference"]["args"] = config_parse["inference"]["args"]
+            config["clustering"]["args"] = config_parse["clustering"]["args"]
+        self.config = config
+        inf, clu = config["inference"]["args"], config["clustering"]["args"]
+        if not torch.cuda.is_available():
+            raise RuntimeError("DiariZenPipeline (diarizen_amd) needs a HIP device; no CPU fallback")
+        self.device = torch.device(device or "cuda:0")
+
+        # ---- plugin boundary: instantiate([model].path, [model].args) + load_state_dict ----
+        margs = dict(config["model"]["args"])
+        margs.setdefault("precision", precision)
+        margs["max_batch"] = int(inf["batch_size"])
+        self.segmentation_model: WavLMConformer = instantiate(config["model"]["path"], margs)
+        if seg_state is None:
+            seg_state = _load_checkpoint(str(hub / "pytorch_model.bin"))
+        if emb_state is None:
+            emb_state = _load_checkpoint(str(embedding_model))
+        emb_state = {k: v for k, v in emb_state.items() if k.startswith("resnet.")}
+        self.seg_duration = float(inf["seg_duration"])
+        self.segmentation_step = float(inf["segmentation_step"])
+        self.batch_size = int(inf["batch_size"])
+        self.apply_median_filtering = bool(inf["apply_median_filtering"])
+        window = int(self.seg_duration * self.segmentation_model.sample_rate)
+        self.engine = Engine(self.segmentation_model.cfg, seg_state, RESNET34, emb_state,
+                             max_batch=self.batch_size, max_samples=window, precision=precision,
+                             device=self.device)
+        self.segmentation_model.load_state_dict(seg_state).bind(self.engine)
+        self._embedding = SpeakerEmbedding(engine=self.engine)
+        self._runner = WindowRunner(self.engine, self.seg_duration, self.segmentation_step,
+                                    self.batch_size, median_size=11 if self.apply_median_filtering else 0,
+                                    exclude_overlap=True)
+        assert self.segmentation_model.specifications.powerset is True
+
+        # ---- clustering (same [clustering.args] keys as the reference) ----
+        self.min_speakers, self.max_speakers = clu["min_speakers"], clu["max_speakers"]
+        if clu["method"] == "AgglomerativeClustering":
+            self.clustering = AgglomerativeClustering(metric="cosine", method="centroid",
+                                                      min_cluster_size=clu["min_cluster_size"],
+                                                      threshold=clu["ahc_threshold"])
+        elif clu["method"] == "VBxClustering":
+            self.clustering = VBxClustering(metric="cosine", plda_dir=str(hub / "plda") if hub else "",
+                                            lda_dim=clu["lda_dim"], max_iters=clu["max_iters"],
+                                            ahc_criterion=clu["ahc_criterion"],
+                                            ahc_threshold=clu["ahc_threshold"], Fa=clu["Fa"], Fb=clu["Fb"])
+        else:
+            raise ValueError(f"Unsupported clustering method: {clu['method']}")
+        if rttm_out_dir is not None:
+            os.makedirs(rttm_out_dir, exist_ok=True)
+        self.rttm_out_dir = rttm_out_dir
+        self.timings: Dict[str, float] = {}
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_pretrained(cls, repo_id: str, cache_dir: str = None, rttm_out_dir: str = None,
+                        **kwargs) -> "DiariZenPipeline":
+        """repo_id: HF hub id (needs network/cache, as in the reference) or a local hub directory.
+        The embedding checkpoint is `<dir>/wespeaker/pytorch_model.bin` when present locally."""
+        if os.path.isdir(repo_id):
+            hub = Path(repo_id).expanduser().absolute()
+            local = hub / "wespeaker" / "pytorch_model.bin"
+            embedding_model = str(local) if local.exists() else None
+        else:
+            from huggingface_hub import snapshot_download
+            hub = Path(snapshot_download(repo_id=repo_id, cache_dir=cache_dir,
+                                         local_files_only=cache_dir is not None)).expanduser().absolute()
+            embedding_model = None
+        if embedding_model is None:
+            from huggingface_hub import hf_hub_download
+            embedding_model = hf_hub_download(repo_id=EMBEDDING_REPO, filename="pytorch_model.bin",
+                                              cache_dir=cache_dir, local_files_only=cache_dir is not None)
+        return cls(diarizen_hub=hub, embedding_model=embedding_model, rttm_out_dir=rttm_out_dir, **kwargs)
+
+    # ------------------------------------------------------------------ stages
+    def chunks_window(self) -> SlidingWindow:
+        """SlidingWindow of the (un-aggregated) per-window outputs, PA/core/inference.py:377-381."""
+        return SlidingWindow(start=0.0, duration=self.seg_duration,
+                             step=self.segmentation_step * self.seg_duration)
+
+    def device_stage(self, waveform: np.ndarray):
+        """host float32 [N] -> (segmentations u8 [C, L, 4], embeddings f32 [C, 4, 256]) on the host."""
+        from . import dist as dz_dist
+        wave = torch.from_numpy(np.ascontiguousarray(waveform, dtype=np.float32)).to(self.device)
+        rng = dz_dist.my_window_range(self._runner.num_windows(wave.numel()))
+        res = self._runner.run(wave, with_embeddings=True, window_range=rng)
+        seg, emb = dz_dist.gather_windows(res.segmentations, res.embeddings)
+        torch.cuda.synchronize(self.device)
+        return seg.cpu().numpy(), emb.cpu().numpy()
+
+    def host_stage(self, seg: np.ndarray, emb: np.ndarray, sess_name: Optional[str] = None) -> Annotation:
+        """counting -> clustering -> reconstruction -> Annotation (inference.py:137-185)."""
+        chunks = self.chunks_window()
+        frames = receptive_field(self.segmentation_model.sample_rate)
+        segf = seg.astype(np.float32)
+        count = speaker_count(segf, chunks, frames)
+        hard, _, _ = self.clustering(embeddings=emb.astype(np.float64) if emb.dtype != np.float32 else emb,
+                                     segmentations=segf, min_clusters=self.min_speakers,
+                                     max_clusters=self.max_speakers)
+        count.data = np.minimum(count.data, self.max_speakers).astype(np.int8)
+        inactive = np.sum(segf, axis=1) == 0
+        hard = np.array(hard, copy=True)
+        hard[inactive] = -2
+        discrete, _ = reconstruct(segf, chunks, hard, count)
+        return binarize(discrete, onset=0.5, offset=0.5, uri=sess_name)
+
+    # ------------------------------------------------------------------ __call__
+    def __call__(self, in_wav, sess_name: Optional[str] = None) -> Annotation:
+        import time
+        if isinstance(in_wav, dict):                       # ProtocolFile-like
+            in_wav = in_wav["audio"]
+        assert isinstance(in_wav, (str, os.PathLike, BytesIO, bytes)), \
+            f"input must be either a str, BytesIO or a ProtocolFile; there was {type(in_wav)}"
+        t0 = time.perf_counter()
+        waveform = audio_io.first_channel_16k(in_wav, self.segmentation_model.sample_rate)
+        t1 = time.perf_counter()
+        seg, emb = self.device_stage(waveform)
+        t2 = time.perf_counter()
+        from . import dist as dz_dist
+        result = None
+        if dz_dist.rank() == 0:
+            result = self.host_stage(seg, emb, sess_name)
+            if self.rttm_out_dir is not None:
+                assert sess_name is not None
+                with open(os.path.join(self.rttm_out_dir, sess_name + ".rttm"), "w") as f:
+                    f.write(result.to_rttm())
+        t3 = time.perf_counter()
+        self.timings = {"load_s": t1 - t0, "device_s": t2 - t1, "host_s": t3 - t2,
+                        "audio_s": len(waveform) / self.segmentation_model.sample_rate}
+        return result

@@ -1,0 +1,168 @@
+"""Host post-processing between the device stages and the RTTM: overlap-add aggregation,
+instantaneous speaker count, reconstruction of the global diarization and binarisation.
+
+Restates, with numpy vector ops instead of per-frame Python loops ("f2" row of SURVEY.md §8f):
+  * Inference.aggregate                      PA/core/inference.py:544-666
+  * SpeakerDiarizationMixin.speaker_count    PA/pipelines/utils/diarization.py:121-157
+  * SpeakerDiarizationMixin.to_diarization   PA/pipelines/utils/diarization.py:192-239
+  * SpeakerDiarization.reconstruct           PA/pipelines/speaker_diarization.py:377-425
+  * Binarize.__call__ (onset = offset = 0.5) PA/utils/signal.py:254-317
+The frame grid is SlidingWindow(start = chunks.start, duration = 0.025, step = 0.02): the
+receptive-field START is discarded by aggregate() (inference.py:577-581) — kept as is.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .core import Annotation, Segment, SlidingWindow, SlidingWindowFeature
+
+
+def receptive_field(sample_rate: int = 16000) -> SlidingWindow:
+    """Model._receptive_field (PA/core/model.py:180-195) for the 7-conv WavLM extractor
+    (k = 10,3,3,3,3,2,2 ; s = 5,2,2,2,2,2,2): size 400 samples, step 320, centre of frame 0 at
+    sample 79.5 -> start = (79.5 - 199.5)/sr = -0.0075 s."""
+    k = [10, 3, 3, 3, 3, 2, 2]
+    s = [5, 2, 2, 2, 2, 2, 2]
+
+    def size(n):
+        for kk, ss in zip(reversed(k), reversed(s)):
+            n = 1 + (kk - 1) + (n - 1) * ss
+        return n
+
+    def center(frame):       # PA/utils/receptive_field.py: frame*stride + (k-1)//2, innermost conv last
+        c = int(frame)
+        for kk, ss in zip(reversed(k), reversed(s)):
+            c = c * ss + (kk - 1) // 2
+        return c
+
+    sz = size(1)
+    st = size(2) - sz
+    start = center(0) - (sz - 1) / 2
+    return SlidingWindow(start=start / sample_rate, duration=sz / sample_rate, step=st / sample_rate)
+
+
+def aggregate(scores: np.ndarray, chunks: SlidingWindow, frames: SlidingWindow, *, hamming: bool = False,
+              missing: float = np.nan, skip_average: bool = False, epsilon: float = 1e-12
+              ) -> SlidingWindowFeature:
+    """scores [C, L, K] (NaN = missing) with window c covering [chunks.start + c*step, +duration).
+    warm_up is (0, 0) on this path (diarizen/pipelines/inference.py:138-142)."""
+    C, L, K = scores.shape
+    frames = SlidingWindow(start=chunks.start, duration=frames.duration, step=frames.step)
+    mask = (~np.isnan(scores)).astype(np.float32)
+    data = np.nan_to_num(scores, nan=0.0).astype(np.float32)
+    win = (np.hamming(L) if hamming else np.ones(L)).reshape(-1, 1).astype(np.float64)
+    num_frames = frames.closest_frame(chunks.start + chunks.duration + (C - 1) * chunks.step
+                                      + 0.5 * frames.duration) + 1
+    out = np.zeros((num_frames, K), dtype=np.float32)
+    cnt = np.zeros((num_frames, K), dtype=np.float32)
+    seen = np.zeros((num_frames, K), dtype=np.float32)
+    for c in range(C):
+        s0 = frames.closest_frame(chunks.start + c * chunks.step + 0.5 * frames.duration)
+        out[s0:s0 + L] += data[c] * mask[c] * win
+        cnt[s0:s0 + L] += mask[c] * win
+        np.maximum(seen[s0:s0 + L], mask[c], out=seen[s0:s0 + L])
+    avg = out if skip_average else out / np.maximum(cnt, epsilon)
+    avg[seen == 0.0] = missing
+    return SlidingWindowFeature(avg, frames)
+
+
+def speaker_count(segmentations: np.ndarray, chunks: SlidingWindow, frames: SlidingWindow
+                  ) -> SlidingWindowFeature:
+    """[C, L, S] {0,1} -> (num_frames, 1) uint8 instantaneous speaker count."""
+    tot = np.sum(segmentations.astype(np.float32), axis=-1, keepdims=True)
+    count = aggregate(tot, chunks, frames, hamming=False, missing=0.0, skip_average=False)
+    count.data = np.rint(count.data).astype(np.uint8)
+    return count
+
+
+def to_diarization(clustered: np.ndarray, chunks: SlidingWindow, count: SlidingWindowFeature
+                   ) -> Tuple[SlidingWindowFeature, SlidingWindowFeature]:
+    act = aggregate(clustered, chunks, count.sliding_window, hamming=False, missing=0.0,
+                    skip_average=True)
+    K = act.data.shape[1]
+    max_per_frame = int(np.max(count.data)) if count.data.size else 0
+    if K < max_per_frame:
+        act.data = np.pad(act.data, ((0, 0), (0, max_per_frame - K)))
+    n = min(len(act.data), len(count.data))      # identical grids: extent & extent keeps all frames
+    a = act.data[:n]
+    c = count.data[:n].reshape(-1).astype(np.int64)
+    order = np.argsort(-a, axis=-1)               # same call as the reference (ties: numpy's order)
+    sel = (np.arange(a.shape[1])[None, :] < c[:, None]).astype(a.dtype)
+    binary = np.zeros_like(a)
+    np.put_along_axis(binary, order, sel, axis=-1)
+    sw = SlidingWindow(start=act.sliding_window.start, duration=act.sliding_window.duration,
+                       step=act.sliding_window.step)
+    return SlidingWindowFeature(binary, sw), SlidingWindowFeature(a, sw)
+
+
+def reconstruct(segmentations: np.ndarray, chunks: SlidingWindow, hard_clusters: np.ndarray,
+                count: SlidingWindowFeature) -> Tuple[SlidingWindowFeature, SlidingWindowFeature]:
+    """segmentations [C, L, S], hard_clusters [C, S] (-2 = inactive) -> discrete diarization."""
+    C, L, S = segmentations.shape
+    K = int(np.max(hard_clusters)) + 1 if hard_clusters.size else 0
+    K = max(K, 0)
+    clustered = np.full((C, L, K), np.nan, dtype=np.float64)
+    seg = segmentations.astype(np.float64)
+    for k in range(K):
+        sel = hard_clusters == k                                   # [C, S]
+        has = sel.any(axis=1)
+        if not has.any():
+            continue
+        vals = np.where(sel[:, None, :], seg, -np.inf).max(axis=2)  # max over local speakers -> [C, L]
+        clustered[has, :, k] = vals[has]
+    return to_diarization(clustered, chunks, count)
+
+
+def binarize(diar: SlidingWindowFeature, onset: float = 0.5, offset: Optional[float] = None,
+             uri: Optional[str] = None) -> Annotation:
+    """Binarize(onset=0.5, offset=0.5, min_duration_on=0, min_duration_off=0): regions run from the
+    MIDDLE of the first active frame to the middle of the first inactive frame (or of the last frame)."""
+    offset = onset if offset is None else offset
+    data = diar.data
+    n, K = data.shape
+    fr = diar.sliding_window
+    # frames[i].middle with pyannote.core's exact float64 op order (the .3f RTTM rounding of the
+    # x.xxx5 timestamps depends on it): s = start + i*step ; e = s + duration ; middle = .5*(s + e)
+    s_ = fr.start + np.arange(n) * fr.step
+    ts = 0.5 * (s_ + (s_ + fr.duration))
+    ann = Annotation(uri=uri)
+    if n < 2:
+        return ann
+    for k in range(K):
+        y = data[:, k]
+        # hysteresis state machine; with onset == offset on {0,1} data it is a plain threshold
+        if onset == offset:
+            on = y > onset
+            act = on.copy()
+            # frames exactly equal to the threshold keep the previous state
+            eq = y == onset
+            if eq.any():
+                act = _hysteresis(y, onset, offset)
+        else:
+            act = _hysteresis(y, onset, offset)
+        d = np.diff(act.astype(np.int8))
+        starts = list(np.nonzero(d == 1)[0] + 1)
+        ends = list(np.nonzero(d == -1)[0] + 1)
+        if act[0]:
+            starts = [0] + starts
+        if act[-1]:
+            ends = ends + [n - 1]
+        for s, e in zip(starts, ends):
+            ann[Segment(float(ts[s]), float(ts[e])), k] = k
+    return ann
+
+
+def _hysteresis(y: np.ndarray, onset: float, offset: float) -> np.ndarray:
+    act = np.zeros(len(y), dtype=bool)
+    state = y[0] > onset
+    act[0] = state
+    for i in range(1, len(y)):
+        if state:
+            if y[i] < offset:
+                state = False
+        elif y[i] > onset:
+            state = True
+        act[i] = state
+    return act

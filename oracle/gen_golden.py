@@ -211,7 +211,141 @@ def gen_statspool_powerset():
     print("statspool/powerset known answers:", {k: v.shape for k, v in outs.items() if k.startswith("y_")})
 
 
-GENERATORS = {"seg": gen_seg, "emb": gen_emb, "kat": gen_statspool_powerset}
+# ------------------------------------------------------------------ host clustering
+def synth_host_case(seed: int, C: int = 60, L: int = 99, S: int = 4, D: int = 256, n_spk: int = 3):
+    """synthetic per-window decisions + embeddings with a known speaker structure"""
+    g = np.random.default_rng(seed)
+    protos = g.normal(size=(n_spk, D))
+    seg = np.zeros((C, L, S), dtype=np.float32)
+    emb = np.zeros((C, S, D), dtype=np.float32)
+    for c in range(C):
+        k = g.integers(1, min(n_spk, 3) + 1)
+        who = g.permutation(n_spk)[:k]
+        slots = g.permutation(S)[:k]
+        for spk, slot in zip(who, slots):
+            a = g.integers(0, L // 2)
+            b = g.integers(a + 5, L)
+            seg[c, a:b, slot] = 1.0
+        for slot in range(S):
+            if seg[c, :, slot].sum() > 0:
+                spk = who[list(slots).index(slot)]
+                emb[c, slot] = protos[spk] + 0.35 * g.normal(size=D)
+            else:
+                emb[c, slot] = 0.1 * g.normal(size=D)      # "bias-like" embedding of an inactive speaker
+    return seg, emb
+
+
+def load_reference_clustering():
+    """PA/pipelines/clustering.py + diarizen/clustering/VBx.py with stubbed pyannote.* parents."""
+    _ref_path()
+    PA = REF / "pyannote-audio" / "pyannote" / "audio"
+
+    def stub(name, **attrs):
+        m = sys.modules.get(name)
+        if m is None:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    class _P:  # pyannote.pipeline.Pipeline / parameter stand-ins (hyper-parameters are set directly)
+        def __init__(self, *a, **k):
+            pass
+
+    from diarizen_amd import core as mycore
+    stub("pyannote")
+    stub("pyannote.core", SlidingWindow=mycore.SlidingWindow, SlidingWindowFeature=mycore.SlidingWindowFeature,
+         Segment=mycore.Segment, Annotation=mycore.Annotation)
+    stub("pyannote.pipeline", Pipeline=_P)
+    stub("pyannote.pipeline.parameter", Categorical=_P, Integer=_P, Uniform=_P)
+    stub("pyannote.audio")
+    stub("pyannote.audio.core")
+    stub("pyannote.audio.core.io", AudioFile=object)
+    stub("pyannote.audio.pipelines")
+    stub("pyannote.audio.pipelines.utils", oracle_segmentation=None)
+    stub("pyannote.audio.utils")
+    stub("pyannote.audio.utils.permutation", permutate=None)
+    return _load_by_path("pyannote.audio.pipelines.clustering", PA / "pipelines" / "clustering.py")
+
+
+def gen_host():
+    import tempfile
+    cl = load_reference_clustering()
+    out = {}
+    for i, (seed, C, nspk, thr, mcs) in enumerate([(1, 60, 3, 0.6, 5), (2, 120, 4, 0.7, 13), (3, 12, 2, 0.6, 13),
+                                                   (4, 200, 5, 0.5, 8)]):
+        seg, emb = synth_host_case(seed, C=C, n_spk=nspk)
+        ahc = cl.AgglomerativeClustering(metric="cosine")
+        ahc.method, ahc.threshold, ahc.min_cluster_size = "centroid", thr, mcs
+        swf = types.SimpleNamespace(data=seg)
+        hard, soft, cent = ahc(embeddings=emb.copy(), segmentations=swf, min_clusters=1, max_clusters=20)
+        out[f"ahc{i}_args"] = np.array([seed, C, nspk, thr, mcs], dtype=np.float64)
+        out[f"ahc{i}_hard"] = hard
+        out[f"ahc{i}_centroids"] = cent
+    # VBx with a synthetic (seeded) PLDA model in the hub's file format (VBx.py:171-175)
+    g = np.random.default_rng(7)
+    D, Dl = 256, 128
+    with tempfile.TemporaryDirectory() as td:
+        a = g.normal(size=(Dl, Dl))
+        np.savez(f"{td}/xvec_transform.npz", mean1=0.1 * g.normal(size=D), mean2=0.1 * g.normal(size=Dl),
+                 lda=g.normal(size=(D, Dl)) / np.sqrt(D))
+        np.savez(f"{td}/plda.npz", mu=0.1 * g.normal(size=Dl), tr=a / np.sqrt(Dl) + np.eye(Dl),
+                 psi=np.sort(g.uniform(0.5, 30.0, size=Dl))[::-1].copy())
+        for f in ("xvec_transform.npz", "plda.npz"):
+            out["plda_" + f.replace(".npz", "")] = np.frombuffer(open(f"{td}/{f}", "rb").read(), dtype=np.uint8)
+        for i, (seed, C, nspk) in enumerate([(11, 80, 3), (12, 150, 4)]):
+            seg, emb = synth_host_case(seed, C=C, n_spk=nspk)
+            vb = cl.VBxClustering(metric="cosine", plda_dir=td, lda_dim=128, maxIters=20)
+            vb.ahc_criterion, vb.ahc_threshold, vb.Fa, vb.Fb = "distance", 0.6, 0.07, 0.8
+            hard, soft, cent = vb(embeddings=emb.copy(), segmentations=types.SimpleNamespace(data=seg))
+            out[f"vbx{i}_args"] = np.array([seed, C, nspk], dtype=np.float64)
+            out[f"vbx{i}_hard"] = hard
+            out[f"vbx{i}_centroids"] = cent
+    np.savez_compressed(GOLD / "host_clustering.npz", **out)
+    print("host_clustering:", {k: v.shape for k, v in out.items() if k.endswith("_hard")},
+          "clusters:", [int(out[k].max()) + 1 for k in out if k.endswith("_hard")])
+
+
+# ------------------------------------------------------------------ end-to-end (BASELINE configs[0])
+E2E_CONFIG = {
+    "model": {"path": "diarizen.models.eend.model_wavlm_conformer.Model",
+              "args": {"wavlm_src": "wavlm_large_s80_md", "wavlm_layer_num": 25, "wavlm_feat_dim": 1024,
+                       "attention_in": 256, "ffn_hidden": 1024, "num_head": 4, "num_layer": 4,
+                       "kernel_size": 31, "chunk_size": 8, "max_speakers_per_chunk": 4,
+                       "max_speakers_per_frame": 2}},
+    "inference": {"args": {"seg_duration": 8, "segmentation_step": 0.1, "batch_size": 32,
+                           "apply_median_filtering": True}},
+    "clustering": {"args": {"method": "AgglomerativeClustering", "min_speakers": 1, "max_speakers": 20,
+                            "ahc_criterion": "distance", "ahc_threshold": 0.7, "min_cluster_size": 3}},
+}
+
+
+def gen_e2e():
+    """example/EN2002a_30s.wav through the oracle device stage (reference execution order, seeded
+    random weights) -> per-window decisions, embeddings.  The wav itself (a data fixture of the
+    reference, not source) is copied next to the goldens so the GPU box can read it."""
+    import shutil
+    from diarizen_amd.audio import first_channel_16k
+    from diarizen_amd.weights import emb_state_dict
+    from oracle.pipeline import device_stage_reference
+    _ref_path()
+    src = REF / "example" / "EN2002a_30s.wav"
+    dst = GOLD / "EN2002a_30s.wav"
+    if not dst.exists():
+        shutil.copyfile(src, dst)
+    wave = torch.from_numpy(first_channel_16k(str(dst)))
+    cfg = get_seg_config("wavlm_large_s80_md")
+    sd = seg_model.seg_state_dict(cfg, 0)
+    esd = emb_state_dict(0)
+    seg, emb = device_stage_reference(wave, cfg, sd, esd, duration=8.0, verbose=True)
+    np.savez_compressed(GOLD / "e2e_EN2002a_30s.npz", seg=seg, emb=emb, weight_seed=0)
+    print("e2e:", seg.shape, emb.shape, "active (window,speaker) pairs:", int((seg.sum(1) > 0).sum()))
+
+
+GENERATORS = {"seg": gen_seg, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
+              "e2e": gen_e2e}
 
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)

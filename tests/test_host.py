@@ -1,0 +1,194 @@
+"""Host logic (CPU only): window arithmetic, clustering vs the reference's own clustering code
+(tests/golden/host_clustering.npz made by oracle/gen_golden.py from PA/pipelines/clustering.py +
+diarizen/clustering/VBx.py), aggregation / counting / reconstruction / binarisation semantics,
+the reference's AHC unit test (pyannote-audio/tests/test_clustering.py:6-29), RTTM formatting,
+and the multi-process window exchange (gloo, world_size 2).
+"""
+import io
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ----------------------------------------------------------------------------- windows
+@pytest.mark.parametrize("n,expect", [(480000, (28, True)), (128000, (1, False)), (100000, (0, True)),
+                                      (128000 + 12800, (2, False)), (28800000, (2241, False))])
+def test_window_plan_matches_reference_arithmetic(n, expect):
+    """PA/core/inference.py:285-299: 30 s file -> 29 windows of 8 s, 30 min -> 2241."""
+    from diarizen_amd.inference import window_plan
+    assert window_plan(n, 128000, 12800) == expect
+
+
+def test_receptive_field_and_num_frames():
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.postprocess import receptive_field
+    rf = receptive_field(16000)
+    assert abs(rf.duration - 0.025) < 1e-12 and abs(rf.step - 0.02) < 1e-12
+    assert abs(rf.start - (-0.00753125)) < 1e-9
+    cfg = get_seg_config("wavlm_large_s80_md")
+    assert [cfg.num_frames(n) for n in (80000, 128000, 256000)] == [249, 399, 799]
+
+
+# ----------------------------------------------------------------------------- clustering
+def _host_case(args):
+    from oracle.gen_golden import synth_host_case
+    seed, C, nspk = int(args[0]), int(args[1]), int(args[2])
+    return synth_host_case(seed, C=C, n_spk=nspk)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+def test_ahc_equals_reference(i):
+    from diarizen_amd.clustering import AgglomerativeClustering
+    g = np.load(os.path.join(GOLD, "host_clustering.npz"))
+    a = g[f"ahc{i}_args"]
+    seg, emb = _host_case(a)
+    ahc = AgglomerativeClustering(metric="cosine", method="centroid", threshold=float(a[3]),
+                                  min_cluster_size=int(a[4]))
+    hard, soft, cent = ahc(embeddings=emb.copy(), segmentations=seg, min_clusters=1, max_clusters=20)
+    assert np.array_equal(hard, g[f"ahc{i}_hard"])
+    assert np.allclose(cent, g[f"ahc{i}_centroids"], atol=1e-6)
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_vbx_equals_reference(i, tmp_path):
+    from diarizen_amd.clustering import VBxClustering
+    g = np.load(os.path.join(GOLD, "host_clustering.npz"))
+    for f in ("xvec_transform", "plda"):
+        (tmp_path / f"{f}.npz").write_bytes(g["plda_" + f].tobytes())
+    seg, emb = _host_case(g[f"vbx{i}_args"])
+    vb = VBxClustering(metric="cosine", plda_dir=str(tmp_path), lda_dim=128, max_iters=20,
+                       ahc_criterion="distance", ahc_threshold=0.6, Fa=0.07, Fb=0.8)
+    hard, soft, cent = vb(embeddings=emb.copy(), segmentations=seg)
+    assert np.array_equal(hard, g[f"vbx{i}_hard"])
+    assert np.allclose(cent, g[f"vbx{i}_centroids"], rtol=1e-5, atol=1e-6)
+
+
+def test_ahc_does_not_overmerge_reference_unit_test():
+    """pyannote-audio/tests/test_clustering.py:6-29: 2 embeddings, threshold 0 -> [0, 1]."""
+    from diarizen_amd.clustering import AgglomerativeClustering
+    ahc = AgglomerativeClustering(metric="cosine", method="centroid", threshold=0.0, min_cluster_size=1)
+    emb = np.array([[1.0, 2.0], [2.0, 1.0]])
+    assert np.array_equal(ahc.cluster(emb, min_clusters=1, max_clusters=np.inf), np.array([0, 1]))
+
+
+# ----------------------------------------------------------------------------- post-processing
+def test_aggregate_count_reconstruct_binarize_small_case():
+    from diarizen_amd.core import SlidingWindow
+    from diarizen_amd.postprocess import aggregate, binarize, reconstruct, speaker_count
+    # 3 windows of 1.0 s (50 frames of 20 ms), step 0.2 s -> start frames 0, 10, 20
+    chunks = SlidingWindow(start=0.0, duration=1.0, step=0.2)
+    frames = SlidingWindow(start=-0.0075, duration=0.025, step=0.02)
+    C, L, S = 3, 50, 2
+    seg = np.zeros((C, L, S), dtype=np.float32)
+    seg[0, 10:30, 0] = 1          # global frames 10..29, local speaker 0
+    seg[1, 0:20, 1] = 1           # global frames 10..29, local speaker 1 (same person)
+    seg[2, 30:50, 0] = 1          # global frames 50..69, another person
+    cnt = speaker_count(seg, chunks, frames)
+    n = frames.__class__(start=0.0, duration=0.025, step=0.02).closest_frame(1.0 + 2 * 0.2 + 0.0125) + 1
+    assert cnt.data.shape == (n, 1) == (71, 1)
+    assert cnt.sliding_window.start == 0.0                      # receptive-field start is discarded
+    exp = np.zeros(71)
+    # frames 20..29 are covered by windows 0,1,2 and two of them agree -> mean 2/3 -> rint 1
+    exp[10:30] = 1
+    # frames 50..59 are covered by windows 1,2 -> mean 1/2 -> rint (half to even) 0 ; 60..69 by window 2 only
+    exp[60:70] = 1
+    assert np.array_equal(cnt.data[:, 0], exp.astype(np.uint8))
+    hard = np.array([[0, -2], [-2, 0], [1, -2]])
+    cnt.data = cnt.data.astype(np.int8)
+    disc, act = reconstruct(seg, chunks, hard, cnt)
+    assert disc.data.shape == (71, 2)
+    assert disc.data[10:30, 0].all() and not disc.data[:, 0][30:].any()
+    assert disc.data[60:70, 1].all() and not disc.data[50:60, 1].any()   # count 0 there
+    ann = binarize(disc, uri="x")
+    lines = ann.to_rttm().splitlines()
+    # regions run between frame MIDDLES: frame i -> i*0.02 + 0.0125
+    def mid(i):                     # pyannote.core: Segment(s, s + duration).middle
+        s_ = 0.0 + i * 0.02
+        return 0.5 * (s_ + (s_ + 0.025))
+    assert lines == [f"SPEAKER x 1 {mid(10):.3f} {mid(30) - mid(10):.3f} <NA> <NA> 0 <NA> <NA>",
+                     f"SPEAKER x 1 {mid(60):.3f} {mid(70) - mid(60):.3f} <NA> <NA> 1 <NA> <NA>"]
+    # NaN handling of aggregate: clusters absent from a window do not count as observations
+    a = aggregate(np.array([[[np.nan], [1.0]], [[2.0], [np.nan]]]),
+                  SlidingWindow(start=0.0, duration=0.04, step=0.02), frames, missing=0.0, skip_average=True)
+    assert a.data[:, 0].tolist()[:3] == [0.0, 3.0, 0.0]
+
+
+def test_binarize_end_of_file_and_empty():
+    from diarizen_amd.core import SlidingWindow, SlidingWindowFeature
+    from diarizen_amd.postprocess import binarize
+    fr = SlidingWindow(start=0.0, duration=0.025, step=0.02)
+    d = np.zeros((10, 2), dtype=np.float32)
+    d[7:, 0] = 1
+    ann = binarize(SlidingWindowFeature(d, fr), uri=None)
+    m7, m9 = 0.5 * (7 * 0.02 + (7 * 0.02 + 0.025)), 0.5 * (9 * 0.02 + (9 * 0.02 + 0.025))
+    assert ann.to_rttm() == f"SPEAKER <NA> 1 {m7:.3f} {m9 - m7:.3f} <NA> <NA> 0 <NA> <NA>\n"
+    assert not binarize(SlidingWindowFeature(np.zeros((10, 2), dtype=np.float32), fr))
+
+
+# ----------------------------------------------------------------------------- audio
+def test_wav_loader_roundtrip(tmp_path):
+    import wave
+    from diarizen_amd.audio import first_channel_16k, load_wav
+    x = (np.sin(np.arange(1600) / 10.0) * 20000).astype("<i2")
+    st = np.stack([x, -x], axis=1)
+    p = tmp_path / "a.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(st.tobytes())
+    y, sr = load_wav(str(p))
+    assert sr == 16000 and y.shape == (2, 1600)
+    assert np.array_equal(y[0], x.astype(np.float32) / 32768.0)
+    assert np.array_equal(first_channel_16k(io.BytesIO(p.read_bytes())), y[0])
+    ref = os.path.join(os.path.dirname(__file__), "golden", "EN2002a_30s_head.wav")
+    if os.path.exists(ref):
+        assert first_channel_16k(ref).shape[0] > 0
+
+
+# ----------------------------------------------------------------------------- multi-process exchange
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, C, out_dir):
+    import torch.distributed as dist
+    from diarizen_amd import dist as dz
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = dz.my_window_range(C)
+    # every rank "computes" its own windows: value = global window index
+    seg = (torch.arange(lo, hi).view(-1, 1, 1) % 251).to(torch.uint8).expand(hi - lo, 5, 4).contiguous()
+    emb = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(hi - lo, 4, 8).contiguous()
+    gs, ge = dz.gather_windows(seg, emb)
+    torch.save((gs, ge), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("C", [7, 8, 1])
+def test_window_sharding_and_gather_gloo_world2(C, tmp_path):
+    import torch.multiprocessing as mp
+    from diarizen_amd.dist import shard_range
+    assert shard_range(7, 0, 2) == (0, 4) and shard_range(7, 1, 2) == (4, 7)
+    assert shard_range(1, 1, 2) == (1, 1)                       # empty trailing shard
+    covered = sorted(i for r in range(8) for i in range(*shard_range(17991, r, 8)))
+    assert covered == list(range(17991))
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, C, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        gs, ge = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        assert gs.shape == (C, 5, 4) and ge.shape == (C, 4, 8)
+        assert torch.equal(ge[:, 0, 0], torch.arange(C, dtype=torch.float32))   # window order kept
+        assert torch.equal(gs[:, 0, 0].long(), torch.arange(C) % 251)
