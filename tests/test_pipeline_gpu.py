@@ -1,0 +1,75 @@
+"""BASELINE.json configs[0]: example/EN2002a_30s.wav through the drop-in DiariZenPipeline on the GPU
+vs the oracle's execution of the reference device stage on CPU (tests/golden/e2e_EN2002a_30s.npz:
+per-window hard decisions after the median filter + per-(window, speaker) embeddings, seeded
+random weights — no hub weights exist offline, so this is the "plumbing / RTTM golden").
+
+Bars: decisions bit-exact (u8), embeddings cosine >= 0.9999, and the RTTM produced from the GPU
+outputs identical to the RTTM produced from the golden outputs by the same host stage.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+WAV = os.path.join(GOLD, "EN2002a_30s.wav")
+
+
+@pytest.fixture(scope="module")
+def pipeline(built_lib, gpu):
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.pipeline import DiariZenPipeline
+    from diarizen_amd.weights import emb_state_dict, seg_state_dict
+    from oracle.gen_golden import E2E_CONFIG
+    import copy
+    cfg = get_seg_config("wavlm_large_s80_md")
+    return DiariZenPipeline(None, None, config=copy.deepcopy(E2E_CONFIG), device=gpu, precision="f32",
+                            seg_state=seg_state_dict(cfg, 0), emb_state=emb_state_dict(0))
+
+
+def test_device_stage_matches_reference_execution(pipeline):
+    from diarizen_amd.audio import first_channel_16k
+    g = np.load(os.path.join(GOLD, "e2e_EN2002a_30s.npz"))
+    wave = first_channel_16k(WAV)
+    assert wave.shape == (480000,)
+    seg, emb = pipeline.device_stage(wave)
+    assert seg.shape == g["seg"].shape == (29, 399, 4)          # 30 s -> 29 windows of 8 s
+    assert np.array_equal(seg, g["seg"])                         # bit-exact hard decisions
+    e, r = torch.from_numpy(emb).reshape(-1, 256), torch.from_numpy(g["emb"]).reshape(-1, 256)
+    cos = torch.nn.functional.cosine_similarity(e, r, dim=-1)
+    assert cos.min().item() > 0.9999
+    assert (e - r).abs().max().item() <= 1e-4 * r.abs().max().item()
+
+
+def test_rttm_equal_and_api_surface(pipeline, tmp_path):
+    g = np.load(os.path.join(GOLD, "e2e_EN2002a_30s.npz"))
+    pipeline.rttm_out_dir = str(tmp_path)
+    ann = pipeline(WAV, sess_name="EN2002a")
+    assert ann.uri == "EN2002a"
+    rttm = (tmp_path / "EN2002a.rttm").read_text()
+    assert rttm == ann.to_rttm()
+    ref = pipeline.host_stage(g["seg"], g["emb"], "EN2002a").to_rttm()
+    assert rttm == ref
+    for line in rttm.splitlines():
+        f = line.split()
+        assert f[0] == "SPEAKER" and f[1] == "EN2002a" and len(f) == 10
+    t = pipeline.timings
+    assert t["audio_s"] == 30.0 and t["device_s"] > 0
+
+
+def test_plugin_facades(pipeline, gpu):
+    """[model].path facade: forward(waveforms[B,C,N]) -> logp[B,L,11]; embedding facade properties."""
+    m = pipeline.segmentation_model
+    x = torch.randn(2, 1, 128000) * 0.1
+    logp = m(x)
+    torch.cuda.synchronize()
+    assert logp.shape == (2, 399, 11) and logp.is_cuda
+    assert torch.allclose(logp.exp().sum(-1).cpu(), torch.ones(2, 399), atol=1e-4)
+    assert m.specifications.powerset and m.num_frames(128000) == 399
+    e = pipeline._embedding
+    assert (e.sample_rate, e.dimension, e.metric) == (16000, 256, "cosine")
+    assert e.min_num_samples == 400                               # speaker_verification.py:677-691
+    out = e(x[:, :, :32000], torch.ones(2, 99))
+    assert out.shape == (2, 256) and np.isfinite(out).all()
