@@ -164,11 +164,11 @@ def profile_enable(on: bool) -> None:
 def profile_collect() -> list:
     """[{name, launches, ms, flops, bytes}] aggregated per kernel class since the last collect."""
     lib = load()
-    arr = (DznProfEntry * 64)()
+    arr = (DznProfEntry * 512)()
     n = C.c_int32(0)
-    check(lib.dzn_profile_collect(arr, 64, C.byref(n)), None, "dzn_profile_collect")
+    check(lib.dzn_profile_collect(arr, 512, C.byref(n)), None, "dzn_profile_collect")
     return [dict(name=arr[i].name.decode(), launches=arr[i].launches, ms=arr[i].ms,
-                 flops=arr[i].flops, bytes=arr[i].bytes) for i in range(min(n.value, 64))]
+                 flops=arr[i].flops, bytes=arr[i].bytes) for i in range(min(n.value, 512))]
 
 
 def check(rc: int, handle=None, what: str = "") -> None:

@@ -22,6 +22,7 @@
 // with one barrier per K tile; workgroup ids are remapped so each XCD (private L2)
 // walks a contiguous run of tiles.
 #include <cstdio>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -181,12 +182,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dzn_gemm_desc d) {
         const int slot = (kb * 4 + lq) ^ ((row >> 1) & 7);
         bf[j] = *reinterpret_cast<const frag_t*>(sW + row * 128 + (slot << 4));
       }
+      // operands swapped (W fragment as the MFMA "A"): the accumulator block is C^T, i.e. lane
+      // (lr, lq) holds C[m = lr][n = 4*lq + 0..3] -> 4 consecutive columns per lane, float4 epilogue
       if constexpr (LOWP) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
       } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dzn_gemm_desc d) {
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
       }
     }
   };
@@ -212,28 +215,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dzn_gemm_desc d) {
     __syncthreads();
   }
 
-  // ---- epilogue ----
+  // ---- epilogue: lane (lr, lq) of block (i, j) holds row m = ..+lr, columns n0..n0+3 ----
   const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
+  const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    const int m = tm * BM + wm * TM + i * 16 + lr;
+    if (m >= d.M) continue;
+    const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int m = tm * BM + wm * TM + i * 16 + lq * 4 + rg;
-      if (m >= d.M) continue;
-      const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
+    for (int j = 0; j < NI; ++j) {
+      const int n0 = tn * BN + wn * TN + j * 16 + lq * 4;
+      if (n0 >= d.N) continue;
+      f32x4 v = acc[i][j];
+      if (vec && n0 + 3 < d.N) {
+        if (bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = tn * BN + wn * TN + j * 16 + lr;
-        if (n >= d.N) continue;
-        float v = acc[i][j][rg];
-        if (bias) v += bias[n];
-        v = apply_act(v, d.act) * d.alpha;
-        if (d.R) v += d.R[crow + n];
-        if (d.post_relu) v = fmaxf(v, 0.f);
-        d.C[crow + n] = v;
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act) * d.alpha;
+        if (d.R) {
+          const float4 r4 = *reinterpret_cast<const float4*>(d.R + crow + n0);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        if (d.post_relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<float4*>(d.C + crow + n0) = make_float4(v[0], v[1], v[2], v[3]);
         if (d.WS) {
-          float* w = d.WS + (int64_t)m * d.ldws + n;
-          *w = d.ws_init ? d.ws_w * v : (*w + d.ws_w * v);
+          float4* w = reinterpret_cast<float4*>(d.WS + (int64_t)m * d.ldws + n0);
+          float4 a = d.ws_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *w;
+          a.x += d.ws_w * v[0]; a.y += d.ws_w * v[1]; a.z += d.ws_w * v[2]; a.w += d.ws_w * v[3];
+          *w = a;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0 + e;
+          if (n >= d.N) continue;
+          float x = v[e];
+          if (bias) x += bias[n];
+          x = apply_act(x, d.act) * d.alpha;
+          if (d.R) x += d.R[crow + n];
+          if (d.post_relu) x = fmaxf(x, 0.f);
+          d.C[crow + n] = x;
+          if (d.WS) {
+            float* w = d.WS + (int64_t)m * d.ldws + n;
+            *w = d.ws_init ? d.ws_w * x : (*w + d.ws_w * x);
+          }
         }
       }
     }
@@ -255,7 +286,12 @@ int launch_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   int pid = -1;
   if (prof_enabled()) {
     char cls[64];
-    snprintf(cls, sizeof(cls), "gemm_%s_%dx%d", LOWP ? "bf16" : "f32", BM, BN);
+    static const bool by_shape = getenv("DZN_PROFILE_SHAPES") != nullptr;
+    if (by_shape)
+      snprintf(cls, sizeof(cls), "gemm_%s_%dx%d M%d N%d K%d z%d", LOWP ? "bf16" : "f32", BM, BN, d.M, d.N,
+               d.K, d.nz);
+    else
+      snprintf(cls, sizeof(cls), "gemm_%s_%dx%d", LOWP ? "bf16" : "f32", BM, BN);
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
     pid = prof_begin(s, cls, fl, 0.0);
   }
@@ -268,7 +304,20 @@ template <bool LOWP>
 int launch_prec(const dzn_gemm_desc& d, hipStream_t s) {
   if (d.N <= 32) return launch_cfg<256, 32, 4, 1, LOWP>(d, s);
   if (d.N <= 64) return launch_cfg<128, 64, 2, 2, LOWP>(d, s);
-  return launch_cfg<128, 128, 2, 2, LOWP>(d, s);
+  // pick the column-tile width that wastes the fewest padded columns (irregular pruned widths:
+  // 153 -> 160, q/k/v = 192 h, FFN 96..1770); ties go to the wider tile (more reuse per A fragment)
+  const int cand[4] = {192, 160, 128, 96};
+  int best = 128, best_cols = 1 << 30;
+  for (int c : cand) {
+    const int cols = (d.N + c - 1) / c * c;
+    if (cols < best_cols) { best_cols = cols; best = c; }
+  }
+  switch (best) {
+    case 192: return launch_cfg<128, 192, 2, 2, LOWP>(d, s);
+    case 160: return launch_cfg<128, 160, 2, 2, LOWP>(d, s);
+    case 96: return launch_cfg<128, 96, 2, 2, LOWP>(d, s);
+    default: return launch_cfg<128, 128, 2, 2, LOWP>(d, s);
+  }
 }
 
 }  // namespace
