@@ -5,7 +5,7 @@
 
 One "step" = one pass of the device hot path over ONE synthetic recording per rank
 (BASELINE.json configs[2]: wavlm-large-s80, 30 min of 16 kHz mono, window 8 s, step 0.8 s ->
-2241 windows, batch 32): for every batch of windows  segmentation (WavLM + Conformer + powerset)
+2241 windows, batch 128 by default: windows are independent, results do not depend on the batch): for every batch of windows  segmentation (WavLM + Conformer + powerset)
 -> median filter + overlap-excluded masks -> ResNet34 embeddings (trunk shared by the 4 local
 speakers), all through the C ABI of libdzn_hip.so, the recording already resident in HBM.  The
 step ends with the hand-off the host clustering needs: u8 decisions + f32 embeddings copied to
@@ -89,7 +89,7 @@ def main():
                     choices=["f32", "bf16"])
     ap.add_argument("--minutes", type=float, default=30.0)
     ap.add_argument("--window", type=float, default=8.0)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--model", default="wavlm_large_s80_md")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")

@@ -44,6 +44,65 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float4& a, const float4& b) {
   return *reinterpret_cast<uint4*>(&v);
 }
 
+template <int BM, int BN, int TM, int TN, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
+                                              int wm, int wn, int lr, int lq, int64_t cz, int64_t bz) {
+  // ---- epilogue: lane (lr, lq) of block (i, j) holds row m = ..+lr, columns n0..n0+3 ----
+  const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
+  const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = tm * BM + wm * TM + i * 16 + lr;
+    if (m >= d.M) continue;
+    const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n0 = tn * BN + wn * TN + j * 16 + lq * 4;
+      if (n0 >= d.N) continue;
+      f32x4 v = acc[i][j];
+      if (vec && n0 + 3 < d.N) {
+        if (bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act) * d.alpha;
+        if (d.R) {
+          const float4 r4 = *reinterpret_cast<const float4*>(d.R + crow + n0);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        if (d.post_relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<float4*>(d.C + crow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+        if (d.WS) {
+          float4* w = reinterpret_cast<float4*>(d.WS + (int64_t)m * d.ldws + n0);
+          float4 a = d.ws_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *w;
+          a.x += d.ws_w * v[0]; a.y += d.ws_w * v[1]; a.z += d.ws_w * v[2]; a.w += d.ws_w * v[3];
+          *w = a;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0 + e;
+          if (n >= d.N) continue;
+          float x = v[e];
+          if (bias) x += bias[n];
+          x = apply_act(x, d.act) * d.alpha;
+          if (d.R) x += d.R[crow + n];
+          if (d.post_relu) x = fmaxf(x, 0.f);
+          d.C[crow + n] = x;
+          if (d.WS) {
+            float* w = d.WS + (int64_t)m * d.ldws + n;
+            *w = d.ws_init ? d.ws_w * x : (*w + d.ws_w * x);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int WGM, int WGN, bool LOWP>
 __global__ __launch_bounds__(256) void gemm_kernel(const dzn_gemm_desc d) {
   static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
@@ -215,73 +274,142 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dzn_gemm_desc d) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane (lr, lq) of block (i, j) holds row m = ..+lr, columns n0..n0+3 ----
-  const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
-  const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = tm * BM + wm * TM + i * 16 + lr;
-    if (m >= d.M) continue;
-    const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n0 = tn * BN + wn * TN + j * 16 + lq * 4;
-      if (n0 >= d.N) continue;
-      f32x4 v = acc[i][j];
-      if (vec && n0 + 3 < d.N) {
-        if (bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act) * d.alpha;
-        if (d.R) {
-          const float4 r4 = *reinterpret_cast<const float4*>(d.R + crow + n0);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-        }
-        if (d.post_relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        *reinterpret_cast<float4*>(d.C + crow + n0) = make_float4(v[0], v[1], v[2], v[3]);
-        if (d.WS) {
-          float4* w = reinterpret_cast<float4*>(d.WS + (int64_t)m * d.ldws + n0);
-          float4 a = d.ws_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *w;
-          a.x += d.ws_w * v[0]; a.y += d.ws_w * v[1]; a.z += d.ws_w * v[2]; a.w += d.ws_w * v[3];
-          *w = a;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0 + e;
-          if (n >= d.N) continue;
-          float x = v[e];
-          if (bias) x += bias[n];
-          x = apply_act(x, d.act) * d.alpha;
-          if (d.R) x += d.R[crow + n];
-          if (d.post_relu) x = fmaxf(x, 0.f);
-          d.C[crow + n] = x;
-          if (d.WS) {
-            float* w = d.WS + (int64_t)m * d.ldws + n;
-            *w = d.ws_init ? d.ws_w * x : (*w + d.ws_w * x);
-          }
-        }
-      }
-    }
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// f32 variant with direct global->LDS loads (global_load_lds_dwordx4, CDNA4 LDS-DMA): no VGPR
+// staging and no ds_write pass — the per-K-tile bubble (LDS write at ~79 B/clk + barrier) of the
+// register-staged kernel shrinks to the barrier.  The LDS image must be lane-linear per wave
+// instruction (1 KiB = 8 rows x 128 B), so the XOR swizzle is applied to the SOURCE chunk index
+// and the same XOR on the fragment read (cdna guide rule 21).  Rows beyond M / N are clamped to
+// a valid row (their accumulators are never stored).  Requires K % 32 == 0 and kc % 32 == 0.
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const dzn_gemm_desc d) {
+  static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
+  constexpr int BK = 32;
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int ACH = BM / 32, WCH = BN / 32;
+  constexpr int BUF = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tilesN = (d.N + BN - 1) / BN;
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int tm = t / tilesN, tn = t % tilesN;
+  const int z = blockIdx.y;
+  const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
+  const float* __restrict__ A = d.A + z0 * d.a_z0 + z1 * d.a_z1;
+  const float* __restrict__ W = d.W + z0 * d.w_z0 + z1 * d.w_z1;
+  const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
+  const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
+
+  // thread -> (row = 8*wave + lane/8 + 32 i, physical 16-B slot p = lane%8); the logical chunk
+  // stored at slot p of row r is c = p ^ ((r >> 1) & 7)   (independent of i: 32 i >> 1 = 16 i)
+  const int r0 = tid >> 3;
+  const int csw = (tid & 7) ^ ((r0 >> 1) & 7);
+  int64_t abase[ACH], wbase[WCH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    int m = tm * BM + r0 + 32 * i;
+    m = m < d.M ? m : d.M - 1;
+    abase[i] = (d.a_rowoff ? (int64_t)d.a_rowoff[m] : (int64_t)m * d.lda) + csw * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) {
+    int n = tn * BN + r0 + 32 * i;
+    n = n < d.N ? n : d.N - 1;
+    wbase[i] = (int64_t)n * d.ldw + csw * 4;
+  }
+
+  auto issue = [&](int k0, int buf) {
+    // k0 is a multiple of 32 and kc % 32 == 0: the whole K tile sits inside one kc chunk
+    const int ch = k0 / d.kc;
+    const int64_t koff = (int64_t)ch * d.ldk + (k0 - ch * d.kc);
+    unsigned char* sA = smem + buf * BUF + wave * 1024;
+    unsigned char* sW = smem + buf * BUF + BM * 128 + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(A + abase[i] + koff),
+          (__attribute__((address_space(3))) void*)(sA + i * 4096), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WCH; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(W + wbase[i] + k0),
+          (__attribute__((address_space(3))) void*)(sW + i * 4096), 16, 0, 0);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int lr = lane & 15, lq = lane >> 4;
+
+  auto compute = [&](int buf) {
+    const unsigned char* sA = smem + buf * BUF;
+    const unsigned char* sW = sA + BM * 128;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * TM + i * 16 + lr;
+        const int slot = (kb * 4 + lq) ^ ((row >> 1) & 7);
+        af[i] = *reinterpret_cast<const f32x4*>(sA + row * 128 + (slot << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = wn * TN + j * 16 + lr;
+        const int slot = (kb * 4 + lq) ^ ((row >> 1) & 7);
+        bf[j] = *reinterpret_cast<const f32x4*>(sW + row * 128 + (slot << 4));
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = d.K / BK;
+  issue(0, 0);
+  __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes tile 0
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) issue((kt + 1) * BK, (kt + 1) & 1);  // in flight during compute
+    compute(kt & 1);
+    __syncthreads();
+  }
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool LOWP>
 int launch_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-  const size_t lds = 2 * (BM + BN) * 128;
+  static const int lds_pad = getenv("DZN_GEMM_LDS_PAD") ? atoi(getenv("DZN_GEMM_LDS_PAD")) : 0;
+  const size_t lds = 2 * (BM + BN) * 128 + lds_pad;
   auto kern = gemm_kernel<BM, BN, WGM, WGN, LOWP>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (!LOWP)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WGM, WGN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  static const bool no_glds = getenv("DZN_NO_GLDS") != nullptr;
+  const bool use_glds = !LOWP && !no_glds && (d.K % 32 == 0) && (d.kc % 32 == 0);
   dim3 grid(tilesM * tilesN, d.nz > 0 ? d.nz : 1, 1);
   int pid = -1;
   if (prof_enabled()) {
@@ -295,7 +423,14 @@ int launch_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
     pid = prof_begin(s, cls, fl, 0.0);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
+  if constexpr (!LOWP) {
+    if (use_glds)
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WGM, WGN>), grid, dim3(256), lds, s, d);
+    else
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
+  } else {
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
+  }
   prof_end(pid, s);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
