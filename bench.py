@@ -59,6 +59,23 @@ def synth_recording(num_samples: int, seed: int = 3407) -> torch.Tensor:
     return x.clamp_(-1.0, 1.0)
 
 
+def pmc_traffic(kernel_class: str, args):
+    """HBM bytes per launch of `kernel_class` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE on this same command, gfx950 correction applied; scripts/pmc_traffic.py).  bench.py
+    cannot run rocprofv3 on itself, so the figure is read from profiles/ and only when the workload
+    matches the one the passes were taken on."""
+    path = ROOT / "profiles" / "r1b_pmc_traffic_30min_b128.json"
+    if not path.exists() or args.minutes != 30.0 or args.batch != 128 or args.precision != "f32" \
+            or args.model != "wavlm_large_s80_md" or args.window != 8.0:
+        return None
+    table = json.loads(path.read_text())
+    key = None
+    if kernel_class.startswith("gemm_f32_"):
+        bm, bn = kernel_class[len("gemm_f32_"):].split("x")
+        key = next((k for k in table if k.startswith(f"gemm_glds_kernel<{bm}, {bn},")), None)
+    return table[key]["hbm_bytes_per_launch"] if key else None
+
+
 def cpu_baseline(seg_cfg, sd, esd, window: int, step_s: float, budget_windows: int = 2):
     """The oracle (CPU port of the reference arithmetic, oracle/) on a bounded sample: B windows
     through segmentation + the embedding stage AS THE REFERENCE EXECUTES IT (one ResNet pass per
@@ -181,7 +198,8 @@ def main():
                 ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
                 roofline = {"kernel": top["name"], "bound": "mfma", "achieved": round(ach, 2),
                             "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
-                            "frac": round(ach / PEAK_TFLOPS[prec], 4), "traffic": None,
+                            "frac": round(ach / PEAK_TFLOPS[prec], 4),
+                            "traffic": pmc_traffic(top["name"], args),
                             "launches": top["launches"],
                             "avg_launch_ms": round(top["ms"] / top["launches"], 4),
                             "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 3)}
