@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--window", type=float, default=8.0)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--model", default="wavlm_large_s80_md")
+    ap.add_argument("--stage", default="full", choices=["full", "seg"],
+                    help="seg = segmentation-only (BASELINE configs[1]: --model wavlm_base_s80_md --window 5 "
+                         "--batch 32 --stage seg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -144,8 +147,12 @@ def main():
     n_windows = runner.num_windows(num_samples)
     audio_s = num_samples / sr
 
+    full = args.stage == "full"
+
     def step():
-        res = runner.run(wave, with_embeddings=True)
+        res = runner.run(wave, with_embeddings=full)
+        if not full:
+            return res.segmentations.cpu()
         if world > 1:
             segs = [torch.empty_like(res.segmentations) for _ in range(world)]
             embs = [torch.empty_like(res.embeddings) for _ in range(world)]
@@ -215,7 +222,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{args.model} hot path (segmentation + masks + ResNet34 embeddings), "
+            "config": {"workload": f"{args.model} hot path ({'segmentation + masks + ResNet34 embeddings' if full else 'segmentation only'}), "
                                    f"{args.minutes:g} min synthetic 16 kHz mono per GPU, window "
                                    f"{args.window:g} s, step {0.1 * args.window:g} s, {n_windows} windows, "
                                    f"batch {args.batch}; host clustering excluded",
@@ -225,7 +232,7 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and full:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, esd, window, 0.1 * args.window)
         print(json.dumps(out))
     if dist is not None:

@@ -80,3 +80,34 @@ def test_embedding_rejects_too_short_waveform(built_lib, gpu):
     out = eng.embed(torch.randn(1, 1600, device=gpu) * 0.1, torch.ones(1, 1, 4, device=gpu))
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
+
+
+def test_embedding_16s_window_and_masks_kernel(built_lib, gpu):
+    """16 s windows (T = 1598 fbank frames, L = 799) + on-device median filter / mask logic vs the
+    numpy restatement of diarizen/pipelines/inference.py:131-132 and speaker_diarization.py:268-322"""
+    import math
+    from scipy.ndimage import median_filter
+    from oracle import emb_model
+    from oracle.gen_golden import synth_wave
+    B, N, L = 2, 256000, 799
+    wave = synth_wave(B, N, 55)
+    g = torch.Generator().manual_seed(9)
+    # random two-state decisions with overlaps, short blips and an almost-fully-overlapped speaker
+    raw = (torch.rand(B, L, 4, generator=g) > 0.55).to(torch.uint8)
+    raw[0, :, 3] = 0
+    raw[1, :, 2] = raw[1, :, 1]
+    eng = _engine(gpu, B, N)
+    min_frames = math.ceil(L * 400 / N)
+    filt, masks = eng.prepare_masks(raw.to(gpu), 11, True, min_frames)
+    torch.cuda.synchronize()
+    ref_f = median_filter(raw.numpy().astype(np.float32), size=(1, 11, 1), mode="reflect")
+    assert np.array_equal(filt.cpu().numpy(), ref_f.astype(np.uint8))
+    clean = ref_f * (ref_f.sum(axis=2, keepdims=True) < 2)
+    ref_m = np.stack([[clean[b, :, s] if clean[b, :, s].sum() > min_frames else ref_f[b, :, s]
+                       for s in range(4)] for b in range(B)])
+    assert np.array_equal(masks.cpu().numpy(), ref_m.astype(np.float32))
+    emb = eng.embed(wave.to(gpu), masks)
+    torch.cuda.synchronize()
+    ref = emb_model.emb_forward(emb_model.emb_state_dict(0), wave, torch.from_numpy(ref_m.astype(np.float32)))
+    rel = (emb.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert rel < 1e-4

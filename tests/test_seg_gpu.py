@@ -111,3 +111,38 @@ def test_seg_batch_and_ragged_lengths(built_lib, gpu):
     assert (lp.cpu() - ref).abs().max().item() < 1e-3
     with pytest.raises(Exception):
         eng.segment(torch.zeros(6, 12000, device=gpu))  # B > max_batch must fail loudly
+
+
+def test_seg_16s_window_cli_default(built_lib, gpu):
+    """the reference CLI default is 16 s windows (diarizen/pipelines/inference.py:224-228): L = 799"""
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from oracle import seg_model
+    from oracle.gen_golden import synth_wave
+    cfg = get_seg_config("wavlm_large_s80_md")
+    sd = seg_model.seg_state_dict(cfg, 0)
+    wave = synth_wave(1, 256000, 41)
+    eng = Engine(cfg, sd, max_batch=1, max_samples=256000, precision="f32", device=gpu)
+    logp, ml = eng.segment(wave.to(gpu))
+    torch.cuda.synchronize()
+    ref = seg_model.seg_forward(sd, cfg, wave)
+    assert logp.shape == ref.shape == (1, 799, 11)
+    assert (logp.cpu() - ref).abs().max().item() < 1e-3
+    assert torch.equal(ml.cpu(), seg_model.to_multilabel(ref, cfg).to(torch.uint8))
+
+
+def test_seg_dense_wavlm_base(built_lib, gpu):
+    """un-pruned wavlm_base (12 x 12 heads, FFN 3072, 512-channel extractor, post-norm, group-norm)"""
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from oracle import seg_model
+    from oracle.gen_golden import synth_wave
+    cfg = get_seg_config("wavlm_base")
+    sd = seg_model.seg_state_dict(cfg, 3)
+    wave = synth_wave(2, 16000, 42)
+    eng = Engine(cfg, sd, max_batch=2, max_samples=16000, precision="f32", device=gpu)
+    logp, ml = eng.segment(wave.to(gpu))
+    torch.cuda.synchronize()
+    ref = seg_model.seg_forward(sd, cfg, wave)
+    assert (logp.cpu() - ref).abs().max().item() < 1e-3
+    assert torch.equal(logp.cpu().argmax(-1), ref.argmax(-1))
