@@ -437,6 +437,15 @@ int launch_cfg(const dzn_gemm_desc& d, hipStream_t s) {
 
 template <bool LOWP>
 int launch_prec(const dzn_gemm_desc& d, hipStream_t s) {
+  static const char* force = getenv("DZN_GEMM_CFG");   // tuning knob: force one tile shape
+  if (force) {
+    if (!strcmp(force, "128x32")) return launch_cfg<128, 32, 4, 1, LOWP>(d, s);
+    if (!strcmp(force, "256x32")) return launch_cfg<256, 32, 4, 1, LOWP>(d, s);
+    if (!strcmp(force, "256x64")) return launch_cfg<256, 64, 4, 1, LOWP>(d, s);
+    if (!strcmp(force, "128x64")) return launch_cfg<128, 64, 2, 2, LOWP>(d, s);
+    if (!strcmp(force, "64x64")) return launch_cfg<64, 64, 2, 2, LOWP>(d, s);
+    if (!strcmp(force, "128x128")) return launch_cfg<128, 128, 2, 2, LOWP>(d, s);
+  }
   if (d.N <= 32) return launch_cfg<256, 32, 4, 1, LOWP>(d, s);
   if (d.N <= 64) return launch_cfg<128, 64, 2, 2, LOWP>(d, s);
   // pick the column-tile width that wastes the fewest padded columns (irregular pruned widths:
