@@ -5,7 +5,7 @@
 
 One "step" = one pass of the device hot path over ONE synthetic recording per rank
 (BASELINE.json configs[2]: wavlm-large-s80, 30 min of 16 kHz mono, window 8 s, step 0.8 s ->
-2241 windows, batch 128 by default: windows are independent, results do not depend on the batch): for every batch of windows  segmentation (WavLM + Conformer + powerset)
+2241 windows, batch 256 by default: windows are independent, results do not depend on the batch): for every batch of windows  segmentation (WavLM + Conformer + powerset)
 -> median filter + overlap-excluded masks -> ResNet34 embeddings (trunk shared by the 4 local
 speakers), all through the C ABI of libdzn_hip.so, the recording already resident in HBM.  The
 step ends with the hand-off the host clustering needs: u8 decisions + f32 embeddings copied to
@@ -64,8 +64,8 @@ def pmc_traffic(kernel_class: str, args):
     WRITE_SIZE on this same command, gfx950 correction applied; scripts/pmc_traffic.py).  bench.py
     cannot run rocprofv3 on itself, so the figure is read from profiles/ and only when the workload
     matches the one the passes were taken on."""
-    path = ROOT / "profiles" / "r1b_pmc_traffic_30min_b128.json"
-    if not path.exists() or args.minutes != 30.0 or args.batch != 128 or args.precision != "f32" \
+    path = ROOT / "profiles" / f"r1_pmc_traffic_30min_b{args.batch}.json"
+    if not path.exists() or args.minutes != 30.0 or args.precision != "f32" \
             or args.model != "wavlm_large_s80_md" or args.window != 8.0:
         return None
     table = json.loads(path.read_text())
@@ -106,7 +106,7 @@ def main():
                     choices=["f32", "bf16"])
     ap.add_argument("--minutes", type=float, default=30.0)
     ap.add_argument("--window", type=float, default=8.0)
-    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--model", default="wavlm_large_s80_md")
     ap.add_argument("--stage", default="full", choices=["full", "seg"],
                     help="seg = segmentation-only (BASELINE configs[1]: --model wavlm_base_s80_md --window 5 "

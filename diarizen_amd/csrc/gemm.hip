@@ -448,6 +448,8 @@ int launch_prec(const dzn_gemm_desc& d, hipStream_t s) {
   }
   if (d.N <= 32) return launch_cfg<256, 32, 4, 1, LOWP>(d, s);
   if (d.N <= 64) return launch_cfg<128, 64, 2, 2, LOWP>(d, s);
+  // short contractions are epilogue-bound: narrower tiles -> 3 resident workgroups per CU hide it
+  if (d.K <= 512 && (d.N % 64) == 0) return launch_cfg<128, 64, 2, 2, LOWP>(d, s);
   // pick the column-tile width that wastes the fewest padded columns (irregular pruned widths:
   // 153 -> 160, q/k/v = 192 h, FFN 96..1770); ties go to the wider tile (more reuse per A fragment)
   const int cand[4] = {192, 160, 128, 96};
