@@ -70,6 +70,34 @@ class SegConfig:
         return n
 
 
+def seg_config_from_wavlm_kwargs(kw: dict, name: str = "custom") -> SegConfig:
+    """Build a SegConfig from the kwargs dict of `wav2vec2_model(**config)` as stored in a WavLM
+    checkpoint's "config" entry (load_wavlm file branch, model_wavlm_conformer.py:209-221) or listed
+    in diarizen/models/module/wavlm_config.py.  Pruning must be disabled (:216-218)."""
+    for k, v in kw.items():
+        if "prune" in k and v is not False:
+            raise ValueError(f"Pruning must be disabled. Found: {k}={v}")
+    if kw.get("extractor_conv_bias", False):
+        raise ValueError("extractor_conv_bias=True is not supported")
+    if not all(kw.get("encoder_use_feed_forward", [True])):
+        raise ValueError("layers without feed-forward are not supported")
+    convs = kw["extractor_conv_layer_config"]
+    heads_total = kw["encoder_total_num_heads"]
+    if len(set(heads_total)) != 1:
+        raise ValueError("encoder_total_num_heads must be uniform")
+    use_attn = kw["encoder_use_attention"]
+    remaining = tuple(tuple(h) if u else () for h, u in zip(kw["encoder_remaining_heads"], use_attn))
+    return SegConfig(
+        name=name, extractor_layer_norm=kw["extractor_mode"] == "layer_norm",
+        normalize_waveform=bool(kw.get("normalize_waveform", False)),
+        conv_channels=tuple(c for c, _, _ in convs), conv_kernels=tuple(k for _, k, _ in convs),
+        conv_strides=tuple(s for _, _, s in convs), embed_dim=kw["encoder_embed_dim"],
+        total_heads=heads_total[0], layer_norm_first=bool(kw["encoder_layer_norm_first"]),
+        remaining_heads=remaining, ffn_dims=tuple(kw["encoder_ff_interm_features"]),
+        pos_conv_kernel=kw["encoder_pos_conv_kernel"], pos_conv_groups=kw["encoder_pos_conv_groups"],
+        num_buckets=kw.get("encoder_num_buckets", 320), max_distance=kw.get("encoder_max_distance", 800))
+
+
 def _dense(n_layers: int, heads: int) -> Tuple[Tuple[int, ...], ...]:
     return tuple(tuple(range(heads)) for _ in range(n_layers))
 

@@ -67,13 +67,19 @@ class WavLMConformer:
                  max_speakers_per_chunk: int = 4, max_speakers_per_frame: int = 2,
                  chunk_size: int = 5, num_channels: int = 8, selected_channel: int = 0,
                  sample_rate: int = 16000, precision: str = "f32", max_batch: int = 32):
-        if os.path.isfile(wavlm_src):
-            raise NotImplementedError("checkpoint-embedded WavLM configs (load_wavlm file branch, "
-                                      "model_wavlm_conformer.py:209-221) are a 'next' row")
         if use_posi or output_activate_function:
             raise NotImplementedError("use_posi / output activation are unused by the released confs")
         from dataclasses import replace
-        cfg = get_seg_config(wavlm_src)
+        if os.path.isfile(wavlm_src):
+            # load_wavlm file branch (model_wavlm_conformer.py:209-221): {"config": ..., "state_dict": ...};
+            # only the architecture is needed here, the weights arrive through load_state_dict()
+            ckpt = torch.load(wavlm_src, map_location="cpu", weights_only=False)
+            if "config" not in ckpt or "state_dict" not in ckpt:
+                raise ValueError("Checkpoint must contain 'config' and 'state_dict'.")
+            from .configs import seg_config_from_wavlm_kwargs
+            cfg = seg_config_from_wavlm_kwargs(ckpt["config"], name=os.path.basename(wavlm_src))
+        else:
+            cfg = get_seg_config(wavlm_src)
         self.cfg: SegConfig = replace(cfg, attention_in=attention_in, ffn_hidden=ffn_hidden,
                                       conf_heads=num_head, conf_layers=num_layer,
                                       conf_kernel=kernel_size,

@@ -192,3 +192,40 @@ def test_window_sharding_and_gather_gloo_world2(C, tmp_path):
         assert gs.shape == (C, 5, 4) and ge.shape == (C, 4, 8)
         assert torch.equal(ge[:, 0, 0], torch.arange(C, dtype=torch.float32))   # window order kept
         assert torch.equal(gs[:, 0, 0].long(), torch.arange(C) % 251)
+
+
+# ----------------------------------------------------------------------------- configs
+def test_seg_config_from_checkpoint_kwargs_matches_named_configs(tmp_path):
+    """load_wavlm's checkpoint branch (model_wavlm_conformer.py:209-221): architecture from the
+    kwargs dict stored in the checkpoint; must reproduce the named configs field by field."""
+    from dataclasses import replace
+    from diarizen_amd.configs import get_seg_config, seg_config_from_wavlm_kwargs
+    for name in ("wavlm_large_s80_md", "wavlm_base_s80_md", "wavlm_base"):
+        ref = get_seg_config(name)
+        kw = {
+            "extractor_mode": "layer_norm" if ref.extractor_layer_norm else "group_norm",
+            "extractor_conv_layer_config": list(zip(ref.conv_channels, ref.conv_kernels, ref.conv_strides)),
+            "extractor_conv_bias": False, "encoder_embed_dim": ref.embed_dim,
+            "encoder_pos_conv_kernel": 128, "encoder_pos_conv_groups": 16,
+            "encoder_num_layers": ref.n_layers, "encoder_use_attention": list(ref.use_attention),
+            "encoder_use_feed_forward": [True] * ref.n_layers,
+            "encoder_total_num_heads": [ref.total_heads] * ref.n_layers,
+            "encoder_remaining_heads": [list(h) for h in ref.remaining_heads],
+            "encoder_num_buckets": 320, "encoder_max_distance": 800,
+            "encoder_ff_interm_features": list(ref.ffn_dims),
+            "encoder_layer_norm_first": ref.layer_norm_first, "normalize_waveform": ref.normalize_waveform,
+            "extractor_prune_conv_channels": False, "encoder_prune_attention_heads": False,
+        }
+        assert replace(seg_config_from_wavlm_kwargs(kw), name=name) == ref
+        kw["encoder_prune_attention_heads"] = True
+        with pytest.raises(ValueError):
+            seg_config_from_wavlm_kwargs(kw)
+    # the facade accepts a checkpoint path as wavlm_src, exactly like the reference Model
+    from diarizen_amd.models import WavLMConformer
+    kw["encoder_prune_attention_heads"] = False
+    p = tmp_path / "wavlm.pt"
+    torch.save({"config": kw, "state_dict": {}}, p)
+    m = WavLMConformer(wavlm_src=str(p), wavlm_layer_num=13, wavlm_feat_dim=768)
+    assert m.cfg.ffn_dims == get_seg_config("wavlm_base").ffn_dims and m.num_frames(80000) == 249
+    with pytest.raises(RuntimeError):
+        m.to("cpu")                      # no CPU fallback, loudly

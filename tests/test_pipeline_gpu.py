@@ -73,3 +73,60 @@ def test_plugin_facades(pipeline, gpu):
     assert e.min_num_samples == 400                               # speaker_verification.py:677-691
     out = e(x[:, :, :32000], torch.ones(2, 99))
     assert out.shape == (2, 256) and np.isfinite(out).all()
+
+
+def test_from_pretrained_local_hub_dir_vbx(built_lib, gpu, tmp_path):
+    """drop-in construction path: a hub directory laid out like BUT-FIT/diarizen-wavlm-*-s80-md
+    (config.toml with the REFERENCE class path, pytorch_model.bin = plain state_dict, plda/*.npz) plus
+    the WeSpeaker Lightning-style checkpoint ({'state_dict': ...}); VBx clustering branch."""
+    import torch as T
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.pipeline import DiariZenPipeline
+    from diarizen_amd.weights import emb_state_dict, seg_state_dict
+    hub = tmp_path / "hub"
+    (hub / "plda").mkdir(parents=True)
+    (hub / "wespeaker").mkdir()
+    (hub / "config.toml").write_text('''
+[model]
+path = "diarizen.models.eend.model_wavlm_conformer.Model"
+[model.args]
+wavlm_src = "wavlm_large_s80_md"
+wavlm_layer_num = 25
+wavlm_feat_dim = 1024
+attention_in = 256
+ffn_hidden = 1024
+num_head = 4
+num_layer = 4
+chunk_size = 8
+selected_channel = 0
+[inference.args]
+seg_duration = 8
+segmentation_step = 0.1
+batch_size = 16
+apply_median_filtering = true
+[clustering.args]
+method = "VBxClustering"
+min_speakers = 1
+max_speakers = 20
+ahc_criterion = "distance"
+ahc_threshold = 0.6
+Fa = 0.07
+Fb = 0.8
+lda_dim = 128
+max_iters = 20
+''')
+    cfg = get_seg_config("wavlm_large_s80_md")
+    T.save(seg_state_dict(cfg, 0), hub / "pytorch_model.bin")
+    T.save({"state_dict": emb_state_dict(0), "pyannote.audio": {"architecture": {"class": "WeSpeakerResNet34"}}},
+           hub / "wespeaker" / "pytorch_model.bin")
+    g = np.load(os.path.join(GOLD, "host_clustering.npz"))
+    for f in ("xvec_transform", "plda"):
+        (hub / "plda" / f"{f}.npz").write_bytes(g["plda_" + f].tobytes())
+    pipe = DiariZenPipeline.from_pretrained(str(hub), rttm_out_dir=str(tmp_path / "rttm"), device=gpu)
+    assert pipe.batch_size == 16 and pipe.apply_median_filtering
+    ann = pipe(WAV, sess_name="EN2002a")
+    gold = np.load(os.path.join(GOLD, "e2e_EN2002a_30s.npz"))
+    assert (tmp_path / "rttm" / "EN2002a.rttm").read_text() == pipe.host_stage(gold["seg"], gold["emb"], "EN2002a").to_rttm()
+    assert ann.to_rttm().count("SPEAKER EN2002a 1 ") >= 1
+    with pytest.raises(Exception):
+        DiariZenPipeline.from_pretrained(str(tmp_path / "missing"), cache_dir=str(tmp_path))
