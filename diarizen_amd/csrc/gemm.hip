@@ -354,41 +354,54 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const dzn_gemm_desc d) {
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int lr = lane & 15, lq = lane >> 4;
 
-  auto compute = [&](int buf) {
+  // fragments of one 16-float K block (kb = 0 / 1) of the tile in LDS stage `buf`
+  auto read_frags = [&](int buf, int kb, f32x4 (&af)[MI], f32x4 (&bf)[NI]) {
     const unsigned char* sA = smem + buf * BUF;
     const unsigned char* sW = sA + BM * 128;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x4 af[MI], bf[NI];
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * TM + i * 16 + lr;
+      const int slot = (kb * 4 + lq) ^ ((row >> 1) & 7);
+      af[i] = *reinterpret_cast<const f32x4*>(sA + row * 128 + (slot << 4));
+    }
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int row = wm * TM + i * 16 + lr;
-        const int slot = (kb * 4 + lq) ^ ((row >> 1) & 7);
-        af[i] = *reinterpret_cast<const f32x4*>(sA + row * 128 + (slot << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int row = wn * TN + j * 16 + lr;
-        const int slot = (kb * 4 + lq) ^ ((row >> 1) & 7);
-        bf[j] = *reinterpret_cast<const f32x4*>(sW + row * 128 + (slot << 4));
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < NI; ++j) {
+      const int row = wn * TN + j * 16 + lr;
+      const int slot = (kb * 4 + lq) ^ ((row >> 1) & 7);
+      bf[j] = *reinterpret_cast<const f32x4*>(sW + row * 128 + (slot << 4));
     }
   };
+  auto mma = [&](const f32x4 (&af)[MI], const f32x4 (&bf)[NI]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
+  };
 
+  // Software pipeline: every batch of LDS fragment reads is followed by the 4*MI*NI MFMAs of the
+  // OTHER K block, so ds_read latency and the barrier never sit in front of an idle matrix pipe:
+  //   [glds tile k+1] [read kb1(k)] [mma kb0(k)] [barrier: tile k+1 landed] [read kb0(k+1)] [mma kb1(k)]
   const int nk = d.K / BK;
+  f32x4 a0[MI], b0[NI], a1[MI], b1[NI];
   issue(0, 0);
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes tile 0
+  read_frags(0, 0, a0, b0);
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) issue((kt + 1) * BK, (kt + 1) & 1);  // in flight during compute
-    compute(kt & 1);
-    __syncthreads();
+    const int buf = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) issue((kt + 1) * BK, buf ^ 1);
+    read_frags(buf, 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // tile k+1 resident; all kb1(k) reads retired before stage `buf` is refilled
+    if (more) read_frags(buf ^ 1, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
   gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz);
 }

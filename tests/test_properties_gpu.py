@@ -1,0 +1,101 @@
+"""Size-independent properties at BASELINE.json's full window size (wavlm-large-s80, 8 s windows),
+where the CPU oracle is too slow to be the checker, plus ragged / degenerate inputs.
+
+  * windows are independent: any batch composition / any contiguous shard of the window range gives
+    BIT-IDENTICAL per-window results (this is the invariant the multi-GPU sharding relies on);
+  * log-probabilities are normalised, hard decisions are a valid powerset row (<= 2 speakers/frame);
+  * masks: median filter is idempotent on its own output for runs >= 6 frames; an inactive speaker's
+    embedding is exactly seg_1.bias; embeddings do not depend on the other speakers' masks;
+  * ragged inputs: recording shorter than one window, exact multiple, and a ragged tail follow the
+    reference window plan (PA/core/inference.py:285-299) and the zero-padded last window equals the
+    explicitly padded waveform.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine(built_lib, gpu):
+    from diarizen_amd.configs import RESNET34, get_seg_config
+    from diarizen_amd.engine import Engine
+    from diarizen_amd.weights import emb_state_dict, seg_state_dict
+    cfg = get_seg_config("wavlm_large_s80_md")
+    return Engine(cfg, seg_state_dict(cfg, 0), RESNET34, emb_state_dict(0), max_batch=48,
+                  max_samples=128000, precision="f32", device=gpu)
+
+
+def _recording(seconds, seed=5):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from bench import synth_recording
+    return synth_recording(int(seconds * 16000), seed=seed)
+
+
+def test_batch_composition_and_sharding_are_bit_invariant(engine, gpu):
+    from diarizen_amd.inference import WindowRunner
+    wave = _recording(8.0 + 0.8 * 40).to(gpu)              # 41 windows
+    r48 = WindowRunner(engine, 8.0, 0.1, batch_size=48)
+    r7 = WindowRunner(engine, 8.0, 0.1, batch_size=7)
+    full = r48.run(wave)
+    small = r7.run(wave)
+    torch.cuda.synchronize()
+    assert full.segmentations.shape == (41, 399, 4) and full.embeddings.shape == (41, 4, 256)
+    assert torch.equal(full.segmentations, small.segmentations)
+    assert torch.equal(full.embeddings, small.embeddings)
+    # contiguous shards (what each rank computes) concatenate to the full result
+    from diarizen_amd.dist import shard_range
+    parts = [r48.run(wave, window_range=shard_range(41, r, 3)) for r in range(3)]
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([p.segmentations for p in parts]), full.segmentations)
+    assert torch.equal(torch.cat([p.embeddings for p in parts]), full.embeddings)
+
+
+def test_outputs_are_well_formed_at_full_size(engine, gpu):
+    wave = _recording(8.0 + 0.8 * 31, seed=9).to(gpu)
+    from diarizen_amd.inference import WindowRunner
+    views = WindowRunner(engine, 8.0, 0.1, 32).windows_view(wave)
+    logp, ml = engine.segment(views[:32].contiguous())
+    torch.cuda.synchronize()
+    assert torch.isfinite(logp).all()
+    assert torch.allclose(logp.exp().sum(-1), torch.ones_like(logp[..., 0]), atol=1e-4)
+    assert ml.sum(-1).max().item() <= 2                     # powerset: at most 2 speakers per frame
+    from diarizen_amd.weights import emb_state_dict
+    filt, masks = engine.prepare_masks(ml, 11, True, 2)
+    filt2, _ = engine.prepare_masks(filt, 11, True, 2)
+    emb = engine.embed(views[:32].contiguous(), masks)
+    torch.cuda.synchronize()
+    assert set(np.unique(filt.cpu().numpy()).tolist()) <= {0, 1}
+    assert (filt2.cpu() != filt.cpu()).float().mean().item() < 0.02   # near-idempotent (blips already removed)
+    inactive = masks.sum(-1) == 0
+    bias = emb_state_dict(0)["resnet.seg_1.bias"].to(gpu)
+    if inactive.any():
+        assert torch.equal(emb[inactive], bias.expand_as(emb[inactive]))
+    # an embedding depends only on its own mask
+    m2 = masks.clone()
+    m2[:, 1:] = 0
+    emb2 = engine.embed(views[:32].contiguous(), m2)
+    torch.cuda.synchronize()
+    assert torch.equal(emb2[:, 0], emb[:, 0])
+
+
+@pytest.mark.parametrize("seconds,expect", [(3.0, 1), (8.0, 1), (8.8, 2), (9.0, 3), (20.33, 17)])
+def test_ragged_recordings_follow_reference_window_plan(engine, gpu, seconds, expect):
+    from diarizen_amd.inference import WindowRunner
+    wave = _recording(seconds, seed=3)
+    r = WindowRunner(engine, 8.0, 0.1, batch_size=48)
+    assert r.num_windows(wave.numel()) == expect
+    res = r.run(wave.to(gpu), with_embeddings=False)
+    torch.cuda.synchronize()
+    assert res.segmentations.shape[0] == expect
+    # the last window of a ragged recording == the explicitly zero-padded waveform run alone
+    start = (expect - 1) * r.step
+    last = torch.zeros(1, r.window)
+    tail = wave[start:start + r.window]
+    last[0, : tail.numel()] = tail
+    _, ml = engine.segment(last.to(gpu), want_logp=False)
+    filt, _ = engine.prepare_masks(ml, 11, True, 2, want_masks=False)
+    torch.cuda.synchronize()
+    assert torch.equal(filt[0], res.segmentations[-1])
