@@ -84,6 +84,7 @@ class DznGemmDesc(C.Structure):
         ("c_z0", C.c_int64), ("c_z1", C.c_int64), ("b_z0", C.c_int64), ("b_z1", C.c_int64),
         ("precision", C.c_int32),
         ("alg_flops", C.c_double),
+        ("a_bf16", C.c_int32), ("c_bf16", C.c_int32), ("r_bf16", C.c_int32),
     ]
 
 

@@ -19,9 +19,9 @@
 
 namespace {
 
-template <bool BIAS>
+template <bool BIAS, typename TO>
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv,
-                                                   float* __restrict__ out,
+                                                   TO* __restrict__ out,
                                                    const float* __restrict__ gate,
                                                    const float* __restrict__ table,
                                                    const int32_t* __restrict__ head_idx, int B,
@@ -181,8 +181,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
     const int q = qt * 64 + wave * 16 + lq * 4 + rg;
     if (q < L) {
       const float inv = 1.0f / lt;
-      float4 o = make_float4(O[0][rg] * inv, O[1][rg] * inv, O[2][rg] * inv, O[3][rg] * inv);
-      *reinterpret_cast<float4*>(out + (rowbase + q) * ldo + j * 64 + lr * 4) = o;
+      TO* op = out + (rowbase + q) * ldo + j * 64 + lr * 4;
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) st_act(op, dblk, O[dblk][rg] * inv);
     }
   }
 }
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
 //   t = Linear(64->8)(y[row, H*64:(H+1)*64]) ; (a, b) = sigmoid(sum t[0:4]), sigmoid(sum t[4:8])
 //   gate = a * (b * const[H] - 1) + 2
 // One wavefront per row; lane (H = lane/4, sub = lane%4) computes outputs 2*sub, 2*sub+1.
-__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ y, int64_t ldy,
+template <typename TI>
+__global__ __launch_bounds__(256) void gate_kernel(const TI* __restrict__ y, int64_t ldy,
                                                    const float* __restrict__ Wg,  // [8,64]
                                                    const float* __restrict__ bg,  // [8]
                                                    const float* __restrict__ cst,  // [Htot]
@@ -209,12 +211,12 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ y, 
     const int H = H0 + (lane >> 2);
     float t0 = 0.f, t1 = 0.f;
     if (H < Htot) {
-      const float* yp = y + row * ldy + H * 64;
+      const TI* yp = y + row * ldy + H * 64;
       const float* w0 = sW + (2 * sub) * 64;
       const float* w1 = w0 + 64;
 #pragma unroll 8
       for (int d = 0; d < 64; ++d) {
-        const float v = yp[d];
+        const float v = ld_act(yp, d);
         t0 = fmaf(v, w0[d], t0);
         t1 = fmaf(v, w1[d], t1);
       }
@@ -238,42 +240,52 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ y, 
 
 }  // namespace
 
-int launch_attention(const float* qkv, float* out, const float* gate, const float* table,
-                     const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
-                     float scale, int precision, hipStream_t s) {
-  (void)precision;
+int launch_attention_t(const float* qkv, void* out, int out_bf16, const float* gate, const float* table,
+                       const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
+                       float scale, hipStream_t s) {
   if (h <= 0 || B <= 0 || L <= 0) return DZN_OK;
   const bool bias = gate && table && head_idx;
   const size_t lds = (2 * 64 * 64 + (bias ? (2 * L - 1) : 0)) * sizeof(float);
   if (lds > 160 * 1024) return DZN_E_INVALID;
   dim3 grid((L + 63) / 64, h, B);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   // algorithmic flops: QK^T and PV, 2*L*L*64 each per (batch, head)
   const int pid = prof_begin(s, bias ? "attention_relpos_f32" : "attention_f32",
                              4.0 * B * h * (double)L * L * 64.0, 0.0);
-  if (bias)
-    hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), lds, s, qkv, out, gate, table,
-                       head_idx, B, L, h, Htot, ldqkv, ldo, scale);
-  else
-    hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), lds, s, qkv, out, gate, table,
-                       head_idx, B, L, h, Htot, ldqkv, ldo, scale);
+#define DZN_ATT(BIASV, T)                                                                          \
+  hipLaunchKernelGGL((attn_kernel<BIASV, T>), grid, dim3(256), lds, s, qkv, static_cast<T*>(out), gate, \
+                     table, head_idx, B, L, h, Htot, ldqkv, ldo, scale)
+  if (bias) {
+    if (out_bf16) DZN_ATT(true, u16); else DZN_ATT(true, float);
+  } else {
+    if (out_bf16) DZN_ATT(false, u16); else DZN_ATT(false, float);
+  }
+#undef DZN_ATT
   prof_end(pid, s);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_attention(const float* qkv, float* out, const float* gate, const float* table,
+                     const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
+                     float scale, int precision, hipStream_t s) {
+  (void)precision;
+  return launch_attention_t(qkv, out, 0, gate, table, head_idx, B, L, h, Htot, ldqkv, ldo, scale, s);
+}
+
+int launch_gate_t(const void* y, int y_bf16, int64_t ldy, const float* Wg, const float* bg,
+                  const float* cst, float* gate, int64_t rows, int Htot, hipStream_t s) {
+  if (rows <= 0) return DZN_OK;
+  if (y_bf16)
+    hipLaunchKernelGGL(gate_kernel<u16>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s,
+                       static_cast<const u16*>(y), ldy, Wg, bg, cst, gate, rows, Htot);
+  else
+    hipLaunchKernelGGL(gate_kernel<float>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s,
+                       static_cast<const float*>(y), ldy, Wg, bg, cst, gate, rows, Htot);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
 int launch_gate(const float* y, int64_t ldy, const float* Wg, const float* bg, const float* cst,
                 float* gate, int64_t rows, int Htot, hipStream_t s) {
-  if (rows <= 0) return DZN_OK;
-  hipLaunchKernelGGL(gate_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, y, ldy, Wg, bg,
-                     cst, gate, rows, Htot);
-  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+  return launch_gate_t(y, 0, ldy, Wg, bg, cst, gate, rows, Htot, s);
 }
 
 extern "C" int dzn_op_attention(const float* qkv, float* out, const float* gate,

@@ -43,6 +43,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// ---- activation element access: fp32 buffers, or bf16 buffers in the bf16 engine mode ----
+__device__ __forceinline__ float ld_act(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float ld_act(const u16* p, int64_t i) {
+  return __uint_as_float(((unsigned int)p[i]) << 16);
+}
+__device__ __forceinline__ void st_act(float* p, int64_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void st_act(u16* p, int64_t i, float v) {
+  __bf16 h = (__bf16)v;  // round to nearest even
+  p[i] = *reinterpret_cast<u16*>(&h);
+}
+
 // host-side float -> bf16 (round to nearest even), used when packing weights
 static inline u16 f32_to_bf16_host(float f) {
   uint32_t u;
@@ -54,12 +65,22 @@ static inline u16 f32_to_bf16_host(float f) {
 
 // ---- kernel launchers (implemented in the .hip files) ----
 int launch_gemm(const dzn_gemm_desc& d, hipStream_t s);
+int launch_gemm_lowp(const dzn_gemm_desc& d, hipStream_t s);  // gemm_lowp.hip: A and W both bf16
 int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* g,
                      const float* b, int64_t rows, int C, int Cpad, float eps, int gelu,
                      hipStream_t s);
+int launch_layernorm_t(const void* x, int x_bf16, int64_t ldx, void* y, int y_bf16, int64_t ldy,
+                       const float* g, const float* b, const float* post, int64_t rows, int C, int Cpad,
+                       float eps, int gelu, hipStream_t s);
+int launch_cast_bf16(const float* x, void* y, int64_t n, hipStream_t s);
 int launch_wave_stats(const float* w, int B, int N, float eps, float* stats, hipStream_t s);
 int launch_gate(const float* y, int64_t ldy, const float* Wg, const float* bg, const float* cst,
                 float* gate, int64_t rows, int Htot, hipStream_t s);
+int launch_gate_t(const void* y, int y_bf16, int64_t ldy, const float* Wg, const float* bg,
+                  const float* cst, float* gate, int64_t rows, int Htot, hipStream_t s);
+int launch_attention_t(const float* qkv, void* out, int out_bf16, const float* gate, const float* table,
+                       const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
+                       float scale, hipStream_t s);
 int launch_attention(const float* qkv, float* out, const float* gate, const float* table,
                      const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
                      float scale, int precision, hipStream_t s);
@@ -67,16 +88,17 @@ int launch_attention(const float* qkv, float* out, const float* gate, const floa
 // frontend.hip
 int launch_conv0(const float* wave, int B, int N, const float* stats, const float* w,
                  const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
-                 int layer_norm, float eps, float* out, hipStream_t st);
-int launch_groupnorm_gelu(float* x, int B, int T, int C, int64_t ld, const float* gamma,
-                          const float* beta, float eps, float* stats, hipStream_t st);
-int launch_pad_rows(const float* x, float* xpad, int B, int L, int Lp, int pad, int D,
+                 int layer_norm, float eps, void* out, int out_bf16, hipStream_t st);
+int launch_groupnorm_gelu(const float* x, void* y, int y_bf16, int B, int T, int C, int Cp, int64_t ld,
+                          const float* gamma, const float* beta, float eps, float* stats, hipStream_t st);
+int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int Lp, int pad, int D,
                     hipStream_t st);
 int launch_ws_accum(const float* x, float* ws, float w, int init, int64_t n, hipStream_t st);
-int launch_col_scale(float* x, int64_t rows, int C, int64_t ld, const float* scale, hipStream_t st);
+int launch_col_scale(void* x, int x_bf16, int64_t rows, int C, int64_t ld, const float* scale,
+                     hipStream_t st);
 // conformer.hip
-int launch_glu_dwconv(const float* u, int64_t ldu, const float* w, const float* bias, float* out,
-                      int64_t ldo, int B, int L, int A, int ks, hipStream_t st);
+int launch_glu_dwconv(const float* u, int64_t ldu, const float* w, const float* bias, void* out,
+                      int out_bf16, int64_t ldo, int B, int L, int A, int ks, hipStream_t st);
 int launch_classify(const float* z, int64_t ldz, const float* W, const float* bias,
                     const uint8_t* mapping, int64_t rows, int A, int NC, int S, float* logp,
                     uint8_t* multilabel, hipStream_t st);
@@ -86,9 +108,9 @@ int launch_frame_prep(const float* wave, int B, int N, int T, int flen, int fshi
 int launch_power(const float* spec, int64_t rows, int nb, float* pw, hipStream_t st);
 int launch_log_cmn(float* mel, int B, int T, int NB, float eps, hipStream_t st);
 int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* w, const float* bias,
-                     float* img, hipStream_t st);
-int launch_stats_pool(const float* img, int B, int H, int W, int C, const float* masks, int S, int L,
-                      float* stats, hipStream_t st);
+                     void* img, int out_bf16, hipStream_t st);
+int launch_stats_pool(const void* img, int in_bf16, int B, int H, int W, int C, const float* masks, int S,
+                      int L, float* stats, hipStream_t st);
 
 // post.hip
 int launch_prepare_masks(const uint8_t* ml, int B, int L, int S, int median, int exclude_overlap,

@@ -16,11 +16,11 @@ namespace {
 
 constexpr int DW_TT = 32;
 
-template <int KS>
+template <int KS, typename TO>
 __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict__ u, int64_t ldu,
                                                          const float* __restrict__ w,  // [A, KS] folded
                                                          const float* __restrict__ bias,  // [A] folded
-                                                         float* __restrict__ out, int64_t ldo, int L,
+                                                         TO* __restrict__ out, int64_t ldo, int L,
                                                          int A) {
   constexpr int PAD = (KS - 1) / 2;
   constexpr int NIN = DW_TT + KS - 1;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < KS; ++j) a = fmaf(in[t + j], wr[j], a);
         a += bc;
-        out[((int64_t)b * L + t0 + t) * ldo + c] = swishf_(a);
+        st_act(out, ((int64_t)b * L + t0 + t) * ldo + c, swishf_(a));
       }
     }
   }
@@ -99,21 +99,24 @@ __global__ __launch_bounds__(256) void classify_kernel(const float* __restrict__
 
 }  // namespace
 
-int launch_glu_dwconv(const float* u, int64_t ldu, const float* w, const float* bias, float* out,
-                      int64_t ldo, int B, int L, int A, int ks, hipStream_t st) {
+int launch_glu_dwconv(const float* u, int64_t ldu, const float* w, const float* bias, void* out,
+                      int out_bf16, int64_t ldo, int B, int L, int A, int ks, hipStream_t st) {
   dim3 grid((L + DW_TT - 1) / DW_TT, B);
   const int threads = A >= 256 ? 256 : (A >= 128 ? 128 : 64);
-  if (ks == 31)
-    hipLaunchKernelGGL(glu_dwconv_kernel<31>, grid, dim3(threads), 0, st, u, ldu, w, bias, out, ldo,
-                       L, A);
-  else if (ks == 7)
-    hipLaunchKernelGGL(glu_dwconv_kernel<7>, grid, dim3(threads), 0, st, u, ldu, w, bias, out, ldo,
-                       L, A);
-  else if (ks == 15)
-    hipLaunchKernelGGL(glu_dwconv_kernel<15>, grid, dim3(threads), 0, st, u, ldu, w, bias, out, ldo,
-                       L, A);
-  else
-    return DZN_E_INVALID;
+#define DZN_DW(KSV)                                                                                   \
+  do {                                                                                                \
+    if (out_bf16)                                                                                     \
+      hipLaunchKernelGGL((glu_dwconv_kernel<KSV, u16>), grid, dim3(threads), 0, st, u, ldu, w, bias,  \
+                         static_cast<u16*>(out), ldo, L, A);                                          \
+    else                                                                                              \
+      hipLaunchKernelGGL((glu_dwconv_kernel<KSV, float>), grid, dim3(threads), 0, st, u, ldu, w, bias, \
+                         static_cast<float*>(out), ldo, L, A);                                        \
+  } while (0)
+  if (ks == 31) DZN_DW(31);
+  else if (ks == 7) DZN_DW(7);
+  else if (ks == 15) DZN_DW(15);
+  else return DZN_E_INVALID;
+#undef DZN_DW
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 

@@ -93,11 +93,12 @@ __global__ __launch_bounds__(256) void log_cmn_kernel(float* __restrict__ mel, i
 }
 
 // fb [B, T, NB]  ->  img [B, NB+2, T+2, C] (interior only; borders stay zero)
+template <typename TO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ fb, int B, int T,
                                                         int NB, int C,
                                                         const float* __restrict__ w,  // [C, 9] folded
                                                         const float* __restrict__ bias,
-                                                        float* __restrict__ img) {
+                                                        TO* __restrict__ img) {
   const int cq = C / 4;
   const int64_t total = (int64_t)B * NB * T * cq;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
@@ -126,14 +127,16 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       for (int k = 0; k < 9; ++k) a = fmaf(in[k], w[ch * 9 + k], a);
       o[c] = fmaxf(a + bias[ch], 0.f);
     }
-    float* op = img + (((int64_t)b * (NB + 2) + h + 1) * (T + 2) + wv + 1) * C + q * 4;
-    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+    TO* op = img + (((int64_t)b * (NB + 2) + h + 1) * (T + 2) + wv + 1) * C + q * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) st_act(op, c, o[c]);
   }
 }
 
 // img [B, H+2, W+2, C] (padded NHWC), masks [B, S, L]  ->  stats [B, S, 2*C*H]
 // feature index f = c*H + h (rearrange "b d c f -> b (d c) f" of resnet.py:49-66)
-__global__ __launch_bounds__(256) void stats_pool_kernel(const float* __restrict__ img, int H, int W,
+template <typename TI>
+__global__ __launch_bounds__(256) void stats_pool_kernel(const TI* __restrict__ img, int H, int W,
                                                          int C, const float* __restrict__ masks,
                                                          int S, int L, float* __restrict__ stats) {
   extern __shared__ float sw[];  // [S][W] interpolated weights
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const float* __restrict
     sw[i] = (W == L) ? masks[((int64_t)b * S + s) * L + t] : masks[((int64_t)b * S + s) * L + src];
   }
   __syncthreads();
-  const float* base = img + (((int64_t)b * (H + 2) + h + 1) * (W + 2) + 1) * C;
+  const TI* base = img + (((int64_t)b * (H + 2) + h + 1) * (W + 2) + 1) * C;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     for (int s = 0; s < S; ++s) {
       const float* wt = sw + s * W;
@@ -156,13 +159,13 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const float* __restrict
         const float wv = wt[t];
         v1 += wv;
         v2 += wv * wv;
-        sx += base[(int64_t)t * C + c] * wv;
+        sx += ld_act(base, (int64_t)t * C + c) * wv;
       }
       v1 += 1e-8f;
       const float mean = sx / v1;
       float sq = 0.f;
       for (int t = 0; t < W; ++t) {
-        const float d = base[(int64_t)t * C + c] - mean;
+        const float d = ld_act(base, (int64_t)t * C + c) - mean;
         sq += d * d * wt[t];
       }
       const float var = sq / (v1 - v2 / v1 + 1e-8f);
@@ -199,16 +202,25 @@ int launch_log_cmn(float* mel, int B, int T, int NB, float eps, hipStream_t st) 
 }
 
 int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* w, const float* bias,
-                     float* img, hipStream_t st) {
-  hipLaunchKernelGGL(stem_conv_kernel, dim3(grid_for((int64_t)B * NB * T * (C / 4))), dim3(256), 0,
-                     st, fb, B, T, NB, C, w, bias, img);
+                     void* img, int out_bf16, hipStream_t st) {
+  const dim3 grid(grid_for((int64_t)B * NB * T * (C / 4)));
+  if (out_bf16)
+    hipLaunchKernelGGL(stem_conv_kernel<u16>, grid, dim3(256), 0, st, fb, B, T, NB, C, w, bias,
+                       static_cast<u16*>(img));
+  else
+    hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, st, fb, B, T, NB, C, w, bias,
+                       static_cast<float*>(img));
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
-int launch_stats_pool(const float* img, int B, int H, int W, int C, const float* masks, int S, int L,
-                      float* stats, hipStream_t st) {
+int launch_stats_pool(const void* img, int in_bf16, int B, int H, int W, int C, const float* masks, int S,
+                      int L, float* stats, hipStream_t st) {
   const size_t lds = (size_t)S * W * sizeof(float);
-  hipLaunchKernelGGL(stats_pool_kernel, dim3(H, B), dim3(256), lds, st, img, H, W, C, masks, S, L,
-                     stats);
+  if (in_bf16)
+    hipLaunchKernelGGL(stats_pool_kernel<u16>, dim3(H, B), dim3(256), lds, st, static_cast<const u16*>(img),
+                       H, W, C, masks, S, L, stats);
+  else
+    hipLaunchKernelGGL(stats_pool_kernel<float>, dim3(H, B), dim3(256), lds, st,
+                       static_cast<const float*>(img), H, W, C, masks, S, L, stats);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }

@@ -125,7 +125,7 @@ struct dzn_handle {
   // ---- segmentation: workspace ----
   int maxT[DZN_MAX_CONV]{};
   int maxL = 0;
-  float *stats = nullptr, *gn_stats = nullptr, *bufA = nullptr, *bufB = nullptr;
+  float *stats = nullptr, *gn_stats = nullptr, *bufA = nullptr, *bufB = nullptr, *craw = nullptr;
   float *x = nullptr, *xpad = nullptr, *y = nullptr, *ws = nullptr, *qkv = nullptr, *ao = nullptr,
         *gate = nullptr, *mid = nullptr;
   float *hz = nullptr, *ht = nullptr, *hmid = nullptr, *hv = nullptr;
@@ -252,6 +252,17 @@ int relpos_bucket(int rel, int num_buckets, int max_distance) {
   long large = max_exact + (long)v;
   if (large > nb - 1) large = nb - 1;
   return ret + (int)large;
+}
+
+int64_t lnx_raw_elems(H* h, int64_t B) {
+  const dzn_config& c = h->cfg;
+  int64_t need = 1;
+  if (c.extractor_layer_norm) {
+    for (int i = 1; i < c.n_conv; ++i) need = std::max(need, B * h->maxT[i] * h->Cp[i]);
+  } else {
+    need = B * h->maxT[0] * h->Cp[0];
+  }
+  return need;
 }
 
 // ------------------------------------------------------------------ segmentation: finalize
@@ -497,6 +508,11 @@ void finalize_seg(H* h) {
     for (int i = 1; i < c.n_conv; i += 2) need_b = std::max(need_b, B * h->maxT[i] * h->Cp[i]);
     h->bufB = dalloc<float>(h, need_b);
   }
+  if (c.precision == DZN_PREC_BF16) {
+    // fp32 scratch for raw conv outputs in front of their LayerNorm / GroupNorm (bf16 mode only)
+    int64_t need_r = lnx_raw_elems(h, B);
+    h->craw = dalloc<float>(h, need_r);
+  }
   h->x = dalloc<float>(h, ML * D);
   h->xpad = dalloc<float>(h, B * (n + c.pos_conv_kernel) * D);
   h->y = dalloc<float>(h, ML * D);
@@ -682,13 +698,32 @@ void chk(int rc, const char* what) {
   if (rc != DZN_OK) throw EngineError(rc, std::string("kernel launch failed: ") + what);
 }
 
-void tap(H* h, const char* name, const float* p, int64_t rows, int cols, int64_t ld, hipStream_t st) {
+// byte-level offset into an activation buffer whose element type depends on the engine mode
+inline float* eoff(float* p, int64_t elems, bool bf16) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + elems * (bf16 ? 2 : 4));
+}
+inline const float* eoff(const float* p, int64_t elems, bool bf16) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + elems * (bf16 ? 2 : 4));
+}
+
+void tap(H* h, const char* name, const float* p, int64_t rows, int cols, int64_t ld, hipStream_t st,
+         bool bf16 = false) {
   if (!h->debug) return;
   HIPCHK(hipStreamSynchronize(st));
   std::vector<float>& v = h->taps[name];
   v.resize((size_t)rows * cols);
-  HIPCHK(hipMemcpy2D(v.data(), (size_t)cols * 4, p, (size_t)ld * 4, (size_t)cols * 4, (size_t)rows,
+  if (!bf16) {
+    HIPCHK(hipMemcpy2D(v.data(), (size_t)cols * 4, p, (size_t)ld * 4, (size_t)cols * 4, (size_t)rows,
+                       hipMemcpyDeviceToHost));
+    return;
+  }
+  std::vector<u16> t((size_t)rows * cols);
+  HIPCHK(hipMemcpy2D(t.data(), (size_t)cols * 2, p, (size_t)ld * 2, (size_t)cols * 2, (size_t)rows,
                      hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < t.size(); ++i) {
+    const uint32_t u = (uint32_t)t[i] << 16;
+    memcpy(&v[i], &u, 4);
+  }
 }
 
 dzn_gemm_desc gd(H* h, const float* A, const Lin& l, float* C, int64_t M, int64_t lda, int64_t ldc) {
@@ -714,9 +749,11 @@ dzn_gemm_desc gd(H* h, const float* A, const Lin& l, float* C, int64_t M, int64_
   return d;
 }
 
-void layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const LNp& p, int64_t rows, int Cpad,
-               int gelu, hipStream_t st) {
-  chk(launch_layernorm(x, ldx, y, ldy, p.g, p.b, rows, p.C, Cpad, 1e-5f, gelu, st), "layernorm");
+// LayerNorm with typed input / output (fp32, or bf16 in the bf16 engine mode)
+void ln_t(const float* x, bool x16, int64_t ldx, float* y, bool y16, int64_t ldy, const LNp& p, int64_t rows,
+          int Cpad, int gelu, hipStream_t st, const float* post = nullptr) {
+  chk(launch_layernorm_t(x, x16, ldx, y, y16, ldy, p.g, p.b, post, rows, p.C, Cpad, 1e-5f, gelu, st),
+      "layernorm");
 }
 
 void ensure_table(H* h, int L, hipStream_t st) {
@@ -734,8 +771,13 @@ void ensure_table(H* h, int L, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ segmentation forward
+// `lp` (bf16 engine mode): every contraction input is a bf16 buffer written by its producer
+// (conv0, LayerNorm, GELU / Swish epilogues, attention, depthwise conv); the residual stream x, the
+// layer-weighted sum, q/k/v, softmax and all norm statistics stay fp32.
 void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* d_ml, hipStream_t st) {
   const dzn_config& c = h->cfg;
+  const bool lp = c.precision == DZN_PREC_BF16;
+  const bool lnx = c.extractor_layer_norm != 0;
   int T[DZN_MAX_CONV];
   {
     int n = N;
@@ -748,6 +790,11 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   if (L < 1) throw EngineError(DZN_E_INVALID, "window too short");
   const int D = h->D, A = h->A, Fh = h->Fh;
   const int64_t ML = (int64_t)B * L;
+  auto gemm = [&](dzn_gemm_desc& d, bool a16, bool c16, const char* what) {
+    d.a_bf16 = a16;
+    d.c_bf16 = c16;
+    chk(launch_gemm(d, st), what);
+  };
 
   // ---- conv feature extractor ----
   const float* stats = nullptr;
@@ -755,44 +802,53 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     chk(launch_wave_stats(wave, B, N, 1e-5f, h->stats, st), "wave_stats");
     stats = h->stats;
   }
-  chk(launch_conv0(wave, B, N, stats, h->conv0_w, h->conv_ln[0].g, h->conv_ln[0].b, h->C[0], h->Cp[0],
-                   c.conv_k[0], c.conv_s[0], T[0], c.extractor_layer_norm, 1e-5f, h->bufA, st),
-      "conv0");
-  if (!c.extractor_layer_norm)
-    chk(launch_groupnorm_gelu(h->bufA, B, T[0], h->C[0], h->Cp[0], h->conv_ln[0].g, h->conv_ln[0].b,
-                              1e-5f, h->gn_stats, st),
+  if (lnx) {
+    chk(launch_conv0(wave, B, N, stats, h->conv0_w, h->conv_ln[0].g, h->conv_ln[0].b, h->C[0], h->Cp[0],
+                     c.conv_k[0], c.conv_s[0], T[0], 1, 1e-5f, h->bufA, lp, st),
+        "conv0");
+  } else {
+    float* raw = lp ? h->craw : h->bufA;
+    chk(launch_conv0(wave, B, N, stats, h->conv0_w, nullptr, nullptr, h->C[0], h->Cp[0], c.conv_k[0],
+                     c.conv_s[0], T[0], 0, 1e-5f, raw, 0, st),
+        "conv0");
+    chk(launch_groupnorm_gelu(raw, h->bufA, lp, B, T[0], h->C[0], h->Cp[0], h->Cp[0], h->conv_ln[0].g,
+                              h->conv_ln[0].b, 1e-5f, h->gn_stats, st),
         "groupnorm");
-  tap(h, "conv0", h->bufA, (int64_t)B * T[0], h->C[0], h->Cp[0], st);
+  }
+  tap(h, "conv0", h->bufA, (int64_t)B * T[0], h->C[0], h->Cp[0], st, lp);
   float* cur = h->bufA;
   float* nxt = h->bufB;
+  const int last = c.n_conv - 1;
   for (int i = 1; i < c.n_conv; ++i) {
     // conv1d(k, s) over channels-last rows: row t of the contraction starts at (t*s)*Cp_in
-    dzn_gemm_desc d = gd(h, cur, h->conv[i], nxt, T[i], (int64_t)c.conv_s[i] * h->Cp[i - 1], h->Cp[i]);
+    float* dst = (lnx && lp) ? h->craw : nxt;
+    dzn_gemm_desc d = gd(h, cur, h->conv[i], dst, T[i], (int64_t)c.conv_s[i] * h->Cp[i - 1], h->Cp[i]);
     d.nz = B;
     d.a_z0 = (int64_t)T[i - 1] * h->Cp[i - 1];
     d.c_z0 = (int64_t)T[i] * h->Cp[i];
-    if (!c.extractor_layer_norm) d.act = DZN_ACT_GELU;
-    chk(launch_gemm(d, st), "conv gemm");
-    if (c.extractor_layer_norm)
-      layernorm(nxt, h->Cp[i], nxt, h->Cp[i], h->conv_ln[i], (int64_t)B * T[i], h->Cp[i], 1, st);
+    if (!lnx) d.act = DZN_ACT_GELU;
+    gemm(d, lp, lp && !lnx, "conv gemm");
+    if (lnx)  // channel LayerNorm + GELU (+ dummy_weight after the last conv, components.py:208)
+      ln_t(dst, false, h->Cp[i], nxt, lp, h->Cp[i], h->conv_ln[i], (int64_t)B * T[i], h->Cp[i], 1, st,
+           i == last ? h->dummy_w : nullptr);
     std::swap(cur, nxt);
   }
-  const int last = c.n_conv - 1;
-  chk(launch_col_scale(cur, ML, h->C[last], h->Cp[last], h->dummy_w, st), "dummy_weight");
-  tap(h, "features", cur, ML, h->C[last], h->Cp[last], st);
+  if (!lnx || c.n_conv == 1)
+    chk(launch_col_scale(cur, lp, ML, h->C[last], h->Cp[last], h->dummy_w, st), "dummy_weight");
+  tap(h, "features", cur, ML, h->C[last], h->Cp[last], st, lp);
 
   // ---- feature projection (components.py:305-306) ----
-  layernorm(cur, h->Cp[last], nxt, h->Cp[last], h->fp_ln, ML, h->Cp[last], 0, st);
+  ln_t(cur, lp, h->Cp[last], nxt, lp, h->Cp[last], h->fp_ln, ML, h->Cp[last], 0, st);
   {
     dzn_gemm_desc d = gd(h, nxt, h->fp, h->x, ML, h->Cp[last], D);
-    chk(launch_gemm(d, st), "feature projection");
+    gemm(d, lp, false, "feature projection");
   }
   tap(h, "featproj", h->x, ML, D, D, st);
 
   // ---- positional conv: x = x + gelu(conv_pos(x))  (components.py:980-987, 366-380) ----
   {
     const int Kc = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G, Lp = L + Kc;
-    chk(launch_pad_rows(h->x, h->xpad, B, L, Lp, Kc / 2, D, st), "pad_rows");
+    chk(launch_pad_rows(h->x, h->xpad, lp, B, L, Lp, Kc / 2, D, st), "pad_rows");
     dzn_gemm_desc d = gd(h, h->xpad, h->posconv, h->x, L, D, D);
     d.N = cg;
     d.kc = cg;
@@ -808,9 +864,9 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     d.c_z1 = cg;
     d.b_z1 = cg;
     d.alg_flops = 2.0 * (double)L * cg * h->posconv.Kt;
-    chk(launch_gemm(d, st), "pos conv");
+    gemm(d, lp, false, "pos conv");
   }
-  if (!c.layer_norm_first) layernorm(h->x, D, h->x, D, h->enc_ln, ML, D, 0, st);
+  if (!c.layer_norm_first) ln_t(h->x, false, D, h->x, false, D, h->enc_ln, ML, D, 0, st);
   chk(launch_ws_accum(h->x, h->ws, h->wsum_w[0], 1, ML * D, st), "ws_accum");
   tap(h, "rep0", h->x, ML, D, D, st);
 
@@ -821,47 +877,58 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     const float wl = h->wsum_w[i + 1];
     if (Ly.attn) {
       const float* yin = h->x;
+      bool y16 = false;
       if (c.layer_norm_first) {
-        layernorm(h->x, D, h->y, D, Ly.ln1, ML, D, 0, st);
+        ln_t(h->x, false, D, h->y, lp, D, Ly.ln1, ML, D, 0, st);
         yin = h->y;
+        y16 = lp;
+      } else if (lp) {
+        chk(launch_cast_bf16(h->x, h->y, ML * D, st), "cast");
+        yin = h->y;
+        y16 = true;
       }
-      chk(launch_gate(yin, D, Ly.Wg, Ly.bg, Ly.cst, h->gate, ML, h->H, st), "gate");
+      chk(launch_gate_t(yin, y16, D, Ly.Wg, Ly.bg, Ly.cst, h->gate, ML, h->H, st), "gate");
       const int hd = Ly.h * 64;
       dzn_gemm_desc d = gd(h, yin, Ly.qkv, h->qkv, ML, D, 3 * hd);
-      chk(launch_gemm(d, st), "qkv");
-      chk(launch_attention(h->qkv, h->ao, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd, hd,
-                           0.125f, c.precision, st),
+      gemm(d, y16, false, "qkv");
+      chk(launch_attention_t(h->qkv, h->ao, lp, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd,
+                             hd, 0.125f, st),
           "attention");
       dzn_gemm_desc o = gd(h, h->ao, Ly.out, h->x, ML, hd, D);
       o.R = h->x;
-      chk(launch_gemm(o, st), "out_proj");
+      gemm(o, lp, false, "out_proj");
     }
     if (c.layer_norm_first) {
       if (Ly.ffn) {
-        layernorm(h->x, D, h->y, D, Ly.ln2, ML, D, 0, st);
+        ln_t(h->x, false, D, h->y, lp, D, Ly.ln2, ML, D, 0, st);
         dzn_gemm_desc f1 = gd(h, h->y, Ly.f1, h->mid, ML, D, Ly.Fp);
         f1.act = DZN_ACT_GELU;
-        chk(launch_gemm(f1, st), "ffn1");
+        gemm(f1, lp, lp, "ffn1");
         dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, h->x, ML, Ly.Fp, D);
         f2.R = h->x;
         f2.WS = h->ws;
         f2.ldws = D;
         f2.ws_w = wl;
-        chk(launch_gemm(f2, st), "ffn2");
+        gemm(f2, lp, false, "ffn2");
       } else {
         chk(launch_ws_accum(h->x, h->ws, wl, 0, ML * D, st), "ws_accum");
       }
     } else {
-      layernorm(h->x, D, h->x, D, Ly.ln1, ML, D, 0, st);
+      ln_t(h->x, false, D, h->x, false, D, Ly.ln1, ML, D, 0, st);
       if (Ly.ffn) {
-        dzn_gemm_desc f1 = gd(h, h->x, Ly.f1, h->mid, ML, D, Ly.Fp);
+        const float* fin = h->x;
+        if (lp) {
+          chk(launch_cast_bf16(h->x, h->y, ML * D, st), "cast");
+          fin = h->y;
+        }
+        dzn_gemm_desc f1 = gd(h, fin, Ly.f1, h->mid, ML, D, Ly.Fp);
         f1.act = DZN_ACT_GELU;
-        chk(launch_gemm(f1, st), "ffn1");
+        gemm(f1, lp, lp, "ffn1");
         dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, h->x, ML, Ly.Fp, D);
         f2.R = h->x;
-        chk(launch_gemm(f2, st), "ffn2");
+        gemm(f2, lp, false, "ffn2");
       }
-      layernorm(h->x, D, h->x, D, Ly.ln2, ML, D, 0, st);
+      ln_t(h->x, false, D, h->x, false, D, Ly.ln2, ML, D, 0, st);
       chk(launch_ws_accum(h->x, h->ws, wl, 0, ML * D, st), "ws_accum");
     }
     if (h->debug) {
@@ -873,49 +940,54 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
 
   // ---- head: proj + LN, Conformer x conf_layers, classifier (model_wavlm_conformer.py:256-262) ----
   {
-    dzn_gemm_desc d = gd(h, h->ws, h->proj, h->hz, ML, D, A);
-    chk(launch_gemm(d, st), "proj");
-    layernorm(h->hz, A, h->hz, A, h->lnorm, ML, A, 0, st);
+    const float* pin = h->ws;
+    if (lp) {
+      chk(launch_cast_bf16(h->ws, h->y, ML * D, st), "cast");
+      pin = h->y;
+    }
+    dzn_gemm_desc d = gd(h, pin, h->proj, h->hz, ML, D, A);
+    gemm(d, lp, false, "proj");
+    ln_t(h->hz, false, A, h->hz, false, A, h->lnorm, ML, A, 0, st);
   }
   tap(h, "head_in", h->hz, ML, A, A, st);
   for (int i = 0; i < c.conf_layers; ++i) {
     ConfLayer& Cl = h->conf[i];
     auto half_ffn = [&](const LNp& ln, const Lin& w1, const Lin& w2) {
-      layernorm(h->hz, A, h->ht, A, ln, ML, A, 0, st);
+      ln_t(h->hz, false, A, h->ht, lp, A, ln, ML, A, 0, st);
       dzn_gemm_desc a = gd(h, h->ht, w1, h->hmid, ML, A, Fh);
       a.act = DZN_ACT_SWISH;
-      chk(launch_gemm(a, st), "conf ffn w1");
+      gemm(a, lp, lp, "conf ffn w1");
       dzn_gemm_desc b = gd(h, h->hmid, w2, h->hz, ML, Fh, A);
       b.alpha = 0.5f;
       b.R = h->hz;
-      chk(launch_gemm(b, st), "conf ffn w2");
+      gemm(b, lp, false, "conf ffn w2");
     };
     half_ffn(Cl.ffn1_ln, Cl.ffn1_w1, Cl.ffn1_w2);
     // MHSA
-    layernorm(h->hz, A, h->ht, A, Cl.mha_ln, ML, A, 0, st);
+    ln_t(h->hz, false, A, h->ht, lp, A, Cl.mha_ln, ML, A, 0, st);
     {
       dzn_gemm_desc q = gd(h, h->ht, Cl.qkv, h->hmid, ML, A, 3 * A);
-      chk(launch_gemm(q, st), "conf qkv");
-      chk(launch_attention(h->hmid, h->hv, nullptr, nullptr, nullptr, B, L, c.conf_heads, 0, 3 * A, A,
-                           0.125f, c.precision, st),
+      gemm(q, lp, false, "conf qkv");
+      chk(launch_attention_t(h->hmid, h->hv, lp, nullptr, nullptr, nullptr, B, L, c.conf_heads, 0, 3 * A, A,
+                             0.125f, st),
           "conf attention");
       dzn_gemm_desc o = gd(h, h->hv, Cl.o, h->hz, ML, A, A);
       o.R = h->hz;
-      chk(launch_gemm(o, st), "conf out");
+      gemm(o, lp, false, "conf out");
     }
     // conv module
-    layernorm(h->hz, A, h->ht, A, Cl.conv_ln, ML, A, 0, st);
+    ln_t(h->hz, false, A, h->ht, lp, A, Cl.conv_ln, ML, A, 0, st);
     {
       dzn_gemm_desc p1 = gd(h, h->ht, Cl.pw1, h->hmid, ML, A, 2 * A);
-      chk(launch_gemm(p1, st), "conf pw1");
-      chk(launch_glu_dwconv(h->hmid, 2 * A, Cl.dw, Cl.dwb, h->hv, A, B, L, A, c.conf_kernel, st),
+      gemm(p1, lp, false, "conf pw1");
+      chk(launch_glu_dwconv(h->hmid, 2 * A, Cl.dw, Cl.dwb, h->hv, lp, A, B, L, A, c.conf_kernel, st),
           "glu_dwconv");
       dzn_gemm_desc p2 = gd(h, h->hv, Cl.pw2, h->hz, ML, A, A);
       p2.R = h->hz;
-      chk(launch_gemm(p2, st), "conf pw2");
+      gemm(p2, lp, false, "conf pw2");
     }
     half_ffn(Cl.ffn2_ln, Cl.ffn2_w1, Cl.ffn2_w2);
-    layernorm(h->hz, A, h->hz, A, Cl.out_ln, ML, A, 0, st);
+    ln_t(h->hz, false, A, h->hz, false, A, Cl.out_ln, ML, A, 0, st);
     if (h->debug) {
       const std::string nm = "conf" + std::to_string(i);
       tap(h, nm.c_str(), h->hz, ML, A, A, st);
@@ -927,9 +999,12 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
 }
 
 // ------------------------------------------------------------------ embedding forward
+// bf16 engine mode: the ResNet images are bf16 (operands, residuals and outputs of every conv);
+// fbank (DFT / mel), pooling statistics and seg_1 stay fp32.
 void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int N, int L, float* d_emb,
                  hipStream_t st) {
   const dzn_config& c = h->cfg;
+  const bool lp = c.precision == DZN_PREC_BF16;
   const int flen = 400, fshift = 160, Kp = 416, NB = c.num_mel_bins;
   if (N < flen) throw EngineError(DZN_E_INVALID, "waveform shorter than one fbank frame (400 samples)");
   const int T = 1 + (N - flen) / fshift;
@@ -951,7 +1026,7 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
   }
   tap(h, "fbank", h->fb, MT, NB, NB, st);
   // ---- ResNet34 trunk ----
-  chk(launch_stem_conv(h->fb, B, T, NB, h->sC[0], h->stem_w, h->stem_b, h->sbuf[0][0], st), "stem");
+  chk(launch_stem_conv(h->fb, B, T, NB, h->sC[0], h->stem_w, h->stem_b, h->sbuf[0][0], lp, st), "stem");
   const float* prev = nullptr;  // output image of the previous stage
   int cur = 0;
   for (int s = 0; s < 4; ++s) {
@@ -962,17 +1037,18 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
     auto conv3 = [&](const float* in, const ResConv& rc, float* out, const float* R, int act,
                      int post_relu) {
       // stride-1 3x3 inside stage s: patch rows via tab1, two-level K = (dh | dw*C + ci)
-      dzn_gemm_desc d = gd(h, in, rc.l, out + interior, M, 0, 0);
+      dzn_gemm_desc d = gd(h, in, rc.l, eoff(out, interior, lp), M, 0, 0);
       d.a_rowoff = h->tab1[s];
       d.c_rowoff = h->tab1[s];
       d.kc = 3 * rc.cin;
       d.ldk = (int64_t)(Ws + 2) * rc.cin;
       d.act = act;
-      d.R = R ? R + interior : nullptr;
+      d.R = R ? eoff(R, interior, lp) : nullptr;
       d.post_relu = post_relu;
       d.nz = B;
       d.a_z0 = img;
       d.c_z0 = img;
+      d.a_bf16 = d.c_bf16 = d.r_bf16 = lp;
       chk(launch_gemm(d, st), "resnet conv3x3");
     };
     for (size_t j = 0; j < h->stages[s].size(); ++j) {
@@ -984,7 +1060,7 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
         float* midb = h->sbuf[s][0];
         float* outb = h->sbuf[s][1];
         float* scb = h->sbuf[s][2];
-        dzn_gemm_desc d = gd(h, prev, rb.c1.l, midb + interior, M, 0, 0);
+        dzn_gemm_desc d = gd(h, prev, rb.c1.l, eoff(midb, interior, lp), M, 0, 0);
         d.a_rowoff = h->tab2[s];
         d.c_rowoff = h->tab1[s];
         d.kc = 3 * Cpv;
@@ -993,13 +1069,16 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
         d.nz = B;
         d.a_z0 = pimg;
         d.c_z0 = img;
+        d.a_bf16 = d.c_bf16 = lp;
         chk(launch_gemm(d, st), "resnet conv3x3 s2");
-        dzn_gemm_desc e = gd(h, prev + ((int64_t)(Wp + 2) + 1) * Cpv, rb.sc.l, scb + interior, M, 0, 0);
+        dzn_gemm_desc e = gd(h, eoff(prev, ((int64_t)(Wp + 2) + 1) * Cpv, lp), rb.sc.l,
+                             eoff(scb, interior, lp), M, 0, 0);
         e.a_rowoff = h->tab2[s];
         e.c_rowoff = h->tab1[s];
         e.nz = B;
         e.a_z0 = pimg;
         e.c_z0 = img;
+        e.a_bf16 = e.c_bf16 = lp;
         chk(launch_gemm(e, st), "resnet shortcut");
         conv3(midb, rb.c2, outb, scb, DZN_ACT_NONE, 1);
         cur = 1;
@@ -1013,14 +1092,10 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
       }
     }
     prev = h->sbuf[s][cur];
-    if (s == 0 && h->debug) {
-      // interior of stage-1 output of image 0 as [H*W, C] is not contiguous; tap a row strip
-      tap(h, "stage1_row1", prev + interior, h->sW[0], h->sC[0], h->sC[0], st);
-    }
   }
   // ---- TSTP pooling for all S masks + seg_1 ----
   const int feat = h->sC[3] * h->sH[3];
-  chk(launch_stats_pool(prev, B, h->sH[3], h->sW[3], h->sC[3], masks, S, L, h->pool, st), "stats_pool");
+  chk(launch_stats_pool(prev, lp, B, h->sH[3], h->sW[3], h->sC[3], masks, S, L, h->pool, st), "stats_pool");
   tap(h, "pool", h->pool, (int64_t)B * S, 2 * feat, 2 * feat, st);
   {
     dzn_gemm_desc d = gd(h, h->pool, h->seg1, d_emb, (int64_t)B * S, 2 * feat, c.embed_out_dim);

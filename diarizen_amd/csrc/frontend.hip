@@ -6,25 +6,25 @@
 //           C0 channels of every frame (components.py:63-70) -> erf-GELU   (all fused here)
 //   base  : conv (raw) ; GroupNorm(C0, C0) = per-channel norm over TIME (components.py:1248-1253)
 //           needs whole-window statistics -> col_stats_kernel + gn_gelu_kernel
-// The stage is HBM-write bound (0.5 MB in, C0*T0*4 B out per window).  Layout: channels-last
-// [B, T0, Cp] so that the next conv is a plain contraction over overlapping rows.  A workgroup
-// stages a run of normalised samples in LDS (coalesced), every lane keeps its channels' 10 taps
-// in registers, a wavefront produces one frame per iteration and stores 256 contiguous bytes
-// per channel group.
+// The stage is HBM-write bound (0.5 MB in, C0*T0*4 B out per window; half that in the bf16 engine
+// mode, which stores the activations as bf16).  Layout: channels-last [B, T0, Cp] so that the next
+// conv is a plain contraction over overlapping rows.  A workgroup stages a run of normalised
+// samples in LDS (coalesced), every lane keeps its channels' 10 taps in registers, a wavefront
+// produces one frame per iteration and stores 256 contiguous bytes per channel group.
 #include "common.h"
 
 namespace {
 
 constexpr int FR_PER_BLOCK = 64;   // frames per workgroup (16 per wavefront)
 
-template <int CPL, bool LN>
+template <int CPL, bool LN, typename TO>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wave, int N,
                                                     const float* __restrict__ stats,  // [B,2] or null
                                                     const float* __restrict__ w,      // [C0, k]
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, int C0, int Cp,
                                                     int k, int s, int T0, float eps,
-                                                    float* __restrict__ out) {
+                                                    TO* __restrict__ out) {
   __shared__ float sx[FR_PER_BLOCK * 8 + 32];
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * FR_PER_BLOCK;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
       acc[j] = a;
       sum += a;  // channels >= C0 have zero taps -> contribute 0
     }
-    float* op = out + ((int64_t)b * T0 + f0 + f) * Cp;
+    TO* op = out + ((int64_t)b * T0 + f0 + f) * Cp;
     if constexpr (LN) {
       const float mu = wave_sum(sum) / (float)C0;
       float sq = 0.f;
@@ -76,18 +76,18 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
       for (int j = 0; j < CPL; ++j) {
         const int c = lane + 64 * j;
         if (c < C0)
-          op[c] = gelu_erf((acc[j] - mu) * rs * gr[j] + br[j]);
+          st_act(op, c, gelu_erf((acc[j] - mu) * rs * gr[j] + br[j]));
         else if (c < Cp)
-          op[c] = 0.f;
+          st_act(op, c, 0.f);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         const int c = lane + 64 * j;
         if (c < C0)
-          op[c] = acc[j];
+          st_act(op, c, acc[j]);
         else if (c < Cp)
-          op[c] = 0.f;
+          st_act(op, c, 0.f);
       }
     }
   }
@@ -127,33 +127,43 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
   }
 }
 
-// x[b,t,c] = gelu((x - mean[b,c]) * rstd[b,c] * gamma[c] + beta[c]) in place
-__global__ __launch_bounds__(256) void gn_gelu_kernel(float* __restrict__ x, int T, int C, int64_t ld,
-                                                      const float* __restrict__ stats,
+// y[b,t,c] = gelu((x - mean[b,c]) * rstd[b,c] * gamma[c] + beta[c]); y may alias x when TO = float;
+// columns [C, Cp) of y are zeroed
+template <typename TO>
+__global__ __launch_bounds__(256) void gn_gelu_kernel(const float* x, TO* y, int T, int C, int Cp,
+                                                      int64_t ld, const float* __restrict__ stats,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta) {
   const int b = blockIdx.y;
-  const int64_t n = (int64_t)T * C;
+  const int64_t n = (int64_t)T * Cp;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int t = (int)(i / C), c = (int)(i - (int64_t)t * C);
-    float* p = x + ((int64_t)b * T + t) * ld + c;
-    const float mu = stats[((int64_t)b * C + c) * 2], rs = stats[((int64_t)b * C + c) * 2 + 1];
-    *p = gelu_erf((*p - mu) * rs * gamma[c] + beta[c]);
+    const int t = (int)(i / Cp), c = (int)(i - (int64_t)t * Cp);
+    const int64_t off = ((int64_t)b * T + t) * ld + c;
+    if (c < C) {
+      const float mu = stats[((int64_t)b * C + c) * 2], rs = stats[((int64_t)b * C + c) * 2 + 1];
+      st_act(y, off, gelu_erf((x[off] - mu) * rs * gamma[c] + beta[c]));
+    } else {
+      st_act(y, off, 0.f);
+    }
   }
 }
 
 // xpad[b, t + pad, :] = x[b, t, :], zero borders (input of the positional conv)
-__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ x,
-                                                       float* __restrict__ xpad, int L, int Lp,
-                                                       int pad, int D4) {
+template <typename TO>
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ x, TO* __restrict__ xpad,
+                                                       int L, int Lp, int pad, int D4) {
   const int b = blockIdx.y;
   const int64_t n = (int64_t)Lp * D4;
   const float4* xs = reinterpret_cast<const float4*>(x) + (int64_t)b * L * D4;
-  float4* xd = reinterpret_cast<float4*>(xpad) + (int64_t)b * Lp * D4;
+  TO* xd = xpad + (int64_t)b * Lp * D4 * 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int t = (int)(i / D4) - pad;
     const int c = (int)(i % D4);
-    xd[i] = (t >= 0 && t < L) ? xs[(int64_t)t * D4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = (t >= 0 && t < L) ? xs[(int64_t)t * D4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    st_act(xd, 4 * i + 0, v.x);
+    st_act(xd, 4 * i + 1, v.y);
+    st_act(xd, 4 * i + 2, v.z);
+    st_act(xd, 4 * i + 3, v.w);
   }
 }
 
@@ -171,14 +181,15 @@ __global__ __launch_bounds__(256) void ws_accum_kernel(const float* __restrict__
   }
 }
 
-// y[r, c] = x[r, c] * scale[c]  (dummy_weight, components.py:208), columns >= C untouched
-__global__ __launch_bounds__(256) void col_scale_kernel(float* __restrict__ x, int64_t rows, int C,
+// x[r, c] *= scale[c]  (dummy_weight, components.py:208), columns >= C untouched
+template <typename T>
+__global__ __launch_bounds__(256) void col_scale_kernel(T* __restrict__ x, int64_t rows, int C,
                                                         int64_t ld, const float* __restrict__ scale) {
   const int64_t n = rows * C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / C;
     const int c = (int)(i - r * C);
-    x[r * ld + c] *= scale[c];
+    st_act(x, r * ld + c, ld_act(x, r * ld + c) * scale[c]);
   }
 }
 
@@ -187,48 +198,70 @@ inline unsigned grid_for(int64_t n, int per = 256, int cap = 4096) {
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-}  // namespace
-
-int launch_conv0(const float* wave, int B, int N, const float* stats, const float* w,
-                 const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
-                 int layer_norm, float eps, float* out, hipStream_t st) {
-  if (k > 10 || C0 > 512 || s > 8) return DZN_E_INVALID;
+template <typename TO>
+int conv0_dispatch(const float* wave, int B, int N, const float* stats, const float* w,
+                   const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
+                   int layer_norm, float eps, TO* out, hipStream_t st) {
   dim3 grid((T0 + FR_PER_BLOCK - 1) / FR_PER_BLOCK, B);
   const int cpl = (max(C0, Cp) + 63) / 64;
-  // algorithmic HBM bytes: read the waveform once, write the fp32 [T0, C0] activations once
-  const int pid = prof_begin(st, layer_norm ? "conv0_ln_gelu" : "conv0_raw",
-                             2.0 * B * (double)T0 * C0 * k, 4.0 * B * ((double)N + (double)T0 * C0));
-#define DZN_C0(CPLV)                                                                              \
-  do {                                                                                            \
-    if (layer_norm)                                                                               \
-      hipLaunchKernelGGL((conv0_kernel<CPLV, true>), grid, dim3(256), 0, st, wave, N, stats, w,   \
-                         gamma, beta, C0, Cp, k, s, T0, eps, out);                                \
-    else                                                                                          \
-      hipLaunchKernelGGL((conv0_kernel<CPLV, false>), grid, dim3(256), 0, st, wave, N, stats, w,  \
-                         gamma, beta, C0, Cp, k, s, T0, eps, out);                                \
+#define DZN_C0(CPLV)                                                                                  \
+  do {                                                                                                \
+    if (layer_norm)                                                                                   \
+      hipLaunchKernelGGL((conv0_kernel<CPLV, true, TO>), grid, dim3(256), 0, st, wave, N, stats, w,   \
+                         gamma, beta, C0, Cp, k, s, T0, eps, out);                                    \
+    else                                                                                              \
+      hipLaunchKernelGGL((conv0_kernel<CPLV, false, TO>), grid, dim3(256), 0, st, wave, N, stats, w,  \
+                         gamma, beta, C0, Cp, k, s, T0, eps, out);                                    \
   } while (0)
   if (cpl <= 1) DZN_C0(1);
   else if (cpl <= 2) DZN_C0(2);
   else if (cpl <= 4) DZN_C0(4);
   else DZN_C0(8);
 #undef DZN_C0
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+}  // namespace
+
+int launch_conv0(const float* wave, int B, int N, const float* stats, const float* w,
+                 const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
+                 int layer_norm, float eps, void* out, int out_bf16, hipStream_t st) {
+  if (k > 10 || C0 > 512 || s > 8) return DZN_E_INVALID;
+  // algorithmic HBM bytes: read the waveform once, write the [T0, C0] activations once
+  const double esz = out_bf16 ? 2.0 : 4.0;
+  const int pid = prof_begin(st, layer_norm ? "conv0_ln_gelu" : "conv0_raw",
+                             2.0 * B * (double)T0 * C0 * k, B * (4.0 * N + esz * (double)T0 * C0));
+  int rc;
+  if (out_bf16)
+    rc = conv0_dispatch(wave, B, N, stats, w, gamma, beta, C0, Cp, k, s, T0, layer_norm, eps,
+                        static_cast<u16*>(out), st);
+  else
+    rc = conv0_dispatch(wave, B, N, stats, w, gamma, beta, C0, Cp, k, s, T0, layer_norm, eps,
+                        static_cast<float*>(out), st);
   prof_end(pid, st);
+  return rc;
+}
+
+int launch_groupnorm_gelu(const float* x, void* y, int y_bf16, int B, int T, int C, int Cp, int64_t ld,
+                          const float* gamma, const float* beta, float eps, float* stats, hipStream_t st) {
+  hipLaunchKernelGGL(col_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, T, C, ld, eps, stats);
+  if (y_bf16)
+    hipLaunchKernelGGL(gn_gelu_kernel<u16>, dim3(grid_for((int64_t)T * Cp), B), dim3(256), 0, st, x,
+                       static_cast<u16*>(y), T, C, Cp, ld, stats, gamma, beta);
+  else
+    hipLaunchKernelGGL(gn_gelu_kernel<float>, dim3(grid_for((int64_t)T * Cp), B), dim3(256), 0, st, x,
+                       static_cast<float*>(y), T, C, Cp, ld, stats, gamma, beta);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
-int launch_groupnorm_gelu(float* x, int B, int T, int C, int64_t ld, const float* gamma,
-                          const float* beta, float eps, float* stats, hipStream_t st) {
-  hipLaunchKernelGGL(col_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, T, C, ld, eps,
-                     stats);
-  hipLaunchKernelGGL(gn_gelu_kernel, dim3(grid_for((int64_t)T * C), B), dim3(256), 0, st, x, T, C,
-                     ld, stats, gamma, beta);
-  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
-}
-
-int launch_pad_rows(const float* x, float* xpad, int B, int L, int Lp, int pad, int D,
+int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int Lp, int pad, int D,
                     hipStream_t st) {
-  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for((int64_t)Lp * (D / 4)), B), dim3(256), 0, st, x,
-                     xpad, L, Lp, pad, D / 4);
+  if (out_bf16)
+    hipLaunchKernelGGL(pad_rows_kernel<u16>, dim3(grid_for((int64_t)Lp * (D / 4)), B), dim3(256), 0, st,
+                       x, static_cast<u16*>(xpad), L, Lp, pad, D / 4);
+  else
+    hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(grid_for((int64_t)Lp * (D / 4)), B), dim3(256), 0, st,
+                       x, static_cast<float*>(xpad), L, Lp, pad, D / 4);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
@@ -237,8 +270,13 @@ int launch_ws_accum(const float* x, float* ws, float w, int init, int64_t n, hip
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
-int launch_col_scale(float* x, int64_t rows, int C, int64_t ld, const float* scale, hipStream_t st) {
-  hipLaunchKernelGGL(col_scale_kernel, dim3(grid_for(rows * C)), dim3(256), 0, st, x, rows, C, ld,
-                     scale);
+int launch_col_scale(void* x, int x_bf16, int64_t rows, int C, int64_t ld, const float* scale,
+                     hipStream_t st) {
+  if (x_bf16)
+    hipLaunchKernelGGL(col_scale_kernel<u16>, dim3(grid_for(rows * C)), dim3(256), 0, st,
+                       static_cast<u16*>(x), rows, C, ld, scale);
+  else
+    hipLaunchKernelGGL(col_scale_kernel<float>, dim3(grid_for(rows * C)), dim3(256), 0, st,
+                       static_cast<float*>(x), rows, C, ld, scale);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }

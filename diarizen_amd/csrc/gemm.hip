@@ -492,6 +492,8 @@ int launch_gemm(const dzn_gemm_desc& din, hipStream_t s) {
   if (d.alpha == 0.f) d.alpha = 1.f;
   if (d.precision == DZN_PREC_BF16) {
     if (!d.W16) return DZN_E_INVALID;
+    if (d.a_bf16) return launch_gemm_lowp(d, s);
+    if (d.c_bf16 || d.r_bf16) return DZN_E_INVALID;
     return launch_prec<true>(d, s);
   }
   if (!d.W) return DZN_E_INVALID;

@@ -1,33 +1,34 @@
-// norm.hip — row LayerNorm (+ optional erf-GELU) and per-window waveform statistics.
+// norm.hip — row LayerNorm (+ optional erf-GELU, + optional per-column post-scale), element-type
+// cast, and per-window waveform statistics.
 //
-// LayerNorm rows: torch.nn.functional.layer_norm over the last dim (biased variance,
-// eps inside the sqrt).  Sites: channel LN after conv1..6 of the WavLM extractor
-// (W2V/components.py:63-70, 119-122, fused with GELU), FeatureProjection.layer_norm
-// (:305), EncoderLayer.layer_norm / final_layer_norm (:923-941), Model.lnorm
-// (model_wavlm_conformer.py:257) and every Conformer ln_norm (conformer.py).
-// HBM-bound: one wavefront per row, the row is held in registers between the two
-// passes, so each element is read once and written once.
+// LayerNorm rows: torch.nn.functional.layer_norm over the last dim (biased variance, eps inside
+// the sqrt).  Sites: channel LN after conv1..6 of the WavLM extractor (W2V/components.py:63-70,
+// 119-122, fused with GELU; the last one also applies FeatureExtractor.dummy_weight, :208),
+// FeatureProjection.layer_norm (:305), EncoderLayer.layer_norm / final_layer_norm (:923-941),
+// Model.lnorm (model_wavlm_conformer.py:257) and every Conformer ln_norm (conformer.py).
+// HBM-bound: one wavefront per row, the row is held in registers between the two passes, so each
+// element is read once and written once.  Input / output may be fp32 or (bf16 engine mode) bf16.
 #include "common.h"
 
 namespace {
 
-template <int MAXI>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
-                                                        float* __restrict__ y, int64_t ldy,
+template <int MAXI, typename TI, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int64_t ldx,
+                                                        TO* __restrict__ y, int64_t ldy,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
-                                                        int64_t rows, int C, int Cpad, float eps,
-                                                        int gelu) {
+                                                        const float* __restrict__ post, int64_t rows,
+                                                        int C, int Cpad, float eps, int gelu) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= rows) return;
-  const float* xp = x + row * ldx;
+  const TI* xp = x + row * ldx;
   float v[MAXI];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXI; ++i) {
     const int idx = lane + 64 * i;
-    v[i] = idx < C ? xp[idx] : 0.f;
+    v[i] = idx < C ? ld_act(xp, idx) : 0.f;
     sum += v[i];
   }
   const float mean = wave_sum(sum) / (float)C;
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
   const float var = wave_sum(sq) / (float)C;
   const float rstd = 1.0f / sqrtf(var + eps);
-  float* yp = y + row * ldy;
+  TO* yp = y + row * ldy;
 #pragma unroll
   for (int i = 0; i < MAXI; ++i) {
     const int idx = lane + 64 * i;
@@ -48,10 +49,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       float o = (v[i] - mean) * rstd;
       if (gamma) o = o * gamma[idx] + beta[idx];
       if (gelu) o = gelu_erf(o);
-      yp[idx] = o;
+      if (post) o *= post[idx];
+      st_act(yp, idx, o);
     } else if (idx < Cpad) {
-      yp[idx] = 0.f;
+      st_act(yp, idx, 0.f);
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y,
+                                                        int64_t n4) {
+  const float4* xs = reinterpret_cast<const float4*>(x);
+  ushort4* yd = reinterpret_cast<ushort4*>(y);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = xs[i];
+    u16 t[4];
+    st_act(t, 0, v.x); st_act(t, 1, v.y); st_act(t, 2, v.z); st_act(t, 3, v.w);
+    yd[i] = make_ushort4(t[0], t[1], t[2], t[3]);
   }
 }
 
@@ -87,27 +101,51 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(const float* __restric
   }
 }
 
+template <typename TI, typename TO>
+int launch_ln_typed(const TI* x, int64_t ldx, TO* y, int64_t ldy, const float* g, const float* b,
+                    const float* post, int64_t rows, int C, int Cpad, float eps, int gelu, hipStream_t s) {
+  const unsigned grid = (unsigned)cdiv64(rows, 4);
+  const int need = (Cpad > C ? Cpad : C);
+#define DZN_LN(MAXI)                                                                               \
+  hipLaunchKernelGGL((layernorm_kernel<MAXI, TI, TO>), dim3(grid), dim3(256), 0, s, x, ldx, y, ldy, g, \
+                     b, post, rows, C, Cpad, eps, gelu)
+  if (need <= 256) DZN_LN(4);
+  else if (need <= 512) DZN_LN(8);
+  else if (need <= 1024) DZN_LN(16);
+  else DZN_LN(32);
+#undef DZN_LN
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
 }  // namespace
+
+int launch_layernorm_t(const void* x, int x_bf16, int64_t ldx, void* y, int y_bf16, int64_t ldy,
+                       const float* g, const float* b, const float* post, int64_t rows, int C, int Cpad,
+                       float eps, int gelu, hipStream_t s) {
+  if (rows <= 0) return DZN_OK;
+  if (C <= 0 || C > 2048 || Cpad > 2048) return DZN_E_INVALID;
+  const float* xf = static_cast<const float*>(x);
+  const u16* xh = static_cast<const u16*>(x);
+  float* yf = static_cast<float*>(y);
+  u16* yh = static_cast<u16*>(y);
+  if (!x_bf16 && !y_bf16) return launch_ln_typed(xf, ldx, yf, ldy, g, b, post, rows, C, Cpad, eps, gelu, s);
+  if (!x_bf16 && y_bf16) return launch_ln_typed(xf, ldx, yh, ldy, g, b, post, rows, C, Cpad, eps, gelu, s);
+  if (x_bf16 && !y_bf16) return launch_ln_typed(xh, ldx, yf, ldy, g, b, post, rows, C, Cpad, eps, gelu, s);
+  return launch_ln_typed(xh, ldx, yh, ldy, g, b, post, rows, C, Cpad, eps, gelu, s);
+}
 
 int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* g,
                      const float* b, int64_t rows, int C, int Cpad, float eps, int gelu,
                      hipStream_t s) {
-  if (rows <= 0) return DZN_OK;
-  if (C <= 0 || C > 2048 || Cpad > 2048) return DZN_E_INVALID;
-  const unsigned grid = (unsigned)cdiv64(rows, 4);
-  const int need = (Cpad > C ? Cpad : C);
-  if (need <= 256)
-    hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows,
-                       C, Cpad, eps, gelu);
-  else if (need <= 512)
-    hipLaunchKernelGGL(layernorm_kernel<8>, dim3(grid), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows,
-                       C, Cpad, eps, gelu);
-  else if (need <= 1024)
-    hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, s, x, ldx, y, ldy, g, b,
-                       rows, C, Cpad, eps, gelu);
-  else
-    hipLaunchKernelGGL(layernorm_kernel<32>, dim3(grid), dim3(256), 0, s, x, ldx, y, ldy, g, b,
-                       rows, C, Cpad, eps, gelu);
+  return launch_layernorm_t(x, 0, ldx, y, 0, ldy, g, b, nullptr, rows, C, Cpad, eps, gelu, s);
+}
+
+int launch_cast_bf16(const float* x, void* y, int64_t n, hipStream_t s) {
+  if (n <= 0) return DZN_OK;
+  if (n & 3) return DZN_E_INVALID;
+  int64_t g = cdiv64(n / 4, 256);
+  g = g > 8192 ? 8192 : g;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)g), dim3(256), 0, s, x, static_cast<u16*>(y), n / 4);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 

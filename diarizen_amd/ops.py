@@ -28,7 +28,10 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
     """C = epilogue(A @ W^T); see dzn_gemm_desc.  A: [M, K] (or raw buffer with lda / rowoff),
     W: [N, K] fp32 (and optionally W16 bf16)."""
     lib = _lib.load()
-    assert A.is_cuda and A.dtype == torch.float32
+    assert A.is_cuda and A.dtype in (torch.float32, torch.bfloat16)
+    a_bf16 = A.dtype == torch.bfloat16
+    if a_bf16 and C_out is None:
+        raise ValueError("bf16 A: pass C_out (fp32 or bf16) explicitly")
     if N is None:
         N = W.shape[0]
     if K is None:
@@ -56,6 +59,9 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
         for k, v in zs.items():
             setattr(d, k, v)
     d.precision = precision
+    d.a_bf16 = int(a_bf16)
+    d.c_bf16 = int(C_out.dtype == torch.bfloat16)
+    d.r_bf16 = int(R is not None and R.dtype == torch.bfloat16)
     check(lib.dzn_op_gemm(C.byref(d), _stream()), what="dzn_op_gemm")
     return C_out
 

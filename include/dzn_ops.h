@@ -67,6 +67,10 @@ typedef struct dzn_gemm_desc {
   int64_t a_z0, a_z1, w_z0, w_z1, c_z0, c_z1, b_z0, b_z1;
   int32_t precision;     /* DZN_PREC_* */
   double alg_flops;      /* algorithmic flops of this launch for profiling (0 -> 2*M*N*K*nz) */
+  /* bf16 mode only: element type of the activation buffers (pointers above are then bf16 data) */
+  int32_t a_bf16;        /* A holds bf16 (both operands arrive by LDS-DMA)               */
+  int32_t c_bf16;        /* C is written as bf16 (requires a_bf16)                       */
+  int32_t r_bf16;        /* R is read as bf16 (requires a_bf16)                          */
 } dzn_gemm_desc;
 
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);

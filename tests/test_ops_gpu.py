@@ -194,3 +194,46 @@ def test_gate(built_lib, gpu):
     ref = a * (b * cst.double() - 1.0) + 2.0
     out = ops.gate(y.to(gpu), Wg.to(gpu), bg.to(gpu), cst.to(gpu))
     assert (out.cpu().double() - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 256), (513, 1024, 1056), (257, 64, 96), (1000, 32, 288)])
+def test_gemm_bf16_activations(built_lib, gpu, M, N, K):
+    """both operands bf16 in HBM (LDS-DMA path), K tail at a 32-element half, bf16 / fp32 outputs,
+    bf16 residual, GELU epilogue"""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) * 0.1).bfloat16()
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g).bfloat16()
+    base = A.double() @ W.double().T + bias.double()
+    out32 = torch.empty(M, N, device=gpu)
+    ops.gemm(A.to(gpu), None, N=N, K=K, ldw=K, W16=W.to(gpu), bias=bias.to(gpu), C_out=out32, precision=1)
+    assert _rel_err(out32.cpu(), base) < 1e-5          # exact bf16 products, fp32 accumulation
+    out16 = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(A.to(gpu), None, N=N, K=K, ldw=K, W16=W.to(gpu), bias=bias.to(gpu), C_out=out16, precision=1,
+             act=1, R=R.to(gpu), post_relu=True)
+    ref = torch.relu(torch.nn.functional.gelu(base) + R.double())
+    assert _rel_err(out16.float().cpu(), ref) < 1e-2   # output rounded to bf16
+
+
+def test_gemm_bf16_activations_conv_addressing(built_lib, gpu):
+    """two-level K addressing + z batching on bf16 activations (positional-conv shape family)"""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(60)
+    Bn, L, D, G, k = 2, 50, 256, 4, 16
+    cg = D // G
+    x = torch.randn(Bn, L, D, generator=g).bfloat16()
+    w = (torch.randn(D, cg, k, generator=g) * 0.1).bfloat16()
+    ref = torch.nn.functional.conv1d(x.double().permute(0, 2, 1), w.double(), None, padding=k // 2,
+                                     groups=G)[..., :-1].permute(0, 2, 1)
+    Lp = L + k
+    xpad = torch.zeros(Bn, Lp, D, dtype=torch.bfloat16)
+    xpad[:, k // 2:k // 2 + L] = x
+    wp = w.permute(0, 2, 1).reshape(D, k * cg).contiguous()
+    out = torch.empty(Bn, L, D, device=gpu)
+    ops.gemm(xpad.to(gpu).view(-1), None, M=L, N=cg, K=k * cg, lda=D, kc=cg, ldk=D, ldw=k * cg,
+             W16=wp.to(gpu), C_out=out.view(-1), ldc=D, nz=Bn * G, zdiv=G, precision=1,
+             zs=dict(a_z0=Lp * D, a_z1=cg, w_z1=cg * k * cg, c_z0=L * D, c_z1=cg))
+    torch.cuda.synchronize()
+    assert _rel_err(out.cpu(), ref) < 1e-5
