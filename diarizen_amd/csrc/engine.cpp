@@ -848,7 +848,10 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   // ---- positional conv: x = x + gelu(conv_pos(x))  (components.py:980-987, 366-380) ----
   {
     const int Kc = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G, Lp = L + Kc;
-    chk(launch_pad_rows(h->x, h->xpad, lp, B, L, Lp, Kc / 2, D, st), "pad_rows");
+    // the LDS-DMA bf16 kernel needs kc % 32 == 0; otherwise (base: 768/16 = 48 channels per group)
+    // keep this one contraction on fp32 activations (register-staged kernel converts on the fly)
+    const bool pc16 = lp && (cg % 32 == 0);
+    chk(launch_pad_rows(h->x, h->xpad, pc16, B, L, Lp, Kc / 2, D, st), "pad_rows");
     dzn_gemm_desc d = gd(h, h->xpad, h->posconv, h->x, L, D, D);
     d.N = cg;
     d.kc = cg;
@@ -864,7 +867,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     d.c_z1 = cg;
     d.b_z1 = cg;
     d.alg_flops = 2.0 * (double)L * cg * h->posconv.Kt;
-    gemm(d, lp, false, "pos conv");
+    gemm(d, pc16, false, "pos conv");
   }
   if (!c.layer_norm_first) ln_t(h->x, false, D, h->x, false, D, h->enc_ln, ML, D, 0, st);
   chk(launch_ws_accum(h->x, h->ws, h->wsum_w[0], 1, ML * D, st), "ws_accum");

@@ -111,3 +111,19 @@ def test_embedding_16s_window_and_masks_kernel(built_lib, gpu):
     ref = emb_model.emb_forward(emb_model.emb_state_dict(0), wave, torch.from_numpy(ref_m.astype(np.float32)))
     rel = (emb.cpu() - ref).abs().max().item() / ref.abs().max().item()
     assert rel < 1e-4
+
+
+def test_embedding_bf16_engine(built_lib, gpu):
+    """bf16 engine mode (bf16 ResNet images / operands, fp32 accumulate, fbank + pooling + seg_1 fp32):
+    cosine >= 0.999 vs the reference golden, inactive speaker still exactly the bias"""
+    from oracle import emb_model
+    from oracle.gen_golden import synth_wave
+    g = np.load(os.path.join(GOLD, "emb_resnet.npz"))
+    B, N = int(g["B"]), int(g["N"])
+    eng = _engine(gpu, B, N, precision="bf16")
+    emb = eng.embed(synth_wave(B, N, int(g["wave_seed"])).to(gpu), torch.from_numpy(g["masks"]).to(gpu))
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g["emb"])
+    cos = torch.nn.functional.cosine_similarity(emb.cpu().reshape(-1, 256), ref.reshape(-1, 256), dim=-1)
+    assert cos.min().item() > 0.999
+    assert torch.equal(emb.cpu()[0, 2], emb_model.emb_state_dict(0)["resnet.seg_1.bias"])

@@ -146,3 +146,18 @@ def test_seg_dense_wavlm_base(built_lib, gpu):
     ref = seg_model.seg_forward(sd, cfg, wave)
     assert (logp.cpu() - ref).abs().max().item() < 1e-3
     assert torch.equal(logp.cpu().argmax(-1), ref.argmax(-1))
+
+
+@pytest.mark.parametrize("name", ["tiny_gn", "wavlm_base_s80_md"])
+def test_seg_bf16_group_norm_models(built_lib, gpu, name):
+    """bf16 engine on the base-style models (group-norm extractor, post-norm encoder, 48-channel
+    positional-conv groups for base: that contraction stays on fp32 activations)"""
+    cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, "bf16")
+    ref = torch.from_numpy(g["logp"])
+    assert (logp - ref).abs().max().item() <= 1e-1
+    # decisions may only differ on frames where the reference's own top-2 margin is inside the tolerance
+    differ = logp.argmax(-1) != ref.argmax(-1)
+    top2 = ref.topk(2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]
+    assert (margin[differ] <= 2e-1).all()
+    assert differ.float().mean().item() <= 0.03
