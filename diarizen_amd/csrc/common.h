@@ -15,10 +15,23 @@ typedef unsigned short u16;
 #define DZN_WAVE 64
 
 // ---- wave-level reductions (64-wide wavefront) ----
+// Sum over the 64 lanes with DPP cross-lane VALU ops (no LDS round trips, unlike __shfl_xor ->
+// ds_bpermute): quad_perm swaps, row rotations inside each 16-lane row, then row_bcast15 /
+// row_bcast31 fold the four rows into lane 63, which is read back as a wave-uniform scalar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(ROW_MASK == 0xF ? __float_as_int(v) : 0, __float_as_int(v), CTRL,
+                                            ROW_MASK, 0xF, false);
+  return v + __int_as_float(t);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_add<0xB1, 0xF>(v);   // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);   // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124, 0xF>(v);  // row_ror:4
+  v = dpp_add<0x128, 0xF>(v);  // row_ror:8  -> every lane holds its row's sum
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1, 3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2, 3 -> lanes 48..63 hold the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
