@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default=os.environ.get("DZN_BENCH_PRECISION", "f32"),
-                    choices=["f32", "bf16"])
+                    choices=["f32", "bf16", "f32s"])
     ap.add_argument("--minutes", type=float, default=30.0)
     ap.add_argument("--window", type=float, default=8.0)
     ap.add_argument("--batch", type=int, default=256)

@@ -16,6 +16,7 @@ DZN_MAX_HEADS = 16
 
 DZN_PREC_F32 = 0
 DZN_PREC_BF16 = 1
+DZN_PREC_F32_SPLIT = 2
 
 DZN_ACT_NONE, DZN_ACT_GELU, DZN_ACT_SWISH, DZN_ACT_RELU = 0, 1, 2, 3
 
@@ -85,6 +86,7 @@ class DznGemmDesc(C.Structure):
         ("precision", C.c_int32),
         ("alg_flops", C.c_double),
         ("a_bf16", C.c_int32), ("c_bf16", C.c_int32), ("r_bf16", C.c_int32),
+        ("W3", C.c_void_p),
     ]
 
 
@@ -142,6 +144,7 @@ def load() -> C.CDLL:
     sig("dzn_profile_collect", i32, [C.POINTER(DznProfEntry), i32, C.POINTER(i32)])
     sig("dzn_op_relpos_bucket", i32, [i32, i32, i32])
     sig("dzn_op_gemm", i32, [C.POINTER(DznGemmDesc), vp])
+    sig("dzn_op_split_weights", i32, [vp, i64, i32, i64, vp, vp])
     sig("dzn_op_layernorm", i32, [vp, i64, vp, i64, vp, vp, i64, i32, i32, f32, i32, vp])
     sig("dzn_op_gate", i32, [vp, i64, vp, vp, vp, vp, i64, i32, vp])
     sig("dzn_op_attention", i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp])
@@ -153,7 +156,7 @@ EXPORTED = [
     "dzn_create", "dzn_load_tensor", "dzn_finalize_weights", "dzn_num_frames",
     "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_debug_fetch", "dzn_num_ignored",
     "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version",
-    "dzn_op_gemm", "dzn_op_layernorm", "dzn_op_gate", "dzn_op_attention",
+    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_layernorm", "dzn_op_gate", "dzn_op_attention",
     "dzn_profile_enable", "dzn_profile_collect", "dzn_op_relpos_bucket",
 ]
 

@@ -79,6 +79,8 @@ static inline u16 f32_to_bf16_host(float f) {
 // ---- kernel launchers (implemented in the .hip files) ----
 int launch_gemm(const dzn_gemm_desc& d, hipStream_t s);
 int launch_gemm_lowp(const dzn_gemm_desc& d, hipStream_t s);  // gemm_lowp.hip: A and W both bf16
+int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s); // gemm_split.hip: fp32 via 3-way bf16 split
+int launch_split_weights(const float* W, int64_t rows, int K, int64_t ldw, void* W3, hipStream_t s);
 int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* g,
                      const float* b, int64_t rows, int C, int Cpad, float eps, int gelu,
                      hipStream_t s);

@@ -49,6 +49,7 @@ struct HostT {
 struct Lin {       // y = x W^T + b with W [N, K] (rows zero-padded to Np, cols to Kp)
   float* W = nullptr;
   u16* W16 = nullptr;
+  u16* W3 = nullptr;   // exact 3-way bf16 split planes (DZN_PREC_F32_SPLIT), gemm_split.hip layout
   float* b = nullptr;
   int N = 0, K = 0;    // padded sizes
   int Nt = 0, Kt = 0;  // reference (un-padded) sizes, for algorithmic flop accounting
@@ -205,6 +206,12 @@ Lin make_lin(H* h, const std::vector<float>& W, const float* bias, int N, int K,
   l.Kt = K;
   l.W = upload(h, wp);
   if (h->cfg.precision == DZN_PREC_BF16) l.W16 = upload_bf16(h, wp);
+  if (h->cfg.precision == DZN_PREC_F32_SPLIT && Kp % 32 == 0) {
+    l.W3 = dalloc<u16>(h, (int64_t)3 * Np * Kp, false);
+    if (launch_split_weights(l.W, Np, Kp, Kp, l.W3, nullptr) != DZN_OK)
+      throw EngineError(DZN_E_HIP, "split_weights launch failed");
+    HIPCHK(hipDeviceSynchronize());
+  }
   if (bias) {
     std::vector<float> bp(Np, 0.f);
     std::copy(bias, bias + N, bp.begin());
@@ -731,6 +738,7 @@ dzn_gemm_desc gd(H* h, const float* A, const Lin& l, float* C, int64_t M, int64_
   d.A = A;
   d.W = l.W;
   d.W16 = l.W16;
+  d.W3 = l.W3;
   d.C = C;
   d.bias = l.b;
   d.M = (int)M;
@@ -1137,7 +1145,8 @@ int dzn_create(const dzn_config* cfg, dzn_handle** out) {
     return DZN_E_INVALID;
   }
   if (cfg->max_batch < 1 || cfg->max_samples < 400 ||
-      (cfg->precision != DZN_PREC_F32 && cfg->precision != DZN_PREC_BF16)) {
+      (cfg->precision != DZN_PREC_F32 && cfg->precision != DZN_PREC_BF16 &&
+       cfg->precision != DZN_PREC_F32_SPLIT)) {
     last_create_error = "bad max_batch / max_samples / precision";
     return DZN_E_INVALID;
   }

@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -42,65 +43,6 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float4& a, const float4& b) {
   v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
   v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
   return *reinterpret_cast<uint4*>(&v);
-}
-
-template <int BM, int BN, int TM, int TN, int MI, int NI>
-__device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
-                                              int wm, int wn, int lr, int lq, int64_t cz, int64_t bz) {
-  // ---- epilogue: lane (lr, lq) of block (i, j) holds row m = ..+lr, columns n0..n0+3 ----
-  const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
-  const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = tm * BM + wm * TM + i * 16 + lr;
-    if (m >= d.M) continue;
-    const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n0 = tn * BN + wn * TN + j * 16 + lq * 4;
-      if (n0 >= d.N) continue;
-      f32x4 v = acc[i][j];
-      if (vec && n0 + 3 < d.N) {
-        if (bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act) * d.alpha;
-        if (d.R) {
-          const float4 r4 = *reinterpret_cast<const float4*>(d.R + crow + n0);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-        }
-        if (d.post_relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        *reinterpret_cast<float4*>(d.C + crow + n0) = make_float4(v[0], v[1], v[2], v[3]);
-        if (d.WS) {
-          float4* w = reinterpret_cast<float4*>(d.WS + (int64_t)m * d.ldws + n0);
-          float4 a = d.ws_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *w;
-          a.x += d.ws_w * v[0]; a.y += d.ws_w * v[1]; a.z += d.ws_w * v[2]; a.w += d.ws_w * v[3];
-          *w = a;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0 + e;
-          if (n >= d.N) continue;
-          float x = v[e];
-          if (bias) x += bias[n];
-          x = apply_act(x, d.act) * d.alpha;
-          if (d.R) x += d.R[crow + n];
-          if (d.post_relu) x = fmaxf(x, 0.f);
-          d.C[crow + n] = x;
-          if (d.WS) {
-            float* w = d.WS + (int64_t)m * d.ldws + n;
-            *w = d.ws_init ? d.ws_w * x : (*w + d.ws_w * x);
-          }
-        }
-      }
-    }
-  }
 }
 
 template <int BM, int BN, int WGM, int WGN, bool LOWP>
@@ -497,6 +439,8 @@ int launch_gemm(const dzn_gemm_desc& din, hipStream_t s) {
     return launch_prec<true>(d, s);
   }
   if (!d.W) return DZN_E_INVALID;
+  if (d.precision == DZN_PREC_F32_SPLIT && d.W3 && !(d.K & 31) && !(d.kc & 31) && d.ldw == d.K)
+    return launch_gemm_split(d, s);
   return launch_prec<false>(d, s);
 }
 

@@ -1,0 +1,396 @@
+// gemm_split.hip — fp32 contraction on the bf16 matrix pipe: exact 3-way operand split
+// ("f32s" engine mode, DZN_PREC_F32_SPLIT).
+//
+// Every fp32 value x is written as x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid) (round-to-nearest at each level; the two subtractions are exact and
+// lo needs <= 8 significant bits, so the decomposition is EXACT).  A product a*w is then
+//     a_hi w_hi + (a_hi w_mid + a_mid w_hi) + (a_hi w_lo + a_mid w_mid + a_lo w_hi)  [+ O(2^-24) terms]
+// i.e. six v_mfma_f32_16x16x32_bf16 products accumulated in fp32; the three dropped cross terms
+// (mid*lo, lo*mid, lo*lo) are bounded by 2^-23 |a w| — the size of one fp32 rounding of the
+// product.  6 bf16 MFMAs of 16 cycles replace 8 fp32 MFMAs (16x16x4) of 32 cycles for the same
+// 16x16x32 block: 2.67x less matrix-pipe time at fp32-grade accuracy (tests/test_ops_gpu.py
+// measures both kernels against a float64 product).
+//
+// Same contract as gemm.hip (dzn_gemm_desc, fused epilogue).  Data movement:
+//   A (activations) : fp32 in HBM, fp32 tile in LDS by LDS-DMA (128-B rows, XOR-swizzled exactly
+//       like the fp32 kernel); each wavefront splits the fragments it reads in registers
+//       (v_cvt_pk_bf16_f32 / shifts / packed fp32 subtracts, overlapped with the MFMAs).
+//   W (weights)     : split ONCE when the weights are packed (dzn_op_split_weights) into
+//       [N][K/32][plane 3][32] bf16; the 32 k of a block are stored in the order the fragment
+//       reads want (lane group q owns k = 4q..4q+3 and 16+4q..16+4q+3, matching the two 16-B
+//       slots q and 4+q of the fp32 A row), so every fragment is one ds_read_b128.  Each plane
+//       of a W tile is a [BN][64 B] LDS image; slot s of row r is stored at s ^ g((r>>2)&3),
+//       g = (0,2,3,1), which makes the four 16-lane groups of ds_read_b128 conflict free.
+// Requires K % 32 == 0 and kc % 32 == 0 (else the caller falls back to the fp32 MFMA kernel).
+#include <cstdio>
+#include <cstdlib>
+
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+__device__ __forceinline__ int wswz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// split 8 fp32 values (two 16-B LDS slots) into the three bf16 fragments; written on pairs so
+// that it compiles to 9 VALU instructions per pair: v_cvt_pk_bf16_f32, v_lshlrev, v_and,
+// v_pk_add_f32 (x - hi), v_cvt_pk, v_lshlrev, v_and, v_pk_add_f32, v_cvt_pk
+__device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  u32x4 H, M, L;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 x;
+    x[0] = p < 2 ? u[2 * p] : v[2 * p - 4];
+    x[1] = p < 2 ? u[2 * p + 1] : v[2 * p - 3];
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+    f32x2 hf;
+    hf[0] = __uint_as_float(hp << 16);
+    hf[1] = __uint_as_float(hp & 0xffff0000u);
+    const f32x2 r1 = x - hf;
+    const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+    f32x2 mf;
+    mf[0] = __uint_as_float(mp << 16);
+    mf[1] = __uint_as_float(mp & 0xffff0000u);
+    const f32x2 r2 = r1 - mf;
+    H[p] = hp;
+    M[p] = mp;
+    L[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+  }
+  hi = __builtin_bit_cast(bf16x8, H);
+  mid = __builtin_bit_cast(bf16x8, M);
+  lo = __builtin_bit_cast(bf16x8, L);
+}
+
+// truncation variant (hi = top 16 bits; remainders exact): and / v_pk_add / v_perm only
+__device__ __forceinline__ void split8_trunc(const f32x4& u, const f32x4& v, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  u32x4 H, M, L;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 x;
+    x[0] = p < 2 ? u[2 * p] : v[2 * p - 4];
+    x[1] = p < 2 ? u[2 * p + 1] : v[2 * p - 3];
+    const unsigned h0 = __float_as_uint(x[0]) & 0xffff0000u, h1 = __float_as_uint(x[1]) & 0xffff0000u;
+    f32x2 hf; hf[0] = __uint_as_float(h0); hf[1] = __uint_as_float(h1);
+    const f32x2 r = x - hf;
+    const unsigned m0 = __float_as_uint(r[0]) & 0xffff0000u, m1 = __float_as_uint(r[1]) & 0xffff0000u;
+    f32x2 mf; mf[0] = __uint_as_float(m0); mf[1] = __uint_as_float(m1);
+    const f32x2 q = r - mf;
+    H[p] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    M[p] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    L[p] = __builtin_amdgcn_perm(__float_as_uint(q[1]), __float_as_uint(q[0]), 0x07060302u);
+  }
+  hi = __builtin_bit_cast(bf16x8, H);
+  mid = __builtin_bit_cast(bf16x8, M);
+  lo = __builtin_bit_cast(bf16x8, L);
+}
+
+// s_waitcnt vmcnt(N) lgkmcnt(0), expcnt left at its maximum (gfx9 encoding: vmcnt = [3:0] + [15:14])
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+  static_assert(N >= 0 && N < 64, "vmcnt range");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4));
+}
+
+// BM x BN tile per workgroup of WGM x WGN wavefronts, S LDS stages of one 32-k tile each.
+//
+// Pipeline.  The matrix pipe retires a K tile in ~1.5k cycles per wavefront-tile while an LDS-DMA
+// fill needs 1.1-1.7 us (2.6k-4k cycles) to land, and a wavefront that has just passed a barrier
+// needs ~0.5k cycles of ds_read + split before its first MFMA.  So:
+//   * tiles are prefetched S tiles ahead (raw s_barrier + s_waitcnt vmcnt(N) that leaves the
+//     younger tiles in flight; __syncthreads would drain them);
+//   * the barrier of K tile kt sits in the MIDDLE of the tile's MFMAs: the first half of the
+//     rows is multiplied, then [wait tile kt+1, barrier, refill the stage of tile kt], then the
+//     fragments of tile kt+1 are read into the second register set while the second half of
+//     tile kt is multiplied — the matrix pipe has work queued across the barrier.
+template <int BM, int BN, int WGM, int WGN, int S, int DBG = 0>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_gemm_desc d) {
+  constexpr int NW = WGM * WGN;           // wavefronts per workgroup
+  constexpr int BK = 32;
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MI = TM / 16, NI = TN / 16, MH = MI / 2;
+  constexpr int RB = NW * 1024;           // bytes per LDS-DMA round (1 KiB per wavefront)
+  constexpr int ACH = BM * 128 / RB;      // rounds of the A tile (BM rows x 128 B)
+  constexpr int WROWS = NW * 16;          // rows of one W plane per round (64-B rows)
+  constexpr int WR = (BN + WROWS - 1) / WROWS;
+  constexpr int ABYTES = BM * 128, WPLANE = WR * WROWS * 64, BUF = ABYTES + 3 * WPLANE;
+  constexpr int LPT = ACH + 3 * WR;       // LDS-DMA instructions per thread per tile
+  static_assert(BM * 128 % RB == 0, "A tile must be whole rounds");
+  static_assert(MI % 2 == 0, "two row halves per wavefront tile");
+  static_assert(S >= 2 && (S - 1) * LPT < 64, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tilesN = (d.N + BN - 1) / BN;
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = t / tilesN, tn = t % tilesN;
+  const int z = blockIdx.y;
+  const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
+  const float* __restrict__ A = d.A + z0 * d.a_z0 + z1 * d.a_z1;
+  const u16* __restrict__ W3 = reinterpret_cast<const u16*>(d.W3) + 3 * (z0 * d.w_z0 + z1 * d.w_z1);
+  const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
+  const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
+
+  // A: thread -> (row = tid/8 + 8 NW i, physical slot tid%8), logical chunk = slot ^ ((row>>1)&7)
+  const int r0 = tid >> 3;
+  const int csw = (tid & 7) ^ ((r0 >> 1) & 7);
+  int64_t abase[ACH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    int m = tm * BM + r0 + 8 * NW * i;
+    m = m < d.M ? m : d.M - 1;
+    abase[i] = (d.a_rowoff ? (int64_t)d.a_rowoff[m] : (int64_t)m * d.lda) + csw * 4;
+  }
+  // W planes: thread -> (row = 16 wave + lane/4 + 16 NW i, physical slot lane%4); rows past N (and the
+  // padding rows of the last round) re-read row N-1, their accumulators are never stored
+  const int wr0 = wave * 16 + (lane >> 2);
+  const int wsw = (lane & 3) ^ wswz(wr0);
+  int64_t wbase[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    int n = tn * BN + wr0 + WROWS * i;
+    n = n < d.N ? n : d.N - 1;
+    wbase[i] = (int64_t)n * 3 * d.ldw + wsw * 8;
+  }
+
+  auto issue = [&](int k0, int stage) {
+    const int ch = k0 / d.kc;
+    const int64_t koff = (int64_t)ch * d.ldk + (k0 - ch * d.kc);
+    unsigned char* sA = smem + stage * BUF + wave * 1024;
+    unsigned char* sW = smem + stage * BUF + ABYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + abase[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(sA + i * RB), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < WR; ++i)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(W3 + wbase[i] + 3 * k0 + p * 32),
+            (__attribute__((address_space(3))) void*)(sW + p * WPLANE + i * RB), 16, 0, 0);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int lr = lane & 15, lq = lane >> 4;
+
+  // per-lane LDS byte offsets of the fragments inside a stage
+  int woff[NI], aoff0[MI], aoff1[MI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = wn * TN + j * 16 + lr;
+    woff[j] = ABYTES + row * 64 + ((lq ^ wswz(row)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * TM + i * 16 + lr;
+    const int sw = (row >> 1) & 7;
+    aoff0[i] = row * 128 + ((lq ^ sw) << 4);
+    aoff1[i] = row * 128 + (((4 + lq) ^ sw) << 4);
+  }
+  auto read_w = [&](int stage, bf16x8 (&wf)[NI][3]) {
+    const unsigned char* base = smem + stage * BUF;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wf[j][p] = *reinterpret_cast<const bf16x8*>(base + p * WPLANE + woff[j]);
+  };
+  auto read_a = [&](int stage, f32x4 (&ar)[MI][2]) {
+    const unsigned char* base = smem + stage * BUF;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      ar[i][0] = *reinterpret_cast<const f32x4*>(base + aoff0[i]);
+      ar[i][1] = *reinterpret_cast<const f32x4*>(base + aoff1[i]);
+    }
+  };
+  // six products of one 16-row block against all NI column blocks: smallest terms first, NI
+  // independent accumulators between dependent MFMAs
+  auto mma6 = [&](int i, const bf16x8 (&wf)[NI][3], const bf16x8& ah, const bf16x8& am, const bf16x8& al) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][2], ah, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], al, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], am, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], ah, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], am, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], ah, acc[i][j], 0, 0, 0);
+  };
+  auto split = [&](const f32x4 (&a)[2], bf16x8& ah, bf16x8& am, bf16x8& al) {
+    if constexpr (DBG == 3) {
+      ah = __builtin_bit_cast(bf16x8, a[0]); am = __builtin_bit_cast(bf16x8, a[1]); al = ah;
+    } else if constexpr (DBG == 4) {
+      split8_trunc(a[0], a[1], ah, am, al);
+    } else {
+      split8(a[0], a[1], ah, am, al);
+    }
+  };
+
+  const int nk = d.K / BK;
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    if (s < nk) issue(s * BK, s);
+  if (nk >= S) wait_vm_lgkm0<(S - 1) * LPT>();
+  else wait_vm_lgkm0<0>();
+  __builtin_amdgcn_s_barrier();
+  bf16x8 wfa[NI][3], wfb[NI][3];
+  f32x4 ar[MI][2];
+  read_w(0, wfa);
+  read_a(0, ar);
+  int stage = 0;
+
+  // one K tile: `wc` holds its W fragments, `ar` its raw A fragments; leaves tile kt+1 in (wn_, ar)
+  auto step = [&](int kt, const bf16x8 (&wc)[NI][3], bf16x8 (&wn_)[NI][3]) {
+    const bool more = kt + 1 < nk;
+#pragma unroll
+    for (int i = 0; i < MH; ++i) {
+      bf16x8 ah, am, al;
+      split(ar[i], ah, am, al);
+      if (DBG != 2) mma6(i, wc, ah, am, al);
+    }
+    bf16x8 ah[MI - MH], am[MI - MH], al[MI - MH];
+#pragma unroll
+    for (int i = MH; i < MI; ++i) split(ar[i], ah[i - MH], am[i - MH], al[i - MH]);
+    const int nstage = stage + 1 == S ? 0 : stage + 1;
+    __builtin_amdgcn_sched_barrier(0);  // keep the second half of the MFMAs BEHIND the barrier block
+    if (more) {
+      // tile kt+1 landed (tiles kt+2 .. kt+S-1 may stay in flight); all my reads of tile kt retired
+      if (kt + S <= nk) wait_vm_lgkm0<(S - 2) * LPT>();
+      else wait_vm_lgkm0<0>();
+      __builtin_amdgcn_s_barrier();
+      if (DBG != 1 && kt + S < nk) issue((kt + S) * BK, stage);  // every wave is past its reads of tile kt
+      read_w(nstage, wn_);
+      read_a(nstage, ar);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = MH; i < MI; ++i)
+      if (DBG != 2) mma6(i, wc, ah[i - MH], am[i - MH], al[i - MH]);
+    stage = nstage;
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, wfa, wfb);
+    if (kt + 1 < nk) step(kt + 1, wfb, wfa);
+  }
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz);
+}
+
+template <int BM, int BN, int WGM, int WGN, int S, int DBG = 0>
+int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
+  const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+  constexpr int WROWS = WGM * WGN * 16;
+  const size_t lds = (size_t)S * (BM * 128 + 3 * ((BN + WROWS - 1) / WROWS * WROWS) * 64);
+  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, DBG>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(tilesM * tilesN, d.nz > 0 ? d.nz : 1, 1);
+  int pid = -1;
+  if (prof_enabled()) {
+    char cls[64];
+    static const bool by_shape = getenv("DZN_PROFILE_SHAPES") != nullptr;
+    if (by_shape)
+      snprintf(cls, sizeof(cls), "gemm_f32s_%dx%d M%d N%d K%d z%d", BM, BN, d.M, d.N, d.K, d.nz);
+    else
+      snprintf(cls, sizeof(cls), "gemm_f32s_%dx%d", BM, BN);
+    const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
+    pid = prof_begin(s, cls, fl, 0.0);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, d);
+  prof_end(pid, s);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+// W [rows][K] fp32 (row stride ldw)  ->  W3 [rows][K/32][3][32] bf16, k permuted inside each block
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ W, int64_t rows, int K,
+                                                            int64_t ldw, u16* __restrict__ W3) {
+  const int64_t n = rows * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / K;
+    const int k = (int)(i - r * K);
+    const float x = W[r * ldw + k];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    const __bf16 l = (__bf16)r2;
+    const int kk = k & 31;
+    const int pos = 8 * ((kk & 15) >> 2) + (kk & 3) + 4 * (kk >> 4);
+    u16* o = W3 + r * 3 * K + (int64_t)(k >> 5) * 96 + pos;
+    o[0] = *reinterpret_cast<const u16*>(&h);
+    o[32] = *reinterpret_cast<const u16*>(&m);
+    o[64] = *reinterpret_cast<const u16*>(&l);
+  }
+}
+
+}  // namespace
+
+int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s) {
+  if ((d.K & 31) || (d.kc & 31) || !d.W3 || d.ldw != d.K) return DZN_E_INVALID;
+  static const char* force = getenv("DZN_GEMM_CFG");
+  if (force) {
+    if (!strcmp(force, "128x128s2")) return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
+    if (!strcmp(force, "128x128s2d1")) return launch_split_cfg<128, 128, 2, 2, 2, 1>(d, s);
+    if (!strcmp(force, "128x128s2d3")) return launch_split_cfg<128, 128, 2, 2, 2, 3>(d, s);
+    if (!strcmp(force, "128x128s2d4")) return launch_split_cfg<128, 128, 2, 2, 2, 4>(d, s);
+    if (!strcmp(force, "128x128s3")) return launch_split_cfg<128, 128, 2, 2, 3>(d, s);
+    if (!strcmp(force, "128x128s4")) return launch_split_cfg<128, 128, 2, 2, 4>(d, s);
+    if (!strcmp(force, "128x128w8s2")) return launch_split_cfg<128, 128, 4, 2, 2>(d, s);
+    if (!strcmp(force, "128x128w8s3")) return launch_split_cfg<128, 128, 4, 2, 3>(d, s);
+    if (!strcmp(force, "128x128w8s3d1")) return launch_split_cfg<128, 128, 4, 2, 3, 1>(d, s);
+    if (!strcmp(force, "128x128w8s3d3")) return launch_split_cfg<128, 128, 4, 2, 3, 3>(d, s);
+    if (!strcmp(force, "128x128w8s4")) return launch_split_cfg<128, 128, 4, 2, 4>(d, s);
+    if (!strcmp(force, "256x128w8s2")) return launch_split_cfg<256, 128, 4, 2, 2>(d, s);
+    if (!strcmp(force, "128x256w8s2")) return launch_split_cfg<128, 256, 2, 4, 2>(d, s);
+    if (!strcmp(force, "128x64s4")) return launch_split_cfg<128, 64, 2, 2, 4>(d, s);
+  }
+  if (d.N <= 32) return launch_split_cfg<128, 32, 4, 1, 2>(d, s);
+  if (d.N <= 64) return launch_split_cfg<128, 64, 2, 2, 2>(d, s);
+  if (d.K <= 512 && (d.N % 64) == 0) return launch_split_cfg<128, 64, 2, 2, 2>(d, s);
+  // column-tile width with the fewest padded columns; ties go to the wider tile
+  const int cand[3] = {128, 96, 64};
+  int best = 128, best_cols = 1 << 30;
+  for (int c : cand) {
+    const int cols = (d.N + c - 1) / c * c;
+    if (cols < best_cols) { best_cols = cols; best = c; }
+  }
+  switch (best) {
+    case 96: return launch_split_cfg<128, 96, 2, 2, 2>(d, s);
+    case 64: return launch_split_cfg<128, 64, 2, 2, 2>(d, s);
+    default: return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
+  }
+}
+
+int launch_split_weights(const float* W, int64_t rows, int K, int64_t ldw, void* W3, hipStream_t s) {
+  if (rows <= 0) return DZN_OK;
+  if (K <= 0 || (K & 31)) return DZN_E_INVALID;
+  int64_t g = cdiv64(rows * K, 256);
+  g = g > 8192 ? 8192 : g;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)g), dim3(256), 0, s, W, rows, K, ldw,
+                     static_cast<u16*>(W3));
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+extern "C" int dzn_op_split_weights(const float* W, int64_t rows, int32_t K, int64_t ldw, void* W3, void* stream) {
+  if (!W || !W3) return DZN_E_INVALID;
+  return launch_split_weights(W, rows, K, ldw, W3, reinterpret_cast<hipStream_t>(stream));
+}

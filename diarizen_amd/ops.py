@@ -24,7 +24,7 @@ def _p(t):
 def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None, ws_w=0.0,
          ws_init=False, a_rowoff=None, c_rowoff=None, lda=None, kc=0, ldk=0, ldw=None, ldc=None,
          ldws=0, act=0, alpha=1.0, post_relu=False, nz=1, zdiv=1, zs=None, precision=0,
-         W16=None):
+         W16=None, W3=None):
     """C = epilogue(A @ W^T); see dzn_gemm_desc.  A: [M, K] (or raw buffer with lda / rowoff),
     W: [N, K] fp32 (and optionally W16 bf16)."""
     lib = _lib.load()
@@ -46,6 +46,8 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
         C_out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     if ldc is None:
         ldc = C_out.stride(0) if C_out.dim() == 2 else N
+    if precision == _lib.DZN_PREC_F32_SPLIT and W3 is None and K % 32 == 0 and ldw == K and W.is_contiguous():
+        W3 = split_weights(W.reshape(-1, K))   # convenience for tests: engines split once at load
     d = DznGemmDesc()
     d.A, d.W, d.W16, d.C = _p(A), _p(W), _p(W16), _p(C_out)
     d.bias, d.R, d.WS = _p(bias), _p(R), _p(WS)
@@ -62,8 +64,21 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
     d.a_bf16 = int(a_bf16)
     d.c_bf16 = int(C_out.dtype == torch.bfloat16)
     d.r_bf16 = int(R is not None and R.dtype == torch.bfloat16)
+    d.W3 = _p(W3)
     check(lib.dzn_op_gemm(C.byref(d), _stream()), what="dzn_op_gemm")
     return C_out
+
+
+def split_weights(W):
+    """Exact 3-way bf16 split of fp32 weights [rows, K] (K % 32 == 0) for precision=DZN_PREC_F32_SPLIT:
+    returns the packed planes as an int16 tensor [rows, K // 32, 3, 32] (csrc/gemm_split.hip)."""
+    lib = _lib.load()
+    assert W.is_cuda and W.dtype == torch.float32 and W.dim() == 2 and W.shape[1] % 32 == 0
+    rows, K = W.shape
+    out = torch.empty((rows, K // 32, 3, 32), device=W.device, dtype=torch.int16)
+    check(lib.dzn_op_split_weights(_p(W), rows, K, W.stride(0), _p(out), _stream()),
+          what="dzn_op_split_weights")
+    return out
 
 
 def layernorm(x, gamma, beta, C_true=None, eps=1e-5, gelu=False, out=None):

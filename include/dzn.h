@@ -60,6 +60,9 @@ extern "C" {
 /* arithmetic of the MFMA contractions */
 #define DZN_PREC_F32 0   /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 everywhere          */
 #define DZN_PREC_BF16 1  /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream / norms */
+#define DZN_PREC_F32_SPLIT 2 /* fp32 data everywhere; contractions split both operands exactly into
+                                3 bf16 terms and run 6 bf16 MFMA products with fp32 accumulate
+                                (fp32-grade accuracy, csrc/gemm_split.hip) */
 
 /*
  * Architecture description.  Mirrors the kwargs of

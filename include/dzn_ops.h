@@ -71,9 +71,16 @@ typedef struct dzn_gemm_desc {
   int32_t a_bf16;        /* A holds bf16 (both operands arrive by LDS-DMA)               */
   int32_t c_bf16;        /* C is written as bf16 (requires a_bf16)                       */
   int32_t r_bf16;        /* R is read as bf16 (requires a_bf16)                          */
+  /* DZN_PREC_F32_SPLIT only: the weights pre-split into three bf16 planes by dzn_op_split_weights
+   * (same z / row offsets as W, times 3); NULL, K % 32 or kc % 32 != 0 -> fp32 MFMA kernel */
+  const void* W3;
 } dzn_gemm_desc;
 
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
+
+/* Exact 3-way bf16 split of fp32 weights for DZN_PREC_F32_SPLIT (csrc/gemm_split.hip):
+ * W fp32 [rows][K] (row stride ldw, K % 32 == 0) -> W3 bf16 [rows][K/32][3][32] (3*rows*K u16). */
+int dzn_op_split_weights(const float* W, int64_t rows, int32_t K, int64_t ldw, void* W3, void* stream);
 
 /* y[r,:] = LayerNorm(x[r,:C]) * gamma + beta (eps), optional fused erf-GELU; row strides
  * ldx / ldy; columns [C, Cpad) of y are written as zero.  torch F.layer_norm. */

@@ -29,14 +29,15 @@ def _engine(gpu, B, N, precision="f32", taps=False):
         os.environ.pop("DZN_DEBUG_TAPS", None)
 
 
-def test_embedding_matches_reference_golden(built_lib, gpu):
+@pytest.mark.parametrize("precision", ["f32", "f32s"])
+def test_embedding_matches_reference_golden(built_lib, gpu, precision):
     from oracle import emb_model
     from oracle.gen_golden import synth_wave
     g = np.load(os.path.join(GOLD, "emb_resnet.npz"))
     B, N = int(g["B"]), int(g["N"])
     wave = synth_wave(B, N, int(g["wave_seed"]))
     masks = torch.from_numpy(g["masks"])
-    eng = _engine(gpu, B, N, taps=True)
+    eng = _engine(gpu, B, N, precision=precision, taps=True)
     emb = eng.embed(wave.to(gpu), masks.to(gpu))
     torch.cuda.synchronize()
     emb = emb.cpu()

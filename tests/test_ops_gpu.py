@@ -12,13 +12,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+# fp32 contraction kernels: 0 = fp32 MFMA, 2 = exact 3-way bf16 split + 6 bf16 MFMA products
+F32_MODES = [0, 2]
+
+
 def _rel_err(a, b):
     return (a.double() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-12)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 96), (257, 64, 64), (1000, 32, 288),
                                    (77, 153, 1536), (513, 1770, 1024), (64, 11, 256)])
-def test_gemm_plain(built_lib, gpu, M, N, K):
+@pytest.mark.parametrize("prec", F32_MODES)
+def test_gemm_plain(built_lib, gpu, M, N, K, prec):
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g)
@@ -26,12 +31,13 @@ def test_gemm_plain(built_lib, gpu, M, N, K):
     W = torch.randn(N, K, generator=g) * torch.linspace(0.5, 1.5, N)[:, None]
     bias = torch.randn(N, generator=g)
     ref = A.double() @ W.double().T + bias.double()
-    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu))
+    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), precision=prec)
     torch.cuda.synchronize()
     assert _rel_err(out.cpu(), ref) < 1e-5
 
 
-def test_gemm_epilogues(built_lib, gpu):
+@pytest.mark.parametrize("prec", F32_MODES)
+def test_gemm_epilogues(built_lib, gpu, prec):
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(3)
     M, N, K = 333, 160, 128
@@ -41,22 +47,23 @@ def test_gemm_epilogues(built_lib, gpu):
     R = torch.randn(M, N, generator=g)
     base = A.double() @ W.double().T + bias.double()
     # gelu
-    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), act=1)
+    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), precision=prec, act=1)
     assert _rel_err(out.cpu(), torch.nn.functional.gelu(base)) < 1e-5
     # swish * 0.5 + residual
-    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), act=2, alpha=0.5, R=R.to(gpu))
+    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), precision=prec, act=2, alpha=0.5, R=R.to(gpu))
     assert _rel_err(out.cpu(), R.double() + 0.5 * base * torch.sigmoid(base)) < 1e-5
     # residual + post relu
-    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), R=R.to(gpu), post_relu=True)
+    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), precision=prec, R=R.to(gpu), post_relu=True)
     assert _rel_err(out.cpu(), torch.relu(base + R.double())) < 1e-5
     # weighted-sum accumulate
     WS = torch.zeros(M, N, device=gpu)
-    ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), WS=WS, ws_w=0.3, ws_init=True, ldws=N)
-    ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), WS=WS, ws_w=-1.2, ws_init=False, ldws=N)
+    ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), precision=prec, WS=WS, ws_w=0.3, ws_init=True, ldws=N)
+    ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), precision=prec, WS=WS, ws_w=-1.2, ws_init=False, ldws=N)
     assert _rel_err(WS.cpu(), (0.3 - 1.2) * base) < 1e-5
 
 
-def test_gemm_conv1d_overlapping_rows(built_lib, gpu):
+@pytest.mark.parametrize("prec", F32_MODES)
+def test_gemm_conv1d_overlapping_rows(built_lib, gpu, prec):
     """conv1d(k=3, s=2) over channels-last rows == contraction with lda = s*C, K = k*C."""
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -69,12 +76,13 @@ def test_gemm_conv1d_overlapping_rows(built_lib, gpu):
     wp = w.permute(0, 2, 1).reshape(Co, k * Ci).contiguous()  # k index = j*Ci + ci
     out = torch.empty(Bn, To, Co, device=gpu)
     ops.gemm(xcl.to(gpu).view(-1), wp.to(gpu), M=To, N=Co, K=k * Ci, lda=s * Ci, C_out=out.view(-1),
-             ldc=Co, nz=Bn, zdiv=1, zs=dict(a_z0=T * Ci, c_z0=To * Co))
+             ldc=Co, nz=Bn, zdiv=1, zs=dict(a_z0=T * Ci, c_z0=To * Co), precision=prec)
     torch.cuda.synchronize()
     assert _rel_err(out.cpu().permute(0, 2, 1), ref) < 1e-5
 
 
-def test_gemm_grouped_posconv_two_level_k(built_lib, gpu):
+@pytest.mark.parametrize("prec", F32_MODES)
+def test_gemm_grouped_posconv_two_level_k(built_lib, gpu, prec):
     """grouped conv1d(k=16, groups=4, pad) via (kc, ldk) addressing and z-batching."""
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(6)
@@ -92,12 +100,13 @@ def test_gemm_grouped_posconv_two_level_k(built_lib, gpu):
     out = torch.empty(Bn, L, D, device=gpu)
     ops.gemm(xpad.to(gpu).view(-1), wp.to(gpu), M=L, N=cg, K=k * cg, lda=D, kc=cg, ldk=D,
              ldw=k * cg, bias=bias.to(gpu), C_out=out.view(-1), ldc=D, nz=Bn * G, zdiv=G,
-             zs=dict(a_z0=Lp * D, a_z1=cg, w_z1=cg * k * cg, c_z0=L * D, c_z1=cg, b_z1=cg))
+             zs=dict(a_z0=Lp * D, a_z1=cg, w_z1=cg * k * cg, c_z0=L * D, c_z1=cg, b_z1=cg), precision=prec)
     torch.cuda.synchronize()
     assert _rel_err(out.cpu(), ref) < 1e-5
 
 
-def test_gemm_rowoff_tables(built_lib, gpu):
+@pytest.mark.parametrize("prec", F32_MODES)
+def test_gemm_rowoff_tables(built_lib, gpu, prec):
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(8)
     M, N, K = 200, 64, 64
@@ -109,9 +118,34 @@ def test_gemm_rowoff_tables(built_lib, gpu):
     ref = A.double() @ W.double().T
     out = torch.zeros(M * N, device=gpu)
     ops.gemm(buf.to(gpu), W.to(gpu), M=M, N=N, K=K, lda=0, a_rowoff=aoff.to(gpu),
-             c_rowoff=coff.to(gpu), C_out=out, ldc=N)
+             c_rowoff=coff.to(gpu), C_out=out, ldc=N, precision=prec)
     got = out.cpu().view(M, N)[(coff // N).long()]
     assert _rel_err(got, ref) < 1e-5
+
+
+def test_gemm_split_is_fp32_grade(built_lib, gpu):
+    """The 3-way split kernel against a float64 product, next to the fp32 MFMA kernel on the same
+    data (wide dynamic range activations): its error must not exceed the fp32 MFMA kernel's (x1.5),
+    measured relative to sum_k |a||w| (the scale fp32 rounding errors live on)."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 1024, 384, 2048
+    A = torch.randn(M, K, generator=g) * torch.exp(2.0 * torch.randn(M, K, generator=g))
+    W = torch.randn(N, K, generator=g) * 0.05
+    ref = A.double() @ W.double().T
+    scale = A.double().abs() @ W.double().abs().T
+    errs = {}
+    for prec in F32_MODES:
+        out = ops.gemm(A.to(gpu), W.to(gpu), precision=prec).cpu().double()
+        e = (out - ref).abs() / scale
+        errs[prec] = (e.max().item(), e.pow(2).mean().sqrt().item())
+    assert errs[2][0] <= 1.5 * errs[0][0] and errs[2][1] <= 1.5 * errs[0][1], errs
+    assert errs[2][0] < 2e-6, errs
+    # the split itself is exact: hi + mid + lo == x bit for bit
+    W3 = ops.split_weights(W.to(gpu)).cpu().view(torch.bfloat16).float()      # [N, K/32, 3, 32]
+    pos = torch.tensor([8 * ((k & 15) >> 2) + (k & 3) + 4 * (k >> 4) for k in range(32)])
+    rec = (W3[:, :, 0] + W3[:, :, 1] + W3[:, :, 2])[:, :, pos].reshape(N, K)
+    assert torch.equal(rec, W)
 
 
 def test_gemm_bf16(built_lib, gpu):

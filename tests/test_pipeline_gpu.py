@@ -17,16 +17,16 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 WAV = os.path.join(GOLD, "EN2002a_30s.wav")
 
 
-@pytest.fixture(scope="module")
-def pipeline(built_lib, gpu):
+@pytest.fixture(scope="module", params=["f32", "f32s"])
+def pipeline(built_lib, gpu, request):
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.pipeline import DiariZenPipeline
     from diarizen_amd.weights import emb_state_dict, seg_state_dict
     from oracle.gen_golden import E2E_CONFIG
     import copy
     cfg = get_seg_config("wavlm_large_s80_md")
-    return DiariZenPipeline(None, None, config=copy.deepcopy(E2E_CONFIG), device=gpu, precision="f32",
-                            seg_state=seg_state_dict(cfg, 0), emb_state=emb_state_dict(0))
+    return DiariZenPipeline(None, None, config=copy.deepcopy(E2E_CONFIG), device=gpu,
+                            precision=request.param, seg_state=seg_state_dict(cfg, 0), emb_state=emb_state_dict(0))
 
 
 def test_device_stage_matches_reference_execution(pipeline):

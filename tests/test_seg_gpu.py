@@ -62,9 +62,12 @@ def _tap_report(cfg, sd, wave, eng):
     return "\n".join(lines)
 
 
+# "f32"  = fp32 MFMA (v_mfma_f32_16x16x4_f32); "f32s" = fp32 by exact 3-way bf16 operand split, six
+# bf16 MFMA products, fp32 accumulate (csrc/gemm_split.hip).  Same strict tolerance for both.
+@pytest.mark.parametrize("precision", ["f32", "f32s"])
 @pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
-def test_seg_fp32_matches_reference_golden(built_lib, gpu, name):
-    cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, "f32", want_taps=True)
+def test_seg_fp32_matches_reference_golden(built_lib, gpu, name, precision):
+    cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, precision, want_taps=True)
     ref = torch.from_numpy(g["logp"])
     err = (logp - ref).abs().max().item()
     report = _tap_report(cfg, sd, wave, eng) if err > 1e-3 else ""
@@ -113,7 +116,8 @@ def test_seg_batch_and_ragged_lengths(built_lib, gpu):
         eng.segment(torch.zeros(6, 12000, device=gpu))  # B > max_batch must fail loudly
 
 
-def test_seg_16s_window_cli_default(built_lib, gpu):
+@pytest.mark.parametrize("precision", ["f32", "f32s"])
+def test_seg_16s_window_cli_default(built_lib, gpu, precision):
     """the reference CLI default is 16 s windows (diarizen/pipelines/inference.py:224-228): L = 799"""
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.engine import Engine
@@ -122,7 +126,7 @@ def test_seg_16s_window_cli_default(built_lib, gpu):
     cfg = get_seg_config("wavlm_large_s80_md")
     sd = seg_model.seg_state_dict(cfg, 0)
     wave = synth_wave(1, 256000, 41)
-    eng = Engine(cfg, sd, max_batch=1, max_samples=256000, precision="f32", device=gpu)
+    eng = Engine(cfg, sd, max_batch=1, max_samples=256000, precision=precision, device=gpu)
     logp, ml = eng.segment(wave.to(gpu))
     torch.cuda.synchronize()
     ref = seg_model.seg_forward(sd, cfg, wave)
@@ -131,7 +135,8 @@ def test_seg_16s_window_cli_default(built_lib, gpu):
     assert torch.equal(ml.cpu(), seg_model.to_multilabel(ref, cfg).to(torch.uint8))
 
 
-def test_seg_dense_wavlm_base(built_lib, gpu):
+@pytest.mark.parametrize("precision", ["f32", "f32s"])
+def test_seg_dense_wavlm_base(built_lib, gpu, precision):
     """un-pruned wavlm_base (12 x 12 heads, FFN 3072, 512-channel extractor, post-norm, group-norm)"""
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.engine import Engine
@@ -140,7 +145,7 @@ def test_seg_dense_wavlm_base(built_lib, gpu):
     cfg = get_seg_config("wavlm_base")
     sd = seg_model.seg_state_dict(cfg, 3)
     wave = synth_wave(2, 16000, 42)
-    eng = Engine(cfg, sd, max_batch=2, max_samples=16000, precision="f32", device=gpu)
+    eng = Engine(cfg, sd, max_batch=2, max_samples=16000, precision=precision, device=gpu)
     logp, ml = eng.segment(wave.to(gpu))
     torch.cuda.synchronize()
     ref = seg_model.seg_forward(sd, cfg, wave)
