@@ -24,6 +24,7 @@
 // Requires K % 32 == 0 and kc % 32 == 0 (else the caller falls back to the fp32 MFMA kernel).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_epilogue.h"
@@ -116,14 +117,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
   constexpr int ACH = BM * 128 / RB;      // rounds of the A tile (BM rows x 128 B)
   constexpr int WROWS = NW * 16;          // rows of one W plane per round (64-B rows)
   constexpr int WR = (BN + WROWS - 1) / WROWS;
-  constexpr int ABYTES = BM * 128, WPLANE = WR * WROWS * 64, BUF = ABYTES + 3 * WPLANE;
-  constexpr int LPT = ACH + 3 * WR;       // LDS-DMA instructions per thread per tile
+  constexpr int ABYTES = BM * 128, WPLANE = BN * 64, BUF = ABYTES + 3 * WPLANE;
+  constexpr int LPT = ACH + 3 * WR;       // LDS-DMA instructions per thread per tile (3 fewer for the
+                                          // wavefronts that sit out a partial last W round)
+  constexpr bool WPART = BN % WROWS != 0;
   static_assert(BM * 128 % RB == 0, "A tile must be whole rounds");
   static_assert(MI % 2 == 0, "two row halves per wavefront tile");
   static_assert(S >= 2 && (S - 1) * LPT < 64, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS-DMA bases stay scalar
   const int wm = wave / WGN, wn = wave % WGN;
   const int tilesN = (d.N + BN - 1) / BN;
   int t;
@@ -143,41 +147,49 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
   // A: thread -> (row = tid/8 + 8 NW i, physical slot tid%8), logical chunk = slot ^ ((row>>1)&7)
   const int r0 = tid >> 3;
   const int csw = (tid & 7) ^ ((r0 >> 1) & 7);
-  int64_t abase[ACH];
+  const float* aptr[ACH];   // per-thread source of K tile 0; a K tile adds a uniform offset
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
     int m = tm * BM + r0 + 8 * NW * i;
     m = m < d.M ? m : d.M - 1;
-    abase[i] = (d.a_rowoff ? (int64_t)d.a_rowoff[m] : (int64_t)m * d.lda) + csw * 4;
+    aptr[i] = A + (d.a_rowoff ? (int64_t)d.a_rowoff[m] : (int64_t)m * d.lda) + csw * 4;
   }
-  // W planes: thread -> (row = 16 wave + lane/4 + 16 NW i, physical slot lane%4); rows past N (and the
-  // padding rows of the last round) re-read row N-1, their accumulators are never stored
+  // W planes: thread -> (row = 16 wave + lane/4 + 16 NW i, physical slot lane%4); rows past N re-read
+  // row N-1 (their accumulators are never stored); a partial last round is fetched by the first waves only
+  const bool wfull = !WPART || (WR - 1) * WROWS + wave * 16 < BN;   // wave-uniform
   const int wr0 = wave * 16 + (lane >> 2);
   const int wsw = (lane & 3) ^ wswz(wr0);
-  int64_t wbase[WR];
+  const u16* wptr[WR];
 #pragma unroll
   for (int i = 0; i < WR; ++i) {
     int n = tn * BN + wr0 + WROWS * i;
     n = n < d.N ? n : d.N - 1;
-    wbase[i] = (int64_t)n * 3 * d.ldw + wsw * 8;
+    wptr[i] = W3 + (int64_t)n * 3 * d.ldw + wsw * 8;
   }
 
-  auto issue = [&](int k0, int stage) {
-    const int ch = k0 / d.kc;
-    const int64_t koff = (int64_t)ch * d.ldk + (k0 - ch * d.kc);
+  // the next K tile to fetch: k index and its A element offset (two-level K addressing), advanced
+  // incrementally on the scalar unit
+  int ik = 0, irem = 0;
+  int64_t ikoff = 0;
+  auto issue = [&](int stage) {
     unsigned char* sA = smem + stage * BUF + wave * 1024;
     unsigned char* sW = smem + stage * BUF + ABYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < ACH; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + abase[i] + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[i] + ikoff),
                                        (__attribute__((address_space(3))) void*)(sA + i * RB), 16, 0, 0);
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int i = 0; i < WR; ++i)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(W3 + wbase[i] + 3 * k0 + p * 32),
-            (__attribute__((address_space(3))) void*)(sW + p * WPLANE + i * RB), 16, 0, 0);
+        if (i + 1 < WR || wfull)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(wptr[i] + 3 * ik + p * 32),
+              (__attribute__((address_space(3))) void*)(sW + p * WPLANE + i * RB), 16, 0, 0);
+    ik += BK;
+    irem += BK;
+    ikoff += BK;
+    if (irem == d.kc) { irem = 0; ikoff += d.ldk - d.kc; }
   };
 
   f32x4 acc[MI][NI];
@@ -245,8 +257,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
   const int nk = d.K / BK;
 #pragma unroll
   for (int s = 0; s < S; ++s)
-    if (s < nk) issue(s * BK, s);
-  if (nk >= S) wait_vm_lgkm0<(S - 1) * LPT>();
+    if (s < nk) issue(s);
+  // wait until all but the `T` youngest tiles of this wavefront's LDS-DMA have landed
+  auto wait_tiles = [&](auto tiles) {
+    constexpr int T = decltype(tiles)::value;
+    if (wfull) wait_vm_lgkm0<T * LPT>();
+    else wait_vm_lgkm0<T * (LPT - 3)>();
+  };
+  if (nk >= S) wait_tiles(std::integral_constant<int, S - 1>{});
   else wait_vm_lgkm0<0>();
   __builtin_amdgcn_s_barrier();
   bf16x8 wfa[NI][3], wfb[NI][3];
@@ -271,10 +289,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
     __builtin_amdgcn_sched_barrier(0);  // keep the second half of the MFMAs BEHIND the barrier block
     if (more) {
       // tile kt+1 landed (tiles kt+2 .. kt+S-1 may stay in flight); all my reads of tile kt retired
-      if (kt + S <= nk) wait_vm_lgkm0<(S - 2) * LPT>();
+      if (kt + S <= nk) wait_tiles(std::integral_constant<int, S - 2>{});
       else wait_vm_lgkm0<0>();
       __builtin_amdgcn_s_barrier();
-      if (DBG != 1 && kt + S < nk) issue((kt + S) * BK, stage);  // every wave is past its reads of tile kt
+      if (DBG != 1 && kt + S < nk) issue(stage);  // every wave is past its reads of tile kt
       read_w(nstage, wn_);
       read_a(nstage, ar);
     }
@@ -294,8 +312,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
 template <int BM, int BN, int WGM, int WGN, int S, int DBG = 0>
 int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-  constexpr int WROWS = WGM * WGN * 16;
-  const size_t lds = (size_t)S * (BM * 128 + 3 * ((BN + WROWS - 1) / WROWS * WROWS) * 64);
+  const size_t lds = (size_t)S * (BM * 128 + 3 * BN * 64);
   auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, DBG>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -361,23 +378,26 @@ int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s) {
     if (!strcmp(force, "128x128w8s4")) return launch_split_cfg<128, 128, 4, 2, 4>(d, s);
     if (!strcmp(force, "256x128w8s2")) return launch_split_cfg<256, 128, 4, 2, 2>(d, s);
     if (!strcmp(force, "128x256w8s2")) return launch_split_cfg<128, 256, 2, 4, 2>(d, s);
-    if (!strcmp(force, "128x64s4")) return launch_split_cfg<128, 64, 2, 2, 4>(d, s);
+    if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 2, 2, 2>(d, s);
+    if (!strcmp(force, "128x64v")) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
+    if (!strcmp(force, "128x64vs3")) return launch_split_cfg<128, 64, 4, 1, 3>(d, s);
+    if (!strcmp(force, "256x64w8")) return launch_split_cfg<256, 64, 8, 1, 2>(d, s);
+    if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2>(d, s);
+    if (!strcmp(force, "128x32s4")) return launch_split_cfg<128, 32, 4, 1, 4>(d, s);
+    if (!strcmp(force, "256x32w8")) return launch_split_cfg<256, 32, 8, 1, 2>(d, s);
+    if (!strcmp(force, "128x96")) return launch_split_cfg<128, 96, 2, 2, 2>(d, s);
+    if (!strcmp(force, "128x160")) return launch_split_cfg<128, 160, 2, 2, 2>(d, s);
+    if (!strcmp(force, "128x192")) return launch_split_cfg<128, 192, 2, 2, 2>(d, s);
+    if (!strcmp(force, "128x128v")) return launch_split_cfg<128, 128, 4, 1, 2>(d, s);
   }
   if (d.N <= 32) return launch_split_cfg<128, 32, 4, 1, 2>(d, s);
-  if (d.N <= 64) return launch_split_cfg<128, 64, 2, 2, 2>(d, s);
-  if (d.K <= 512 && (d.N % 64) == 0) return launch_split_cfg<128, 64, 2, 2, 2>(d, s);
-  // column-tile width with the fewest padded columns; ties go to the wider tile
-  const int cand[3] = {128, 96, 64};
-  int best = 128, best_cols = 1 << 30;
-  for (int c : cand) {
-    const int cols = (d.N + c - 1) / c * c;
-    if (cols < best_cols) { best_cols = cols; best = c; }
-  }
-  switch (best) {
-    case 96: return launch_split_cfg<128, 96, 2, 2, 2>(d, s);
-    case 64: return launch_split_cfg<128, 64, 2, 2, 2>(d, s);
-    default: return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
-  }
+  // 128x64 tiles run 4 wavefronts as 4x1 (32 rows x 64 columns each): the in-register operand
+  // split is per A row, so wide-and-short wavefront tiles halve the VALU work per MFMA
+  if (d.N <= 64 || d.K <= 512) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
+  // 128-wide column tiles unless 64-wide ones save more than ~1/8 of the (padded) columns
+  const int cols128 = (d.N + 127) / 128 * 128, cols64 = (d.N + 63) / 64 * 64;
+  if (cols64 * 9 < cols128 * 8) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
+  return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
 }
 
 int launch_split_weights(const float* W, int64_t rows, int K, int64_t ldw, void* W3, hipStream_t s) {
