@@ -267,7 +267,8 @@ int launch_attention_t(const float* qkv, void* out, int out_bf16, const float* g
 int launch_attention(const float* qkv, float* out, const float* gate, const float* table,
                      const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
                      float scale, int precision, hipStream_t s) {
-  (void)precision;
+  if (precision == DZN_PREC_F32_SPLIT)
+    return launch_attention_split(qkv, out, gate, table, head_idx, B, L, h, Htot, ldqkv, ldo, scale, s);
   return launch_attention_t(qkv, out, 0, gate, table, head_idx, B, L, h, Htot, ldqkv, ldo, scale, s);
 }
 

@@ -1,0 +1,278 @@
+// attention_split.hip — the fused attention of attention.hip with both contractions (S = Q K^T and
+// O = P V) on the bf16 matrix pipe through the exact 3-way operand split of split.h
+// (DZN_PREC_F32_SPLIT): 6 bf16 MFMA products per 16x16x32 block, fp32 accumulate, fp32 softmax.
+//
+// Same reference arithmetic and work split as attention.hip (W2V/components.py:453-486, :690-725;
+// conformer.py:47-71; grid (ceil(L/64), kept heads, B), 4 wavefronts x 16 queries, flash-style
+// online softmax, S computed transposed so a lane owns one query column).  What changes:
+//   * Q is split once per workgroup (registers); K and V are split ONCE per 64-key tile by the
+//     staging pass (each element by exactly one thread) and stored as three bf16 planes in LDS;
+//     P (the probabilities, already in registers in MFMA operand order) is split per wavefront.
+//   * the k dimension of P.V is the key index, so V is staged TRANSPOSED: thread (d, group)
+//     gathers the 8 keys one lane group feeds to one MFMA (coalesced across d) and writes them as
+//     one 16-byte run of the [d][key] plane — the P fragment needs no data movement at all.
+//   * planes are [64][128 B] images with the 16-B slot XOR ((row >> 1) & 7): every fragment is one
+//     conflict-free ds_read_b128.
+#include "common.h"
+#include "split.h"
+
+namespace {
+
+constexpr int ATT_PLANE = 64 * 128;  // one bf16 plane of a 64 x 64 tile
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) void attn_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                         const float* __restrict__ gate,
+                                                         const float* __restrict__ table,
+                                                         const int32_t* __restrict__ head_idx, int B, int L,
+                                                         int h, int Htot, int ldqkv, int ldo, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;                    // 3 planes [64 keys][64 d]
+  unsigned char* sV = smem + 3 * ATT_PLANE;    // 3 planes [64 d][64 keys in MFMA order]
+  float* sT = reinterpret_cast<float*>(smem + 6 * ATT_PLANE);  // [2L-1] bias table of this head
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int qt = blockIdx.x, j = blockIdx.y, b = blockIdx.z;
+  const int64_t rowbase = (int64_t)b * L;
+  const float* Qp = qkv + j * 64;
+  const float* Kp = qkv + (h + j) * 64;
+  const float* Vp = qkv + (2 * h + j) * 64;
+
+  int H = 0;
+  if constexpr (BIAS) {
+    H = head_idx[j];
+    for (int i = tid; i < 2 * L - 1; i += 256) sT[i] = table[(int64_t)H * (2 * L - 1) + i];
+  }
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (query lr, group lq) holds d = 32 half + 8 lq .. +7 ----
+  const int q_row = qt * 64 + wave * 16 + lr;
+  const bool q_ok = q_row < L;
+  bf16x8 qh[2], qm[2], ql[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 u = (f32x4){0.f, 0.f, 0.f, 0.f}, v = u;
+    if (q_ok) {
+      const float* p = Qp + (rowbase + q_row) * ldqkv + half * 32 + lq * 8;
+      const float4 a = *reinterpret_cast<const float4*>(p);
+      const float4 c = *reinterpret_cast<const float4*>(p + 4);
+      u = (f32x4){a.x * scale, a.y * scale, a.z * scale, a.w * scale};
+      v = (f32x4){c.x * scale, c.y * scale, c.z * scale, c.w * scale};
+    }
+    split8(u, v, qh[half], qm[half], ql[half]);
+  }
+  float g = 0.f;
+  if constexpr (BIAS) {
+    if (q_ok) g = gate[(rowbase + q_row) * Htot + H];
+  }
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 O[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) O[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging assignment ----
+  // K: item = tid + 256 i -> (key = item / 8, 8-d chunk = item % 8): 32 contiguous bytes per thread
+  // V: item = tid + 256 i -> (d = item % 64, group = item / 64 = 4 mm + lq'): the 8 keys
+  //    (2 mm + e/4) * 16 + 4 lq' + e%4 that lane group lq' feeds to P.V MFMA mm
+  const int nkt = (L + 63) / 64;
+  f32x4 rk[2][2], rv[2][2];
+  auto prefetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int item = tid + 256 * i;
+      const int key = kt * 64 + (item >> 3);
+      if (key < L) {
+        const float* p = Kp + (rowbase + key) * ldqkv + (item & 7) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 c = *reinterpret_cast<const float4*>(p + 4);
+        rk[i][0] = (f32x4){a.x, a.y, a.z, a.w};
+        rk[i][1] = (f32x4){c.x, c.y, c.z, c.w};
+      } else {
+        rk[i][0] = rk[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      const int d = item & 63, grp = item >> 6, mm = grp >> 2, lqk = grp & 3;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key_e = kt * 64 + (2 * mm + (e >> 2)) * 16 + lqk * 4 + (e & 3);
+        const float x = key_e < L ? Vp[(rowbase + key_e) * ldqkv + d] : 0.f;
+        if (e < 4) rv[i][0][e] = x;
+        else rv[i][1][e - 4] = x;
+      }
+    }
+  };
+
+  prefetch(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int item = tid + 256 * i;
+      bf16x8 ph, pm, pl;
+      {
+        const int key = item >> 3, slot = item & 7;
+        const int off = key * 128 + ((slot ^ ((key >> 1) & 7)) << 4);
+        split8(rk[i][0], rk[i][1], ph, pm, pl);
+        *reinterpret_cast<bf16x8*>(sK + off) = ph;
+        *reinterpret_cast<bf16x8*>(sK + ATT_PLANE + off) = pm;
+        *reinterpret_cast<bf16x8*>(sK + 2 * ATT_PLANE + off) = pl;
+      }
+      {
+        const int d = item & 63, grp = item >> 6;
+        const int off = d * 128 + ((grp ^ ((d >> 1) & 7)) << 4);
+        split8(rv[i][0], rv[i][1], ph, pm, pl);
+        *reinterpret_cast<bf16x8*>(sV + off) = ph;
+        *reinterpret_cast<bf16x8*>(sV + ATT_PLANE + off) = pm;
+        *reinterpret_cast<bf16x8*>(sV + 2 * ATT_PLANE + off) = pl;
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) prefetch(kt + 1);
+
+    // ---- S^T = K Q^T : 4 key blocks x 2 halves of d, six products each ----
+    f32x4 s[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      bf16x8 kh[4], km[4], kl[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int key = kb * 16 + lr;
+        const int off = key * 128 + (((half * 4 + lq) ^ ((key >> 1) & 7)) << 4);
+        kh[kb] = *reinterpret_cast<const bf16x8*>(sK + off);
+        km[kb] = *reinterpret_cast<const bf16x8*>(sK + ATT_PLANE + off);
+        kl[kb] = *reinterpret_cast<const bf16x8*>(sK + 2 * ATT_PLANE + off);
+      }
+      // product-major order: 4 independent accumulators between dependent MFMAs
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[kb], qh[half], s[kb], 0, 0, 0);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kb], ql[half], s[kb], 0, 0, 0);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km[kb], qm[half], s[kb], 0, 0, 0);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km[kb], qh[half], s[kb], 0, 0, 0);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kb], qm[half], s[kb], 0, 0, 0);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kb], qh[half], s[kb], 0, 0, 0);
+    }
+
+    // ---- bias, mask, online softmax (lane owns query q_row; keys kb*16 + lq*4 + rg) ----
+    const int key0 = kt * 64;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int key = key0 + kb * 16 + lq * 4 + rg;
+        float v = s[kb][rg];
+        if constexpr (BIAS) {
+          if (q_ok && key < L) v += g * sT[key - q_row + L - 1];
+        }
+        if (key >= L) v = -INFINITY;
+        s[kb][rg] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float p = expf(s[kb][rg] - m_new);
+        s[kb][rg] = p;
+        psum += p;
+      }
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+
+    // O rows are query (lq*4 + rg): fetch that query's alpha from lane (lq*4 + rg)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float a = __shfl(alpha, lq * 4 + rg, 64);
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) O[dblk][rg] *= a;
+    }
+
+    // ---- O += P V : P fragment of MFMA mm = {s[2mm], s[2mm+1]} (the order V was staged in) ----
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+      bf16x8 ph, pm, pl;
+      split8(s[2 * mm], s[2 * mm + 1], ph, pm, pl);
+      bf16x8 vh[4], vm[4], vl[4];
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) {
+        const int d = dblk * 16 + lr;
+        const int off = d * 128 + (((mm * 4 + lq) ^ ((d >> 1) & 7)) << 4);
+        vh[dblk] = *reinterpret_cast<const bf16x8*>(sV + off);
+        vm[dblk] = *reinterpret_cast<const bf16x8*>(sV + ATT_PLANE + off);
+        vl[dblk] = *reinterpret_cast<const bf16x8*>(sV + 2 * ATT_PLANE + off);
+      }
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[dblk], O[dblk], 0, 0, 0);
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[dblk], O[dblk], 0, 0, 0);
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, vm[dblk], O[dblk], 0, 0, 0);
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, vh[dblk], O[dblk], 0, 0, 0);
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vm[dblk], O[dblk], 0, 0, 0);
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[dblk], O[dblk], 0, 0, 0);
+    }
+  }
+
+  // ---- normalise and store: lane holds O[q = lq*4 + rg][d = dblk*16 + lr] ----
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const float lt = __shfl(l_tot, lq * 4 + rg, 64);
+    const int q = qt * 64 + wave * 16 + lq * 4 + rg;
+    if (q < L) {
+      const float inv = 1.0f / lt;
+      float* op = out + (rowbase + q) * ldo + j * 64 + lr;
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk) op[dblk * 16] = O[dblk][rg] * inv;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_attention_split(const float* qkv, float* out, const float* gate, const float* table,
+                           const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
+                           float scale, hipStream_t s) {
+  if (h <= 0 || B <= 0 || L <= 0) return DZN_OK;
+  if ((ldqkv & 3) || (reinterpret_cast<uintptr_t>(qkv) & 15)) return DZN_E_INVALID;
+  const bool bias = gate && table && head_idx;
+  const size_t lds = 6 * ATT_PLANE + (bias ? (2 * L - 1) : 0) * sizeof(float);
+  if (lds > 160 * 1024) return DZN_E_INVALID;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid((L + 63) / 64, h, B);
+  const int pid = prof_begin(s, bias ? "attention_relpos_f32s" : "attention_f32s",
+                             4.0 * B * h * (double)L * L * 64.0, 0.0);
+  if (bias)
+    hipLaunchKernelGGL(attn_split_kernel<true>, grid, dim3(256), lds, s, qkv, out, gate, table, head_idx, B, L, h,
+                       Htot, ldqkv, ldo, scale);
+  else
+    hipLaunchKernelGGL(attn_split_kernel<false>, grid, dim3(256), lds, s, qkv, out, gate, table, head_idx, B, L, h,
+                       Htot, ldqkv, ldo, scale);
+  prof_end(pid, s);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}

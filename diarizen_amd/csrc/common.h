@@ -96,6 +96,9 @@ int launch_gate_t(const void* y, int y_bf16, int64_t ldy, const float* Wg, const
 int launch_attention_t(const float* qkv, void* out, int out_bf16, const float* gate, const float* table,
                        const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
                        float scale, hipStream_t s);
+int launch_attention_split(const float* qkv, float* out, const float* gate, const float* table,
+                           const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
+                           float scale, hipStream_t s);  // attention_split.hip (DZN_PREC_F32_SPLIT)
 int launch_attention(const float* qkv, float* out, const float* gate, const float* table,
                      const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
                      float scale, int precision, hipStream_t s);

@@ -902,9 +902,14 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       const int hd = Ly.h * 64;
       dzn_gemm_desc d = gd(h, yin, Ly.qkv, h->qkv, ML, D, 3 * hd);
       gemm(d, y16, false, "qkv");
-      chk(launch_attention_t(h->qkv, h->ao, lp, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd,
-                             hd, 0.125f, st),
-          "attention");
+      if (c.precision == DZN_PREC_F32_SPLIT)
+        chk(launch_attention_split(h->qkv, h->ao, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd, hd,
+                                   0.125f, st),
+            "attention");
+      else
+        chk(launch_attention_t(h->qkv, h->ao, lp, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd,
+                               hd, 0.125f, st),
+            "attention");
       dzn_gemm_desc o = gd(h, h->ao, Ly.out, h->x, ML, hd, D);
       o.R = h->x;
       gemm(o, lp, false, "out_proj");
@@ -979,9 +984,14 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     {
       dzn_gemm_desc q = gd(h, h->ht, Cl.qkv, h->hmid, ML, A, 3 * A);
       gemm(q, lp, false, "conf qkv");
-      chk(launch_attention_t(h->hmid, h->hv, lp, nullptr, nullptr, nullptr, B, L, c.conf_heads, 0, 3 * A, A,
-                             0.125f, st),
-          "conf attention");
+      if (c.precision == DZN_PREC_F32_SPLIT)
+        chk(launch_attention_split(h->hmid, h->hv, nullptr, nullptr, nullptr, B, L, c.conf_heads, 0, 3 * A, A,
+                                   0.125f, st),
+            "conf attention");
+      else
+        chk(launch_attention_t(h->hmid, h->hv, lp, nullptr, nullptr, nullptr, B, L, c.conf_heads, 0, 3 * A, A,
+                               0.125f, st),
+            "conf attention");
       dzn_gemm_desc o = gd(h, h->hv, Cl.o, h->hz, ML, A, A);
       o.R = h->hz;
       gemm(o, lp, false, "conf out");

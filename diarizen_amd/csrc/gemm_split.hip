@@ -28,66 +28,11 @@
 
 #include "common.h"
 #include "gemm_epilogue.h"
+#include "split.h"
 
 namespace {
 
 __device__ __forceinline__ int wswz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// split 8 fp32 values (two 16-B LDS slots) into the three bf16 fragments; written on pairs so
-// that it compiles to 9 VALU instructions per pair: v_cvt_pk_bf16_f32, v_lshlrev, v_and,
-// v_pk_add_f32 (x - hi), v_cvt_pk, v_lshlrev, v_and, v_pk_add_f32, v_cvt_pk
-__device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-  u32x4 H, M, L;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    f32x2 x;
-    x[0] = p < 2 ? u[2 * p] : v[2 * p - 4];
-    x[1] = p < 2 ? u[2 * p + 1] : v[2 * p - 3];
-    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
-    f32x2 hf;
-    hf[0] = __uint_as_float(hp << 16);
-    hf[1] = __uint_as_float(hp & 0xffff0000u);
-    const f32x2 r1 = x - hf;
-    const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-    f32x2 mf;
-    mf[0] = __uint_as_float(mp << 16);
-    mf[1] = __uint_as_float(mp & 0xffff0000u);
-    const f32x2 r2 = r1 - mf;
-    H[p] = hp;
-    M[p] = mp;
-    L[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-  }
-  hi = __builtin_bit_cast(bf16x8, H);
-  mid = __builtin_bit_cast(bf16x8, M);
-  lo = __builtin_bit_cast(bf16x8, L);
-}
-
-// truncation variant (hi = top 16 bits; remainders exact): and / v_pk_add / v_perm only
-__device__ __forceinline__ void split8_trunc(const f32x4& u, const f32x4& v, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-  u32x4 H, M, L;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    f32x2 x;
-    x[0] = p < 2 ? u[2 * p] : v[2 * p - 4];
-    x[1] = p < 2 ? u[2 * p + 1] : v[2 * p - 3];
-    const unsigned h0 = __float_as_uint(x[0]) & 0xffff0000u, h1 = __float_as_uint(x[1]) & 0xffff0000u;
-    f32x2 hf; hf[0] = __uint_as_float(h0); hf[1] = __uint_as_float(h1);
-    const f32x2 r = x - hf;
-    const unsigned m0 = __float_as_uint(r[0]) & 0xffff0000u, m1 = __float_as_uint(r[1]) & 0xffff0000u;
-    f32x2 mf; mf[0] = __uint_as_float(m0); mf[1] = __uint_as_float(m1);
-    const f32x2 q = r - mf;
-    H[p] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-    M[p] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-    L[p] = __builtin_amdgcn_perm(__float_as_uint(q[1]), __float_as_uint(q[0]), 0x07060302u);
-  }
-  hi = __builtin_bit_cast(bf16x8, H);
-  mid = __builtin_bit_cast(bf16x8, M);
-  lo = __builtin_bit_cast(bf16x8, L);
-}
 
 // s_waitcnt vmcnt(N) lgkmcnt(0), expcnt left at its maximum (gfx9 encoding: vmcnt = [3:0] + [15:14])
 template <int N>
@@ -247,8 +192,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
   auto split = [&](const f32x4 (&a)[2], bf16x8& ah, bf16x8& am, bf16x8& al) {
     if constexpr (DBG == 3) {
       ah = __builtin_bit_cast(bf16x8, a[0]); am = __builtin_bit_cast(bf16x8, a[1]); al = ah;
-    } else if constexpr (DBG == 4) {
-      split8_trunc(a[0], a[1], ah, am, al);
     } else {
       split8(a[0], a[1], ah, am, al);
     }
@@ -368,7 +311,6 @@ int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s) {
     if (!strcmp(force, "128x128s2")) return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
     if (!strcmp(force, "128x128s2d1")) return launch_split_cfg<128, 128, 2, 2, 2, 1>(d, s);
     if (!strcmp(force, "128x128s2d3")) return launch_split_cfg<128, 128, 2, 2, 2, 3>(d, s);
-    if (!strcmp(force, "128x128s2d4")) return launch_split_cfg<128, 128, 2, 2, 2, 4>(d, s);
     if (!strcmp(force, "128x128s3")) return launch_split_cfg<128, 128, 2, 2, 3>(d, s);
     if (!strcmp(force, "128x128s4")) return launch_split_cfg<128, 128, 2, 2, 4>(d, s);
     if (!strcmp(force, "128x128w8s2")) return launch_split_cfg<128, 128, 4, 2, 2>(d, s);

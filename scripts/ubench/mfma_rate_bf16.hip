@@ -35,6 +35,30 @@ __device__ __forceinline__ void split_trunc(const f32x4& u, const f32x4& v, bf16
   hi = __builtin_bit_cast(bf16x8, H); mid = __builtin_bit_cast(bf16x8, M); lo = __builtin_bit_cast(bf16x8, L);
 }
 
+// RNE split on pairs, the two exact subtractions as scalar v_sub_f32 (inline asm keeps the SLP
+// vectoriser from fusing them into v_pk_add_f32, which is expensive next to MFMAs)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vsub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <bool ASM>
+__device__ __forceinline__ void split_pairs(const f32x4& u, const f32x4& v, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  u32x4 H, M, L;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 x; x[0] = p < 2 ? u[2 * p] : v[2 * p - 4]; x[1] = p < 2 ? u[2 * p + 1] : v[2 * p - 3];
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+    f32x2 r1;
+    if (ASM) { r1[0] = vsub(x[0], __uint_as_float(hp << 16)); r1[1] = vsub(x[1], __uint_as_float(hp & 0xffff0000u)); }
+    else { f32x2 hf; hf[0] = __uint_as_float(hp << 16); hf[1] = __uint_as_float(hp & 0xffff0000u); r1 = x - hf; }
+    const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+    f32x2 r2;
+    if (ASM) { r2[0] = vsub(r1[0], __uint_as_float(mp << 16)); r2[1] = vsub(r1[1], __uint_as_float(mp & 0xffff0000u)); }
+    else { f32x2 mf; mf[0] = __uint_as_float(mp << 16); mf[1] = __uint_as_float(mp & 0xffff0000u); r2 = r1 - mf; }
+    H[p] = hp; M[p] = mp; L[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+  }
+  hi = __builtin_bit_cast(bf16x8, H); mid = __builtin_bit_cast(bf16x8, M); lo = __builtin_bit_cast(bf16x8, L);
+}
+
 // MODE 0: MFMA only (96 per iteration, 16 accumulators); 1: + RNE split of 4 A fragments; 2: + truncation split
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters) {
@@ -55,6 +79,8 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters)
     for (int i = 0; i < 4; ++i) {
       if constexpr (MODE == 1) { split_rne(au[i], av[i], ah[i], am[i], al[i]); }
       if constexpr (MODE == 2) { split_trunc(au[i], av[i], ah[i], am[i], al[i]); }
+      if constexpr (MODE == 3) { split_pairs<false>(au[i], av[i], ah[i], am[i], al[i]); }
+      if constexpr (MODE == 4) { split_pairs<true>(au[i], av[i], ah[i], am[i], al[i]); }
       if constexpr (MODE >= 1) {   // keep the inputs live / changing so the split is not hoisted
         au[i][0] = __uint_as_float(__float_as_uint(au[i][0]) ^ (unsigned)it);
         asm volatile("" : "+v"(au[i]), "+v"(av[i]));
@@ -107,6 +133,8 @@ int main(int argc, char** argv) {
     run<0>("mfma only", out, in, blocks);
     run<1>("+ RNE split (cvt_pk_bf16)", out, in, blocks);
     run<2>("+ truncation split (and/perm)", out, in, blocks);
+    run<3>("+ RNE pairs (v_pk_add_f32)", out, in, blocks);
+    run<4>("+ RNE pairs (v_sub_f32 asm)", out, in, blocks);
   }
   return 0;
 }

@@ -183,20 +183,22 @@ def _attn_ref(q, k, v, bias=None):
     return torch.softmax(s, -1) @ v.double()
 
 
+@pytest.mark.parametrize("prec", F32_MODES)
 @pytest.mark.parametrize("L", [64, 99, 399])
-def test_attention_nobias(built_lib, gpu, L):
+def test_attention_nobias(built_lib, gpu, L, prec):
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(L)
     B, h = 2, 4
     qkv = torch.randn(B * L, 3 * h * 64, generator=g)
     q, k, v = [qkv[:, i * h * 64:(i + 1) * h * 64].view(B, L, h, 64).permute(0, 2, 1, 3) for i in range(3)]
     ref = _attn_ref(q, k, v).permute(0, 2, 1, 3).reshape(B * L, h * 64)
-    out = ops.attention(qkv.to(gpu), B, L, h)
+    out = ops.attention(qkv.to(gpu), B, L, h, precision=prec)
     assert (out.cpu().double() - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("prec", F32_MODES)
 @pytest.mark.parametrize("L", [99, 399])
-def test_attention_gated_relpos(built_lib, gpu, L):
+def test_attention_gated_relpos(built_lib, gpu, L, prec):
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(L + 1)
     B, Htot = 2, 16
@@ -212,7 +214,7 @@ def test_attention_gated_relpos(built_lib, gpu, L):
     bias = bias[:, heads]
     ref = _attn_ref(q, k, v, bias).permute(0, 2, 1, 3).reshape(B * L, h * 64)
     out = ops.attention(qkv.to(gpu), B, L, h, gate=gate.to(gpu), table=table.to(gpu),
-                        head_idx=torch.tensor(heads, dtype=torch.int32, device=gpu), Htot=Htot)
+                        head_idx=torch.tensor(heads, dtype=torch.int32, device=gpu), Htot=Htot, precision=prec)
     assert (out.cpu().double() - ref).abs().max() < 2e-5
 
 
