@@ -45,6 +45,10 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const float* __restrict
     for (int i = tid; i < 2 * L - 1; i += 256) sT[i] = table[(int64_t)H * (2 * L - 1) + i];
   }
 
+  // scores are kept in the log2 domain (q and the bias gate carry a factor log2 e), so the softmax
+  // exponentials are bare v_exp_f32: exp(s - m) == exp2(s log2e - m log2e)
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float qs = scale * LOG2E;
   // ---- Q fragments (B operand of S^T = K Q^T): lane (query lr, group lq) holds d = 32 half + 8 lq .. +7 ----
   const int q_row = qt * 64 + wave * 16 + lr;
   const bool q_ok = q_row < L;
@@ -56,14 +60,14 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const float* __restrict
       const float* p = Qp + (rowbase + q_row) * ldqkv + half * 32 + lq * 8;
       const float4 a = *reinterpret_cast<const float4*>(p);
       const float4 c = *reinterpret_cast<const float4*>(p + 4);
-      u = (f32x4){a.x * scale, a.y * scale, a.z * scale, a.w * scale};
-      v = (f32x4){c.x * scale, c.y * scale, c.z * scale, c.w * scale};
+      u = (f32x4){a.x * qs, a.y * qs, a.z * qs, a.w * qs};
+      v = (f32x4){c.x * qs, c.y * qs, c.z * qs, c.w * qs};
     }
     split8(u, v, qh[half], qm[half], ql[half]);
   }
   float g = 0.f;
   if constexpr (BIAS) {
-    if (q_ok) g = gate[(rowbase + q_row) * Htot + H];
+    if (q_ok) g = gate[(rowbase + q_row) * Htot + H] * LOG2E;
   }
 
   float m_run = -INFINITY, l_run = 0.f;
@@ -72,30 +76,39 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const float* __restrict
   for (int i = 0; i < 4; ++i) O[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- staging assignment ----
-  // K: item = tid + 256 i -> (key = item / 8, 8-d chunk = item % 8): 32 contiguous bytes per thread
-  // V: item = tid + 256 i -> (d = item % 64, group = item / 64 = 4 mm + lq'): the 8 keys
-  //    (2 mm + e/4) * 16 + 4 lq' + e%4 that lane group lq' feeds to P.V MFMA mm
+  // K: item = tid + 256 i -> (key = tid / 8 + 32 i, 8-d chunk = tid % 8): 32 contiguous bytes per thread
+  // V: item = tid + 256 i -> (d = tid % 64, group = wave + 4 i, i.e. MFMA mm = i, lane group lq' = wave):
+  //    the 8 keys (2 mm + e/4) * 16 + 4 lq' + e%4 that lane group lq' feeds to P.V MFMA mm.
+  // Rows past L are clamped to row L-1: their scores are masked to -inf (p = 0), so any finite data do.
   const int nkt = (L + 63) / 64;
+  const int koff = (tid >> 3) * ldqkv + (tid & 7) * 8;   // + (64 kt + 32 i) ldqkv
+  const int voff = wave * 4 * ldqkv + (tid & 63);        // + (64 kt + const(i, e)) ldqkv
   f32x4 rk[2][2], rv[2][2];
   auto prefetch = [&](int kt) {
+    const int64_t trow = rowbase + kt * 64;               // wave-uniform
+    const bool full = kt * 64 + 64 <= L;
+    const float* kt_base = Kp + trow * ldqkv;
+    const float* vt_base = Vp + trow * ldqkv;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int item = tid + 256 * i;
-      const int key = kt * 64 + (item >> 3);
-      if (key < L) {
-        const float* p = Kp + (rowbase + key) * ldqkv + (item & 7) * 8;
-        const float4 a = *reinterpret_cast<const float4*>(p);
-        const float4 c = *reinterpret_cast<const float4*>(p + 4);
-        rk[i][0] = (f32x4){a.x, a.y, a.z, a.w};
-        rk[i][1] = (f32x4){c.x, c.y, c.z, c.w};
-      } else {
-        rk[i][0] = rk[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int ko = koff + 32 * i * ldqkv;
+      if (!full) {
+        const int key = (tid >> 3) + 32 * i;
+        if (kt * 64 + key >= L) ko += (L - 1 - kt * 64 - key) * ldqkv;
       }
-      const int d = item & 63, grp = item >> 6, mm = grp >> 2, lqk = grp & 3;
+      const float4 a = *reinterpret_cast<const float4*>(kt_base + ko);
+      const float4 c = *reinterpret_cast<const float4*>(kt_base + ko + 4);
+      rk[i][0] = (f32x4){a.x, a.y, a.z, a.w};
+      rk[i][1] = (f32x4){c.x, c.y, c.z, c.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int key_e = kt * 64 + (2 * mm + (e >> 2)) * 16 + lqk * 4 + (e & 3);
-        const float x = key_e < L ? Vp[(rowbase + key_e) * ldqkv + d] : 0.f;
+        const int ce = (2 * i + (e >> 2)) * 16 + (e & 3);   // compile-time part of the key index
+        int vo = voff + ce * ldqkv;
+        if (!full) {
+          const int key = ce + wave * 4;
+          if (kt * 64 + key >= L) vo += (L - 1 - kt * 64 - key) * ldqkv;
+        }
+        const float x = vt_base[vo];
         if (e < 4) rv[i][0][e] = x;
         else rv[i][1][e - 4] = x;
       }
@@ -159,33 +172,42 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const float* __restrict
       for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kb], qh[half], s[kb], 0, 0, 0);
     }
 
-    // ---- bias, mask, online softmax (lane owns query q_row; keys kb*16 + lq*4 + rg) ----
+    // ---- bias, mask (last tile only), online softmax; lane owns query q_row, keys kb*16 + lq*4 + rg ----
     const int key0 = kt * 64;
-    float mx = -INFINITY;
+    if constexpr (BIAS) {
+      const float* tp = sT + (key0 + lq * 4 - q_row + L - 1);
+      if (q_ok) {
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int key = key0 + kb * 16 + lq * 4 + rg;
-        float v = s[kb][rg];
-        if constexpr (BIAS) {
-          if (q_ok && key < L) v += g * sT[key - q_row + L - 1];
-        }
-        if (key >= L) v = -INFINITY;
-        s[kb][rg] = v;
-        mx = fmaxf(mx, v);
+          for (int rg = 0; rg < 4; ++rg) {
+            const int key = key0 + kb * 16 + lq * 4 + rg;
+            if (key < L) s[kb][rg] = fmaf(g, tp[kb * 16 + rg], s[kb][rg]);
+          }
       }
     }
+    if (key0 + 64 > L) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          if (key0 + kb * 16 + lq * 4 + rg >= L) s[kb][rg] = -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) mx = fmaxf(mx, s[kb][rg]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const float p = expf(s[kb][rg] - m_new);
+        const float p = __builtin_amdgcn_exp2f(s[kb][rg] - m_new);
         s[kb][rg] = p;
         psum += p;
       }
