@@ -31,7 +31,12 @@ if str(ROOT) not in sys.path:
 
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+# MI355X dense MFMA peaks (MI355X_MICROARCH.md).  "f32s" contractions run fp32 arithmetic as 6 bf16 MFMA
+# products per block (exact 3-way operand split, csrc/gemm_split.hip): their ALGORITHMIC peak is bf16 / 6.
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32s": 2500.0 / 6.0}
+DTYPE_NOTE = {"f32": "f32 (fp32 MFMA v_mfma_f32_16x16x4_f32)",
+              "f32s": "f32 (operands split exactly into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate)",
+              "bf16": "bf16 (bf16 MFMA operands, fp32 accumulate / residual stream / norms)"}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -64,15 +69,16 @@ def pmc_traffic(kernel_class: str, args):
     WRITE_SIZE on this same command, gfx950 correction applied; scripts/pmc_traffic.py).  bench.py
     cannot run rocprofv3 on itself, so the figure is read from profiles/ and only when the workload
     matches the one the passes were taken on."""
-    path = ROOT / "profiles" / f"r1_pmc_traffic_30min_b{args.batch}.json"
-    if not path.exists() or args.minutes != 30.0 or args.precision != "f32" \
-            or args.model != "wavlm_large_s80_md" or args.window != 8.0:
+    path = ROOT / "profiles" / f"r1_pmc_traffic_{args.precision}_30min_b{args.batch}.json"
+    if not path.exists() or args.minutes != 30.0 or args.model != "wavlm_large_s80_md" or args.window != 8.0:
         return None
     table = json.loads(path.read_text())
     key = None
-    if kernel_class.startswith("gemm_f32_"):
-        bm, bn = kernel_class[len("gemm_f32_"):].split("x")
-        key = next((k for k in table if k.startswith(f"gemm_glds_kernel<{bm}, {bn},")), None)
+    for prefix, kern in (("gemm_f32s_", "gemm_split_kernel"), ("gemm_f32_", "gemm_glds_kernel")):
+        if kernel_class.startswith(prefix):
+            bm, bn = kernel_class[len(prefix):].split("x")
+            key = next((k for k in table if k.startswith(f"{kern}<{bm}, {bn},")), None)
+            break
     return table[key]["hbm_bytes_per_launch"] if key else None
 
 
@@ -102,8 +108,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default=os.environ.get("DZN_BENCH_PRECISION", "f32"),
-                    choices=["f32", "bf16", "f32s"])
+    ap.add_argument("--precision", default=os.environ.get("DZN_BENCH_PRECISION", "f32s"),
+                    choices=["f32s", "f32", "bf16"],
+                    help="f32s (default) and f32 are both fp32 arithmetic held to the strict parity tolerance; "
+                         "f32 runs the contractions on the fp32 MFMA instead of the split bf16 products")
     ap.add_argument("--minutes", type=float, default=30.0)
     ap.add_argument("--window", type=float, default=8.0)
     ap.add_argument("--batch", type=int, default=256)
@@ -113,6 +121,7 @@ def main():
                          "--batch 32 --stage seg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra fp32-MFMA-mode step reported beside f32s")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,15 +216,19 @@ def main():
                 kernels.append(e)
             top = max(prof, key=lambda p: p["ms"])
             if top["flops"] > 0:
-                prec = "bf16" if "bf16" in top["name"] else "f32"
+                prec = "bf16" if "bf16" in top["name"] else ("f32s" if "f32s" in top["name"] else "f32")
                 ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
                 roofline = {"kernel": top["name"], "bound": "mfma", "achieved": round(ach, 2),
-                            "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                            "peak": round(PEAK_TFLOPS[prec], 1), "unit": "TFLOP/s",
                             "frac": round(ach / PEAK_TFLOPS[prec], 4),
                             "traffic": pmc_traffic(top["name"], args),
                             "launches": top["launches"],
                             "avg_launch_ms": round(top["ms"] / top["launches"], 4),
                             "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 3)}
+                if prec == "f32s":
+                    roofline["note"] = ("achieved = algorithmic fp32 flops / s; every 16x16x32 block costs 6 bf16 "
+                                        "MFMAs, so peak = bf16 dense peak 2500 / 6; executed MFMA rate = 6 x achieved")
+                    roofline["executed_tflops"] = round(6 * ach, 1)
             else:
                 ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
                 roofline = {"kernel": top["name"], "bound": "hbm", "achieved": round(ach, 1),
@@ -227,7 +240,7 @@ def main():
             "value": round(value, 2), "unit": "audio-seconds/s", "rtf": round(1.0 / value, 6),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
             "config": {"workload": f"{args.model} hot path ({'segmentation + masks + ResNet34 embeddings' if full else 'segmentation only'}), "
                                    f"{args.minutes:g} min synthetic 16 kHz mono per GPU, window "
                                    f"{args.window:g} s, step {0.1 * args.window:g} s, {n_windows} windows, "
@@ -238,6 +251,21 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        if args.precision == "f32s" and world == 1 and not args.no_alt:
+            # the same workload with the contractions on the fp32 MFMA (one extra untimed-warmup + timed step)
+            eng2 = Engine(cfg, sd, RESNET34, esd, max_batch=args.batch, max_samples=window, precision="f32",
+                          device=dev)
+            r2 = WindowRunner(eng2, args.window, 0.1, args.batch)
+            for timed in (False, True):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                res = r2.run(wave, with_embeddings=full)
+                _ = (res.segmentations.cpu(), res.embeddings.cpu()) if full else res.segmentations.cpu()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+            out["fp32_mfma_mode"] = {"value": round(audio_s / dt2, 2), "unit": "audio-seconds/s",
+                                     "ms_per_step": round(dt2 * 1e3, 2), "steps": 1,
+                                     "note": "--precision f32: same workload, contractions on v_mfma_f32_16x16x4_f32"}
         if not args.no_cpu_baseline and world == 1 and full:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, esd, window, 0.1 * args.window)
         print(json.dumps(out))

@@ -122,6 +122,8 @@ struct dzn_handle {
   uint8_t* mapping = nullptr;
   // rel-pos table cache
   int table_L = -1;
+  int pos_L = -1;               // geometry baked into pos_rowoff
+  int32_t* pos_rowoff = nullptr;  // row m = b*L + t of the positional conv -> element offset into xpad
   float* table = nullptr;
   // ---- segmentation: workspace ----
   int maxT[DZN_MAX_CONV]{};
@@ -764,6 +766,19 @@ void ln_t(const float* x, bool x16, int64_t ldx, float* y, bool y16, int64_t ldy
       "layernorm");
 }
 
+// positional conv rows: m = b*L + t reads xpad[b][t .. t+Kc) — one table for all batch sizes
+void ensure_pos_rowoff(H* h, int L, int Lp, hipStream_t st) {
+  if (L == h->pos_L) return;
+  HIPCHK(hipStreamSynchronize(st));
+  const int Bm = h->cfg.max_batch;
+  std::vector<int32_t> t((size_t)Bm * L);
+  for (int b = 0; b < Bm; ++b)
+    for (int i = 0; i < L; ++i) t[(size_t)b * L + i] = (int32_t)(((int64_t)b * Lp + i) * h->D);
+  if (!h->pos_rowoff) h->pos_rowoff = dalloc<int32_t>(h, (int64_t)Bm * h->maxL, false);
+  HIPCHK(hipMemcpy(h->pos_rowoff, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  h->pos_L = L;
+}
+
 void ensure_table(H* h, int L, hipStream_t st) {
   if (L == h->table_L) return;
   HIPCHK(hipStreamSynchronize(st));
@@ -860,21 +875,32 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     // keep this one contraction on fp32 activations (register-staged kernel converts on the fly)
     const bool pc16 = lp && (cg % 32 == 0);
     chk(launch_pad_rows(h->x, h->xpad, pc16, B, L, Lp, Kc / 2, D, st), "pad_rows");
-    dzn_gemm_desc d = gd(h, h->xpad, h->posconv, h->x, L, D, D);
+    // one contraction per channel group over ALL B*L rows (row-offset table into the padded copy), so
+    // the 128-row tiles are not padded per window (L = 399 would waste 22 % of every window's last tile)
+    const bool tabled = (int64_t)c.max_batch * Lp * D < (int64_t)1 << 31;
+    if (tabled) ensure_pos_rowoff(h, L, Lp, st);
+    dzn_gemm_desc d = gd(h, h->xpad, h->posconv, h->x, tabled ? ML : L, D, D);
     d.N = cg;
     d.kc = cg;
     d.ldk = D;
     d.act = DZN_ACT_GELU;
     d.R = h->x;
-    d.nz = B * G;
-    d.zdiv = G;
-    d.a_z0 = (int64_t)Lp * D;
     d.a_z1 = cg;
     d.w_z1 = (int64_t)cg * h->posconv.K;
-    d.c_z0 = (int64_t)L * D;
     d.c_z1 = cg;
     d.b_z1 = cg;
-    d.alg_flops = 2.0 * (double)L * cg * h->posconv.Kt;
+    if (tabled) {
+      d.a_rowoff = h->pos_rowoff;
+      d.nz = G;
+      d.zdiv = G;
+      d.alg_flops = 2.0 * (double)ML * cg * h->posconv.Kt;
+    } else {
+      d.nz = B * G;
+      d.zdiv = G;
+      d.a_z0 = (int64_t)Lp * D;
+      d.c_z0 = (int64_t)L * D;
+      d.alg_flops = 2.0 * (double)L * cg * h->posconv.Kt;
+    }
     gemm(d, pc16, false, "pos conv");
   }
   if (!c.layer_norm_first) ln_t(h->x, false, D, h->x, false, D, h->enc_ln, ML, D, 0, st);
