@@ -82,7 +82,7 @@ def pmc_traffic(kernel_class: str, args):
     return table[key]["hbm_bytes_per_launch"] if key else None
 
 
-def cpu_baseline(seg_cfg, sd, esd, window: int, step_s: float, budget_windows: int = 2):
+def cpu_baseline(seg_cfg, sd, esd, window: int, step_s: float, budget_windows: int = 8):
     """The oracle (CPU port of the reference arithmetic, oracle/) on a bounded sample: B windows
     through segmentation + the embedding stage AS THE REFERENCE EXECUTES IT (one ResNet pass per
     (window, local speaker), PA/pipelines/speaker_diarization.py:295-353)."""
