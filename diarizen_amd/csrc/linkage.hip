@@ -1,0 +1,239 @@
+// linkage.hip — centroid-linkage agglomerative clustering with the distance matrix resident in HBM
+// (row f1 of SURVEY.md §8f: host clustering scale-out).
+//
+// Replaces, for large inputs, the call
+//     scipy.cluster.hierarchy.linkage(embeddings, method="centroid", metric="euclidean")
+// of AgglomerativeClustering.cluster (PA/pipelines/clustering.py:407-416) and of the AHC
+// initialisation of VBxClustering (PA/pipelines/clustering.py:656-658).  scipy forms the
+// condensed n(n-1)/2 float64 distance matrix on the host and runs the generic O(n^2)..O(n^3)
+// nearest-neighbour algorithm single-threaded: 17 s at 2 h of audio (36 k embeddings), minutes and
+// 20 GB at 4 h — longer than the whole device stage on 8 GPUs.  Here:
+//   * D [n][n] float64 lives in HBM (41 GB at n = 72 k; 288 GB available), filled by a tiled
+//     pairwise-distance kernel (inactive columns / the diagonal hold +inf, so a row scan is a bare min);
+//   * the same greedy algorithm as scipy's fast_linkage runs on the device: per row a LOWER BOUND
+//     lb[z] of its minimum with a candidate neighbour nb[z]; each merge = one single-workgroup
+//     kernel (global argmin of lb, verify against D, rescan the row if the bound was stale, emit the
+//     dendrogram row) + one wide kernel (Lance-Williams centroid update of row / column `hi`,
+//     written in scipy's operation order in float64, bounds refreshed);
+//   * no host round trip inside the loop: 2(n-1) launches are queued back to back.
+// With no exact ties in the data the merge sequence — hence the dendrogram Z and every flat
+// clustering cut from it — equals scipy's (tests/test_ops_gpu.py compares Z and fcluster output).
+#include <math.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct MergeState {
+  int lo, hi, nlo, nhi, k;
+  double dist;
+};
+
+constexpr double DINF = __builtin_huge_val();
+
+// ---- pairwise euclidean distances, float64 accumulation: 64 x 64 tile per workgroup, j-tile >= i-tile ----
+__global__ __launch_bounds__(256) void pdist_kernel(const float* __restrict__ E, int n, int dim,
+                                                    double* __restrict__ D) {
+  __shared__ float sa[64][17], sb[64][17];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // thread -> rows ty*4.., cols tx*4..
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int k0 = 0; k0 < dim; k0 += 16) {
+    for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+      const int r = idx >> 4, c = idx & 15;
+      const int gi = bi * 64 + r, gj = bj * 64 + r, gk = k0 + c;
+      sa[r][c] = (gi < n && gk < dim) ? E[(int64_t)gi * dim + gk] : 0.f;
+      sb[r][c] = (gj < n && gk < dim) ? E[(int64_t)gj * dim + gk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = (double)sa[ty * 4 + a][c];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = (double)sb[tx * 4 + b][c];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double df = av[a] - bv[b];
+          acc[a][b] += df * df;
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = bi * 64 + ty * 4 + a, j = bj * 64 + tx * 4 + b;
+      if (i < n && j < n) {
+        const double d = i == j ? DINF : sqrt(acc[a][b]);
+        D[(int64_t)i * n + j] = d;
+        D[(int64_t)j * n + i] = d;
+      }
+    }
+}
+
+// block-wide argmin (lowest index on ties) of p[0..n); result valid in every thread
+__device__ __forceinline__ void block_argmin(const double* __restrict__ p, int n, double& val, int& idx,
+                                             double* sval, int* sidx) {
+  double v = DINF;
+  int id = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double x = p[i];
+    if (x < v) { v = x; id = i; }   // ascending i per thread: first occurrence kept
+  }
+  // wave reduction
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(id, o, 64);
+    if (ov < v || (ov == v && oi < id)) { v = ov; id = oi; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  __syncthreads();  // previous users of sval / sidx are done
+  if (lane == 0) { sval[wave] = v; sidx[wave] = id; }
+  __syncthreads();
+  v = sval[0];
+  id = sidx[0];
+  for (int w = 1; w < nw; ++w) {
+    const double ov = sval[w];
+    const int oi = sidx[w];
+    if (ov < v || (ov == v && oi < id)) { v = ov; id = oi; }
+  }
+  val = v;
+  idx = id;
+}
+
+// initial bounds: one workgroup per row
+__global__ __launch_bounds__(256) void init_rows_kernel(const double* __restrict__ D, int n, double* __restrict__ lb,
+                                                        int* __restrict__ nb) {
+  __shared__ double sval[4];
+  __shared__ int sidx[4];
+  const int z = blockIdx.x;
+  double v;
+  int id;
+  block_argmin(D + (int64_t)z * n, n, v, id, sval, sidx);
+  if (threadIdx.x == 0) { lb[z] = v; nb[z] = id; }
+}
+
+// one merge, part 1 (single workgroup): find the closest pair, emit the dendrogram row
+__global__ __launch_bounds__(1024) void select_kernel(double* __restrict__ D, int n, double* __restrict__ lb,
+                                                      int* __restrict__ nb, int* __restrict__ size,
+                                                      int* __restrict__ cid, double* __restrict__ Z,
+                                                      MergeState* __restrict__ st) {
+  __shared__ double sval[16];
+  __shared__ int sidx[16];
+  const int k = st->k;
+  int x, y;
+  double d;
+  for (int guard = 0; guard <= n; ++guard) {
+    block_argmin(lb, n, d, x, sval, sidx);
+    y = nb[x];
+    const bool exact = y >= 0 && D[(int64_t)x * n + y] == d;
+    if (exact) break;
+    double rv;
+    int ri;
+    block_argmin(D + (int64_t)x * n, n, rv, ri, sval, sidx);   // stale bound: rescan row x
+    __syncthreads();
+    if (threadIdx.x == 0) { lb[x] = rv; nb[x] = ri; }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int lo = x < y ? x : y, hi = x < y ? y : x;
+    const int nlo = size[lo], nhi = size[hi];
+    const int ia = cid[lo], ib = cid[hi];
+    Z[4 * k + 0] = (double)(ia < ib ? ia : ib);
+    Z[4 * k + 1] = (double)(ia < ib ? ib : ia);
+    Z[4 * k + 2] = d;
+    Z[4 * k + 3] = (double)(nlo + nhi);
+    size[lo] = 0;            // cluster lo is dropped ...
+    size[hi] = nlo + nhi;    // ... cluster hi becomes the union
+    cid[hi] = n + k;
+    lb[lo] = DINF;
+    lb[hi] = -1.0;           // below every distance: row hi is rescanned before it can be selected
+    nb[hi] = -1;
+    st->lo = lo; st->hi = hi; st->nlo = nlo; st->nhi = nhi; st->dist = d; st->k = k + 1;
+  }
+}
+
+// one merge, part 2: Lance-Williams centroid update of row / column hi, column lo retired
+__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ D, int n, double* __restrict__ lb,
+                                                     int* __restrict__ nb, const int* __restrict__ size,
+                                                     const MergeState* __restrict__ st) {
+  const int z = blockIdx.x * 256 + threadIdx.x;
+  if (z >= n) return;
+  const int lo = st->lo, hi = st->hi;
+  const int nz = size[z];
+  if (z == hi) { D[(int64_t)hi * n + lo] = DINF; return; }
+  if (nz == 0) return;      // inactive (includes z == lo)
+  const int sx = st->nlo, sy = st->nhi;
+  const double dxy = st->dist;
+  const double dxi = D[(int64_t)lo * n + z], dyi = D[(int64_t)hi * n + z];
+  // scipy _hierarchy_distance_update.pxi, _centroid(d_xi, d_yi, d_xy, size_x, size_y, size_i), same order
+  const double nd =
+      sqrt((((sx * dxi * dxi) + (sy * dyi * dyi)) - (sx * sy * dxy * dxy) / (sx + sy)) / (sx + sy));
+  D[(int64_t)hi * n + z] = nd;
+  D[(int64_t)z * n + hi] = nd;
+  D[(int64_t)z * n + lo] = DINF;
+  if (nb[z] == lo) nb[z] = hi;             // a guess; lb[z] stays a valid lower bound
+  if (nd < lb[z]) { lb[z] = nd; nb[z] = hi; }
+}
+
+#define LCHK(call)                                   \
+  do {                                               \
+    if ((call) != hipSuccess) { rc = DZN_E_HIP; goto done; } \
+  } while (0)
+
+}  // namespace
+
+extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, double* h_Z, int32_t device) {
+  if (!h_emb || !h_Z || n < 2 || dim < 1) return DZN_E_INVALID;
+  int rc = DZN_OK;
+  float* E = nullptr;
+  double *D = nullptr, *lb = nullptr, *Z = nullptr;
+  int *nb = nullptr, *size = nullptr, *cid = nullptr;
+  MergeState* st = nullptr;
+  std::vector<int> ones(n, 1), ids(n);
+  for (int i = 0; i < n; ++i) ids[i] = i;
+  MergeState st0{};
+  if (device >= 0) LCHK(hipSetDevice(device));
+  if (hipMalloc(&D, (size_t)n * n * sizeof(double)) != hipSuccess) { rc = DZN_E_NOMEM; goto done; }
+  LCHK(hipMalloc(&E, (size_t)n * dim * sizeof(float)));
+  LCHK(hipMalloc(&lb, (size_t)n * sizeof(double)));
+  LCHK(hipMalloc(&Z, (size_t)(n - 1) * 4 * sizeof(double)));
+  LCHK(hipMalloc(&nb, (size_t)n * sizeof(int)));
+  LCHK(hipMalloc(&size, (size_t)n * sizeof(int)));
+  LCHK(hipMalloc(&cid, (size_t)n * sizeof(int)));
+  LCHK(hipMalloc(&st, sizeof(MergeState)));
+  LCHK(hipMemcpy(E, h_emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice));
+  LCHK(hipMemcpy(size, ones.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  LCHK(hipMemcpy(cid, ids.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  LCHK(hipMemcpy(st, &st0, sizeof(MergeState), hipMemcpyHostToDevice));
+  {
+    const int tiles = (n + 63) / 64;
+    hipLaunchKernelGGL(pdist_kernel, dim3(tiles, tiles), dim3(256), 0, 0, E, n, dim, D);
+    hipLaunchKernelGGL(init_rows_kernel, dim3(n), dim3(256), 0, 0, D, n, lb, nb);
+    const int ug = (n + 255) / 256;
+    for (int k = 0; k < n - 1; ++k) {
+      hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, 0, D, n, lb, nb, size, cid, Z, st);
+      hipLaunchKernelGGL(update_kernel, dim3(ug), dim3(256), 0, 0, D, n, lb, nb, size, st);
+    }
+  }
+  LCHK(hipGetLastError());
+  LCHK(hipMemcpy(h_Z, Z, (size_t)(n - 1) * 4 * sizeof(double), hipMemcpyDeviceToHost));
+done:
+  (void)hipFree(D); (void)hipFree(E); (void)hipFree(lb); (void)hipFree(Z);
+  (void)hipFree(nb); (void)hipFree(size); (void)hipFree(cid); (void)hipFree(st);
+  return rc;
+}

@@ -81,6 +81,19 @@ def split_weights(W):
     return out
 
 
+def linkage_centroid(emb, device: int = -1):
+    """scipy.cluster.hierarchy.linkage(emb, "centroid", "euclidean") on the device (csrc/linkage.hip):
+    emb = host float32 [n, dim] (numpy), returns the dendrogram float64 [n - 1, 4]."""
+    import numpy as np
+    lib = _lib.load()
+    e = np.ascontiguousarray(emb, dtype=np.float32)
+    n, dim = e.shape
+    Z = np.empty((n - 1, 4), dtype=np.float64)
+    check(lib.dzn_linkage_centroid(e.ctypes.data_as(C.c_void_p), n, dim, Z.ctypes.data_as(C.c_void_p), device),
+          what="dzn_linkage_centroid")
+    return Z
+
+
 def layernorm(x, gamma, beta, C_true=None, eps=1e-5, gelu=False, out=None):
     lib = _lib.load()
     rows, ld = x.shape[0], x.stride(0)

@@ -180,6 +180,17 @@ const char* dzn_last_error(const dzn_handle* h); /* h may be NULL: last create e
 int dzn_destroy(dzn_handle* h);
 const char* dzn_version(void);
 
+/*
+ * Host-clustering accelerator.  Drop-in for
+ *     scipy.cluster.hierarchy.linkage(emb, method="centroid", metric="euclidean")
+ * as called by AgglomerativeClustering.cluster (PA/pipelines/clustering.py:407-416) and by the AHC
+ * initialisation of VBxClustering (PA/pipelines/clustering.py:656-658): h_emb is a HOST float32
+ * [n, dim] matrix (rows already unit-normalised by the caller, as in the reference), h_Z receives the
+ * scipy dendrogram [n-1, 4] float64 (ids, ids, distance, size).  The n x n float64 distance matrix
+ * lives in HBM (8 n^2 bytes -> DZN_E_NOMEM when it does not fit).  Blocking; device < 0 = current.
+ */
+int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, double* h_Z, int32_t device);
+
 #ifdef __cplusplus
 }
 #endif

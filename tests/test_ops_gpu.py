@@ -273,3 +273,37 @@ def test_gemm_bf16_activations_conv_addressing(built_lib, gpu):
              zs=dict(a_z0=Lp * D, a_z1=cg, w_z1=cg * k * cg, c_z0=L * D, c_z1=cg))
     torch.cuda.synchronize()
     assert _rel_err(out.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("C", [40, 700, 2600])
+def test_linkage_centroid_equals_scipy(built_lib, gpu, C):
+    """csrc/linkage.hip vs scipy.cluster.hierarchy.linkage(method="centroid"): same dendrogram (ids, sizes
+    exactly; distances to 1e-12) and the same flat clusters, on embeddings with speaker structure."""
+    import numpy as np
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from diarizen_amd import ops
+    from oracle.gen_golden import synth_host_case
+    seg, emb = synth_host_case(C, C=C, L=99, n_spk=5)
+    e = emb[seg.sum(1) > 0].astype(np.float32)
+    e /= np.linalg.norm(e, axis=-1, keepdims=True)
+    Zs = linkage(e, method="centroid", metric="euclidean")
+    Zg = ops.linkage_centroid(e)
+    assert np.array_equal(Zs[:, [0, 1, 3]], Zg[:, [0, 1, 3]])
+    assert np.abs(Zs[:, 2] - Zg[:, 2]).max() <= 1e-12
+    for thr in (0.5, 0.7, 1.0):
+        assert np.array_equal(fcluster(Zs, thr, "distance"), fcluster(Zg, thr, "distance"))
+
+
+def test_clustering_backends_agree(built_lib, gpu):
+    """AHC and VBx-style AHC initialisation through both linkage backends: identical hard clusters."""
+    import numpy as np
+    from diarizen_amd import clustering as cl
+    from oracle.gen_golden import synth_host_case
+    seg, emb = synth_host_case(5, C=1500, L=99, n_spk=4)
+    out = {}
+    for backend in ("scipy", "hip"):
+        ahc = cl.AgglomerativeClustering(threshold=0.7, min_cluster_size=13, linkage_backend=backend)
+        hard, soft, cent = ahc(embeddings=emb.copy(), segmentations=seg, min_clusters=1, max_clusters=20)
+        out[backend] = (hard, cent)
+    assert np.array_equal(out["scipy"][0], out["hip"][0])
+    assert np.allclose(out["scipy"][1], out["hip"][1])
