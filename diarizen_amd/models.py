@@ -66,7 +66,7 @@ class WavLMConformer:
                  use_posi: bool = False, output_activate_function=False,
                  max_speakers_per_chunk: int = 4, max_speakers_per_frame: int = 2,
                  chunk_size: int = 5, num_channels: int = 8, selected_channel: int = 0,
-                 sample_rate: int = 16000, precision: str = "f32", max_batch: int = 32):
+                 sample_rate: int = 16000, precision: str = "f32s", max_batch: int = 32):
         if use_posi or output_activate_function:
             raise NotImplementedError("use_posi / output activation are unused by the released confs")
         from dataclasses import replace

@@ -46,7 +46,7 @@ def _load_checkpoint(path: str) -> Dict[str, torch.Tensor]:
 class DiariZenPipeline:
     def __init__(self, diarizen_hub, embedding_model, config_parse: Optional[Dict[str, Any]] = None,
                  rttm_out_dir: Optional[str] = None, *, device: Optional[torch.device] = None,
-                 precision: str = "f32", seg_state: Optional[Mapping[str, torch.Tensor]] = None,
+                 precision: str = "f32s", seg_state: Optional[Mapping[str, torch.Tensor]] = None,
                  emb_state: Optional[Mapping[str, torch.Tensor]] = None,
                  config: Optional[Dict[str, Any]] = None):
         """diarizen_hub: directory with config.toml / pytorch_model.bin / plda ; embedding_model: path of
