@@ -1,7 +1,12 @@
 """Audio ingest for the pipeline (replaces `torchaudio.load` at diarizen/pipelines/inference.py:127
-and the `Audio` helper of PA/core/io.py for the one case the hot path needs: 16 kHz WAV, first
-channel kept — "force to use the SDM data", inference.py:128).  torchaudio is not available in
-this image; RIFF/WAVE PCM16/PCM32/float32 is decoded with the standard library + numpy.
+and the `Audio` helper of PA/core/io.py for what the hot path needs: WAV in, first channel kept —
+"force to use the SDM data", inference.py:128 — resampled to 16 kHz when the file is at another
+rate, as `Audio.downmix_and_resample` does with `torchaudio.functional.resample`, PA/core/io.py:214-218).
+torchaudio is not available in this image: RIFF/WAVE PCM8/16/32 and float32 are decoded with the
+standard library + numpy, and the resampler restates torchaudio's default algorithm
+(sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99; torchaudio==2.1.1 functional/functional.py
+`_get_sinc_resample_kernel` / `_apply_sinc_resample_kernel`).  Parity of the resampler is UNPINNED
+(no torchaudio here, no fixture in the reference); tests pin its properties instead.
 """
 from __future__ import annotations
 
@@ -62,9 +67,42 @@ def _load_float_wav(src):
     return np.frombuffer(body, dtype="<f4").astype(np.float32), sr, nch
 
 
+def resample(x: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+             rolloff: float = 0.99) -> np.ndarray:
+    """float32 [..., T] -> [..., ceil(T * new / orig)]: band-limited sinc interpolation with a Hann
+    window, evaluated as one strided convolution with `new/gcd` polyphase filters (torchaudio's default
+    `functional.resample`).  The filter bank is built in float64 and applied in float32, like torchaudio."""
+    import math
+    import torch
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq == new_freq:
+        return np.ascontiguousarray(x, dtype=np.float32)
+    g = math.gcd(orig_freq, new_freq)
+    o, n = orig_freq // g, new_freq // g
+    base = min(o, n) * rolloff
+    width = math.ceil(lowpass_filter_width * o / base)
+    idx = torch.arange(-width, width + o, dtype=torch.float64)[None, None] / o
+    t = torch.arange(0, -n, -1, dtype=torch.float64)[:, None, None] / n + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / o)
+    kernels = kernels.to(torch.float32)                                  # [n, 1, 2 width + o]
+    w = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    shape = w.shape
+    w = w.reshape(-1, shape[-1])
+    length = w.shape[-1]
+    w = torch.nn.functional.pad(w, (width, width + o))
+    y = torch.nn.functional.conv1d(w[:, None], kernels, stride=o)        # [B, n, frames]
+    y = y.transpose(1, 2).reshape(w.shape[0], -1)
+    target = math.ceil(n * length / o)
+    return y[..., :target].reshape(shape[:-1] + (target,)).numpy()
+
+
 def first_channel_16k(src, expected_sr: int = 16000) -> np.ndarray:
+    """-> float32 [N] at `expected_sr`: channel 0 of the file (inference.py:128), resampled if needed."""
     x, sr = load_wav(src)
+    x0 = np.ascontiguousarray(x[0])
     if sr != expected_sr:
-        raise ValueError(f"expected {expected_sr} Hz audio, got {sr} Hz (resampling is host I/O, "
-                         "out of scope of the engine: convert the file first)")
-    return np.ascontiguousarray(x[0])
+        x0 = resample(x0, sr, expected_sr)
+    return x0

@@ -52,7 +52,7 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 //     rows is multiplied, then [wait tile kt+1, barrier, refill the stage of tile kt], then the
 //     fragments of tile kt+1 are read into the second register set while the second half of
 //     tile kt is multiplied — the matrix pipe has work queued across the barrier.
-template <int BM, int BN, int WGM, int WGN, int S, int DBG = 0>
+template <int BM, int BN, int WGM, int WGN, int S>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_gemm_desc d) {
   constexpr int NW = WGM * WGN;           // wavefronts per workgroup
   constexpr int BK = 32;
@@ -190,11 +190,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
     for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], ah, acc[i][j], 0, 0, 0);
   };
   auto split = [&](const f32x4 (&a)[2], bf16x8& ah, bf16x8& am, bf16x8& al) {
-    if constexpr (DBG == 3) {
-      ah = __builtin_bit_cast(bf16x8, a[0]); am = __builtin_bit_cast(bf16x8, a[1]); al = ah;
-    } else {
-      split8(a[0], a[1], ah, am, al);
-    }
+    split8(a[0], a[1], ah, am, al);
   };
 
   const int nk = d.K / BK;
@@ -223,7 +219,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
     for (int i = 0; i < MH; ++i) {
       bf16x8 ah, am, al;
       split(ar[i], ah, am, al);
-      if (DBG != 2) mma6(i, wc, ah, am, al);
+      mma6(i, wc, ah, am, al);
     }
     bf16x8 ah[MI - MH], am[MI - MH], al[MI - MH];
 #pragma unroll
@@ -235,14 +231,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
       if (kt + S <= nk) wait_tiles(std::integral_constant<int, S - 2>{});
       else wait_vm_lgkm0<0>();
       __builtin_amdgcn_s_barrier();
-      if (DBG != 1 && kt + S < nk) issue(stage);  // every wave is past its reads of tile kt
+      if (kt + S < nk) issue(stage);  // every wave is past its reads of tile kt
       read_w(nstage, wn_);
       read_a(nstage, ar);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = MH; i < MI; ++i)
-      if (DBG != 2) mma6(i, wc, ah[i - MH], am[i - MH], al[i - MH]);
+    for (int i = MH; i < MI; ++i) mma6(i, wc, ah[i - MH], am[i - MH], al[i - MH]);
     stage = nstage;
   };
   for (int kt = 0; kt < nk; kt += 2) {
@@ -252,11 +247,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
   gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz);
 }
 
-template <int BM, int BN, int WGM, int WGN, int S, int DBG = 0>
+template <int BM, int BN, int WGM, int WGN, int S>
 int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
   const size_t lds = (size_t)S * (BM * 128 + 3 * BN * 64);
-  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, DBG>;
+  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -306,31 +301,12 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 
 int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s) {
   if ((d.K & 31) || (d.kc & 31) || !d.W3 || d.ldw != d.K) return DZN_E_INVALID;
-  static const char* force = getenv("DZN_GEMM_CFG");
+  static const char* force = getenv("DZN_GEMM_CFG");   // tuning knob: force one tile shape
   if (force) {
-    if (!strcmp(force, "128x128s2")) return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
-    if (!strcmp(force, "128x128s2d1")) return launch_split_cfg<128, 128, 2, 2, 2, 1>(d, s);
-    if (!strcmp(force, "128x128s2d3")) return launch_split_cfg<128, 128, 2, 2, 2, 3>(d, s);
-    if (!strcmp(force, "128x128s3")) return launch_split_cfg<128, 128, 2, 2, 3>(d, s);
-    if (!strcmp(force, "128x128s4")) return launch_split_cfg<128, 128, 2, 2, 4>(d, s);
-    if (!strcmp(force, "128x128w8s2")) return launch_split_cfg<128, 128, 4, 2, 2>(d, s);
-    if (!strcmp(force, "128x128w8s3")) return launch_split_cfg<128, 128, 4, 2, 3>(d, s);
-    if (!strcmp(force, "128x128w8s3d1")) return launch_split_cfg<128, 128, 4, 2, 3, 1>(d, s);
-    if (!strcmp(force, "128x128w8s3d3")) return launch_split_cfg<128, 128, 4, 2, 3, 3>(d, s);
-    if (!strcmp(force, "128x128w8s4")) return launch_split_cfg<128, 128, 4, 2, 4>(d, s);
-    if (!strcmp(force, "256x128w8s2")) return launch_split_cfg<256, 128, 4, 2, 2>(d, s);
-    if (!strcmp(force, "128x256w8s2")) return launch_split_cfg<128, 256, 2, 4, 2>(d, s);
-    if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 2, 2, 2>(d, s);
-    if (!strcmp(force, "128x64v")) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
-    if (!strcmp(force, "128x64vs3")) return launch_split_cfg<128, 64, 4, 1, 3>(d, s);
-    if (!strcmp(force, "256x64w8")) return launch_split_cfg<256, 64, 8, 1, 2>(d, s);
+    if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
+    if (!strcmp(force, "256x128")) return launch_split_cfg<256, 128, 4, 2, 2>(d, s);
+    if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
     if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2>(d, s);
-    if (!strcmp(force, "128x32s4")) return launch_split_cfg<128, 32, 4, 1, 4>(d, s);
-    if (!strcmp(force, "256x32w8")) return launch_split_cfg<256, 32, 8, 1, 2>(d, s);
-    if (!strcmp(force, "128x96")) return launch_split_cfg<128, 96, 2, 2, 2>(d, s);
-    if (!strcmp(force, "128x160")) return launch_split_cfg<128, 160, 2, 2, 2>(d, s);
-    if (!strcmp(force, "128x192")) return launch_split_cfg<128, 192, 2, 2, 2>(d, s);
-    if (!strcmp(force, "128x128v")) return launch_split_cfg<128, 128, 4, 1, 2>(d, s);
   }
   if (d.N <= 32) return launch_split_cfg<128, 32, 4, 1, 2>(d, s);
   // 128x64 tiles run 4 wavefronts as 4x1 (32 rows x 64 columns each): the in-register operand

@@ -152,6 +152,36 @@ def test_wav_loader_roundtrip(tmp_path):
         assert first_channel_16k(ref).shape[0] > 0
 
 
+def test_resampler_properties(tmp_path):
+    """torchaudio-style sinc/Hann resampler (PA/core/io.py:214-218): output length = ceil(T new / orig);
+    a band-limited tone is reproduced at the new rate (away from the edges); identity at equal rates;
+    energy above the new Nyquist is removed; a 48 kHz stereo file comes out as its first channel at 16 kHz."""
+    import wave
+    from diarizen_amd.audio import first_channel_16k, resample
+    sr0, sr1, T = 48000, 16000, 48000
+    t0 = np.arange(T) / sr0
+    x = (0.5 * np.sin(2 * np.pi * 440.0 * t0)).astype(np.float32)
+    y = resample(x, sr0, sr1)
+    assert y.shape == (16000,) and y.dtype == np.float32
+    t1 = np.arange(16000) / sr1
+    assert np.abs(y[200:-200] - 0.5 * np.sin(2 * np.pi * 440.0 * t1[200:-200])).max() < 2e-3
+    assert resample(x, 16000, 16000) is not None and np.array_equal(resample(x, 16000, 16000), x)
+    assert resample(np.zeros(1001, np.float32), 44100, 16000).shape == (int(np.ceil(1001 * 160 / 441)),)
+    hi = (0.5 * np.sin(2 * np.pi * 12000.0 * t0)).astype(np.float32)        # above the 8 kHz Nyquist
+    assert np.abs(resample(hi, sr0, sr1)[200:-200]).max() < 5e-3
+    up = resample(y, sr1, sr0)                                               # back up: the tone survives
+    assert np.abs(up[600:-600] - x[600:-600]).max() < 4e-3
+    st = np.stack([(x * 32767).astype("<i2"), np.zeros(T, "<i2")], axis=1)
+    p = tmp_path / "b.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(sr0)
+        w.writeframes(st.tobytes())
+    z = first_channel_16k(str(p))
+    assert z.shape == (16000,) and np.abs(z[200:-200] - y[200:-200]).max() < 1e-3
+
+
 # ----------------------------------------------------------------------------- multi-process exchange
 def _free_port():
     s = socket.socket()
