@@ -130,6 +130,10 @@ int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* 
 int launch_stats_pool(const void* img, int in_bf16, int B, int H, int W, int C, const float* masks, int S,
                       int L, float* stats, hipStream_t st);
 
+// conv_split.hip: 3x3 stride-1 conv 32 -> 32 over zero-bordered NHWC images (DZN_PREC_F32_SPLIT)
+int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias, const float* R, float* out, int B,
+                             int Hs, int Ws, int relu, int post_relu, hipStream_t s);
+
 // post.hip
 int launch_prepare_masks(const uint8_t* ml, int B, int L, int S, int median, int exclude_overlap,
                          int min_num_frames, uint8_t* filtered, float* masks, hipStream_t st);

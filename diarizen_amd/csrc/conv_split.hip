@@ -1,0 +1,210 @@
+// conv_split.hip — 3x3 stride-1 convolution, 32 -> 32 channels, for the first ResNet34 stage
+// (wespeaker/resnet.py:139-144 BasicBlock.conv1 / conv2 at 32 planes, BatchNorm folded) in the
+// fp32-split arithmetic of split.h (DZN_PREC_F32_SPLIT).
+//
+// Why a dedicated kernel: as a generic contraction (gemm_split.hip, N = 32, K = 9 x 32) every input
+// pixel is split into its three bf16 terms NINE times (once per tap that reads it) and the 32-wide
+// column tile leaves the in-register split as expensive as the MFMAs — 105 TFLOP/s, the slowest
+// contraction class of the pipeline (8.7 % of device time).  Here:
+//   * the image is walked as ONE flat pixel axis over the zero-bordered NHWC layout
+//     [B][H+2][W+2][32]: a tile is 128 consecutive padded pixels, tap (dh, dw) of pixel q reads pixel
+//     q + (dh-1)(W+2) + (dw-1), so a tile needs three contiguous 130-pixel segments; outputs that
+//     fall on a border column are computed and masked at the store (2 / (W+2) of the work);
+//   * each input pixel of the strip is split ONCE by the staging pass and kept as three bf16 planes in
+//     LDS ([segment][pixel][64 B], 16-B chunk XOR ((pixel >> 1) & 3): every fragment — at any of the
+//     three dw shifts — is one conflict-free ds_read_b128);
+//   * the pre-split weights of a wavefront's 16 output channels (9 taps x 3 planes = 27 fragments)
+//     live in registers for the whole persistent loop, so the MFMA phase reads only pixels from LDS;
+//   * persistent workgroups, 2 per CU (75 KB of LDS each): the strip of the next tile is fetched into
+//     registers while the current one is multiplied, and one workgroup splits while the other multiplies.
+// Measured 138 TFLOP/s (2.2 ms per launch at B = 256) against 105 for the generic kernel; the MFMA
+// phase still waits on its just-in-time fragment reads (register budget: 108 weight + 56 prefetch).
+// Epilogue: + bias (folded BN shift), optional ReLU, optional residual, optional post-ReLU, float4 store.
+#include <type_traits>
+
+#include "common.h"
+#include "split.h"
+
+namespace {
+
+constexpr int CS_TP = 128;               // output pixels per tile
+constexpr int CS_SEG = CS_TP + 2;        // pixels per input segment
+constexpr int CS_PLANE = 3 * CS_SEG * 64;  // bytes per bf16 plane of the strip
+
+struct ConvArgs {
+  const float* in;
+  const u16* W3;       // [32 oc][9 taps][3 planes][32] bf16, k order of gemm_split.hip
+  const float* bias;   // [32]
+  const float* R;      // residual image (same geometry) or nullptr
+  float* out;
+  int B, Hs, Ws;       // interior size; images are [Hs+2][Ws+2][32]
+  int relu, post_relu;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int mh = wave >> 1, nb = wave & 1;     // wavefront -> 64-pixel half, 16-channel block
+  const int P = a.Ws + 2;
+  const int64_t img = (int64_t)(a.Hs + 2) * P * 32;   // elements per image
+  const int npix = a.Hs * P;                          // flat pixels of the rows that hold outputs
+  const int tiles_img = (npix + CS_TP - 1) / CS_TP;
+  const int ntiles = tiles_img * a.B;
+  const int last_pix = (a.Hs + 2) * P - 1;
+
+  // this wavefront's weight fragments: A operand rows = output channels nb*16 + lr, k = 8 lq .. 8 lq + 7
+  bf16x8 wf[9][3];
+  {
+    const u16* wp = a.W3 + (int64_t)(nb * 16 + lr) * (9 * 96) + lq * 8;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wf[t][p] = *reinterpret_cast<const bf16x8*>(wp + t * 96 + p * 32);
+  }
+  const float4 b4 = *reinterpret_cast<const float4*>(a.bias + nb * 16 + lq * 4);
+
+  // staging registers: 7 items per thread (3 segments x 130 pixels x 4 chunks of 8 channels = 1560 items);
+  // the strip of tile t+1 is fetched into them while tile t is multiplied
+  constexpr int NITEM = 3 * CS_SEG * 4, NIT = 7;
+  static_assert(NITEM <= NIT * 256, "7 items per thread");
+  float4 u4[NIT], v4[NIT];
+  auto fetch = [&](int tile) {
+    const int b = tile / tiles_img;
+    const int q0 = P + (tile - b * tiles_img) * CS_TP;
+    const float* ib = a.in + (int64_t)b * img;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      int item = tid + 256 * i;
+      item = item < NITEM ? item : NITEM - 1;
+      const int seg = item / (CS_SEG * 4);
+      const int r = item - seg * (CS_SEG * 4);
+      int gq = q0 + (seg - 1) * P - 1 + (r >> 2);
+      gq = gq < 0 ? 0 : (gq > last_pix ? last_pix : gq);  // only masked outputs ever see a clamped pixel
+      const float* src = ib + (int64_t)gq * 32 + 4 * (r & 3);
+      u4[i] = *reinterpret_cast<const float4*>(src);        // channels 4c .. 4c+3
+      v4[i] = *reinterpret_cast<const float4*>(src + 16);   // channels 16+4c .. 16+4c+3
+    }
+  };
+  auto split_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int item = tid + 256 * i;
+      const int seg = item / (CS_SEG * 4);
+      const int r = item - seg * (CS_SEG * 4);
+      const int px = r >> 2, c = r & 3;
+      bf16x8 ph, pm, pl;
+      split8((f32x4){u4[i].x, u4[i].y, u4[i].z, u4[i].w}, (f32x4){v4[i].x, v4[i].y, v4[i].z, v4[i].w}, ph, pm, pl);
+      if (item < NITEM) {
+        const int off = (seg * CS_SEG + px) * 64 + ((c ^ ((px >> 1) & 3)) << 4);
+        *reinterpret_cast<bf16x8*>(smem + off) = ph;
+        *reinterpret_cast<bf16x8*>(smem + CS_PLANE + off) = pm;
+        *reinterpret_cast<bf16x8*>(smem + 2 * CS_PLANE + off) = pl;
+      }
+    }
+  };
+
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / tiles_img;
+    const int q0 = P + (tile - b * tiles_img) * CS_TP;    // first output pixel (flat, padded coords)
+    split_store();      // every input pixel of the strip is split exactly once
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);   // in flight during the MFMA phase
+
+    // ---- multiply: 4 pixel blocks x 9 taps x 6 products; accumulators D[oc][pixel]; two pixel blocks
+    // at a time keeps the fragment registers at 24 (the strip prefetch needs the rest) ----
+    f32x4 acc[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int t = dh * 3 + dw;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          bf16x8 xh[2], xm[2], xl[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int px = mh * 64 + (2 * g + m) * 16 + lr + dw;
+            const int off = (dh * CS_SEG + px) * 64 + ((lq ^ ((px >> 1) & 3)) << 4);
+            xh[m] = *reinterpret_cast<const bf16x8*>(smem + off);
+            xm[m] = *reinterpret_cast<const bf16x8*>(smem + CS_PLANE + off);
+            xl[m] = *reinterpret_cast<const bf16x8*>(smem + 2 * CS_PLANE + off);
+          }
+          // product-major, smallest terms first
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][2], xh[m], acc[2 * g + m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0], xl[m], acc[2 * g + m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][1], xm[m], acc[2 * g + m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][1], xh[m], acc[2 * g + m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0], xm[m], acc[2 * g + m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0], xh[m], acc[2 * g + m], 0, 0, 0);
+        }
+      }
+
+    // ---- epilogue: lane holds pixel lr of block mb, output channels nb*16 + 4 lq .. +3 ----
+    float* ob = a.out + (int64_t)b * img;
+    const float* rb = a.R ? a.R + (int64_t)b * img : nullptr;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int q = q0 + mh * 64 + mb * 16 + lr;
+      const int col = q % P;
+      if (q < P + npix && col >= 1 && col <= a.Ws) {
+        const int64_t o = (int64_t)q * 32 + nb * 16 + lq * 4;
+        f32x4 v = acc[mb];
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (rb) {
+          const float4 r4 = *reinterpret_cast<const float4*>(rb + o);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        if (a.post_relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<float4*>(ob + o) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __syncthreads();  // the strip is free for the next tile's staging
+  }
+}
+
+}  // namespace
+
+// in / out / R: zero-bordered fp32 NHWC images [B][Hs+2][Ws+2][32] (image bases, not interior pointers)
+int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias, const float* R, float* out, int B,
+                             int Hs, int Ws, int relu, int post_relu, hipStream_t s) {
+  if (B <= 0 || Hs <= 0 || Ws <= 0) return DZN_OK;
+  if (!in || !W3 || !bias || !out) return DZN_E_INVALID;
+  static bool attr_set = false;
+  const size_t lds = 3 * CS_PLANE;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_split_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  ConvArgs a{in, static_cast<const u16*>(W3), bias, R, out, B, Hs, Ws, relu, post_relu};
+  const int64_t ntiles = (int64_t)((Hs * (Ws + 2) + CS_TP - 1) / CS_TP) * B;
+  const int grid = (int)(ntiles < 512 ? ntiles : 512);   // persistent: 2 workgroups per CU
+  const int pid = prof_begin(s, "conv3x3_c32_f32s", 2.0 * B * Hs * (double)Ws * 32.0 * 288.0, 0.0);
+  hipLaunchKernelGGL(conv3x3_c32_split_kernel, dim3(grid), dim3(256), lds, s, a);
+  prof_end(pid, s);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+extern "C" int dzn_op_conv3x3_c32(const float* in, const void* W3, const float* bias, const float* R, float* out,
+                                  int32_t B, int32_t Hs, int32_t Ws, int32_t relu, int32_t post_relu, void* stream) {
+  return launch_conv3x3_c32_split(in, W3, bias, R, out, B, Hs, Ws, relu, post_relu,
+                                  reinterpret_cast<hipStream_t>(stream));
+}

@@ -1083,6 +1083,13 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
     const int M = Hs * Ws;
     auto conv3 = [&](const float* in, const ResConv& rc, float* out, const float* R, int act,
                      int post_relu) {
+      if (c.precision == DZN_PREC_F32_SPLIT && rc.cin == 32 && rc.cout == 32 && rc.l.W3 &&
+          (act == DZN_ACT_NONE || act == DZN_ACT_RELU)) {
+        // first ResNet stage: dedicated kernel, every input pixel split once instead of once per tap
+        chk(launch_conv3x3_c32_split(in, rc.l.W3, rc.l.b, R, out, B, Hs, Ws, act == DZN_ACT_RELU, post_relu, st),
+            "resnet conv3x3 c32");
+        return;
+      }
       // stride-1 3x3 inside stage s: patch rows via tab1, two-level K = (dh | dw*C + ci)
       dzn_gemm_desc d = gd(h, in, rc.l, eoff(out, interior, lp), M, 0, 0);
       d.a_rowoff = h->tab1[s];

@@ -81,6 +81,19 @@ def split_weights(W):
     return out
 
 
+def conv3x3_c32(img, W3, bias, R=None, relu=False, post_relu=False, out=None):
+    """3x3 stride-1 conv 32 -> 32 on zero-bordered NHWC fp32 images [B, H+2, W+2, 32] (csrc/conv_split.hip);
+    W3 = split_weights(W[32, 288]) with k = (dh*3 + dw)*32 + ci.  Returns a new zero-bordered image."""
+    lib = _lib.load()
+    assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and img.shape[-1] == 32
+    B, Hp, Wp, _ = img.shape
+    if out is None:
+        out = torch.zeros_like(img)
+    check(lib.dzn_op_conv3x3_c32(_p(img), _p(W3), _p(bias), _p(R), _p(out), B, Hp - 2, Wp - 2, int(relu),
+                                 int(post_relu), _stream()), what="dzn_op_conv3x3_c32")
+    return out
+
+
 def linkage_centroid(emb, device: int = -1):
     """scipy.cluster.hierarchy.linkage(emb, "centroid", "euclidean") on the device (csrc/linkage.hip):
     emb = host float32 [n, dim] (numpy), returns the dendrogram float64 [n - 1, 4]."""

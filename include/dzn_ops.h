@@ -82,6 +82,13 @@ int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
  * W fp32 [rows][K] (row stride ldw, K % 32 == 0) -> W3 bf16 [rows][K/32][3][32] (3*rows*K u16). */
 int dzn_op_split_weights(const float* W, int64_t rows, int32_t K, int64_t ldw, void* W3, void* stream);
 
+/* 3x3 stride-1 convolution 32 -> 32 channels over zero-bordered fp32 NHWC images [B][Hs+2][Ws+2][32]
+ * (first ResNet34 stage, wespeaker/resnet.py:139-144 with BatchNorm folded into W / bias) in the fp32-split
+ * arithmetic: W3 = dzn_op_split_weights of W [32][(dh*3+dw)*32 + ci]; out = post_relu?max(0,·):(·) of
+ * (relu?max(0,·):(·))(conv + bias) + R.  Only interior pixels are written (borders stay zero). */
+int dzn_op_conv3x3_c32(const float* in, const void* W3, const float* bias, const float* R, float* out,
+                       int32_t B, int32_t Hs, int32_t Ws, int32_t relu, int32_t post_relu, void* stream);
+
 /* y[r,:] = LayerNorm(x[r,:C]) * gamma + beta (eps), optional fused erf-GELU; row strides
  * ldx / ldy; columns [C, Cpad) of y are written as zero.  torch F.layer_norm. */
 int dzn_op_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,

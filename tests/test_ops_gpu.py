@@ -307,3 +307,32 @@ def test_clustering_backends_agree(built_lib, gpu):
         out[backend] = (hard, cent)
     assert np.array_equal(out["scipy"][0], out["hip"][0])
     assert np.allclose(out["scipy"][1], out["hip"][1])
+
+
+@pytest.mark.parametrize("H,W,B", [(5, 37, 2), (80, 798, 1), (12, 126, 3)])
+def test_conv3x3_c32_split(built_lib, gpu, H, W, B):
+    """csrc/conv_split.hip vs torch conv2d in float64: plain, and with ReLU / residual / post-ReLU; borders
+    of the output image must stay exactly zero (they are the next layer's padding)."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    x = torch.randn(B, 32, H, W, generator=g)
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.1
+    bias = torch.randn(32, generator=g)
+    res = torch.randn(B, 32, H, W, generator=g)
+    def padded(t):
+        o = torch.zeros(B, H + 2, W + 2, 32)
+        o[:, 1:-1, 1:-1] = t.permute(0, 2, 3, 1)
+        return o.contiguous()
+    wp = w.permute(0, 2, 3, 1).reshape(32, 288).contiguous()           # k = (dh*3 + dw)*32 + ci
+    W3 = ops.split_weights(wp.to(gpu))
+    conv = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    cases = [(False, False, None, conv),
+             (True, False, None, torch.relu(conv)),
+             (False, True, res, torch.relu(conv + res.double()))]
+    for relu, post, R, ref in cases:
+        out = ops.conv3x3_c32(padded(x).to(gpu), W3, bias.to(gpu), R=None if R is None else padded(R).to(gpu),
+                              relu=relu, post_relu=post).cpu()
+        got = out[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double()
+        assert _rel_err(got, ref) < 1e-5
+        assert out[:, 0].abs().max() == 0 and out[:, -1].abs().max() == 0
+        assert out[:, :, 0].abs().max() == 0 and out[:, :, -1].abs().max() == 0
