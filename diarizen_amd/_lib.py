@@ -87,6 +87,7 @@ class DznGemmDesc(C.Structure):
         ("alg_flops", C.c_double),
         ("a_bf16", C.c_int32), ("c_bf16", C.c_int32), ("r_bf16", C.c_int32),
         ("W3", C.c_void_p),
+        ("a_split3", C.c_int32), ("a_plane", C.c_int64),
     ]
 
 

@@ -80,6 +80,9 @@ static inline u16 f32_to_bf16_host(float f) {
 int launch_gemm(const dzn_gemm_desc& d, hipStream_t s);
 int launch_gemm_lowp(const dzn_gemm_desc& d, hipStream_t s);  // gemm_lowp.hip: A and W both bf16
 int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s); // gemm_split.hip: fp32 via 3-way bf16 split
+int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s);  // gemm_split_pre.hip: A pre-split planes
+int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
+                           hipStream_t st);
 int launch_split_weights(const float* W, int64_t rows, int K, int64_t ldw, void* W3, hipStream_t s);
 int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* g,
                      const float* b, int64_t rows, int C, int Cpad, float eps, int gelu,

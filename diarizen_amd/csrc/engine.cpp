@@ -124,6 +124,8 @@ struct dzn_handle {
   int table_L = -1;
   int pos_L = -1;               // geometry baked into pos_rowoff
   int32_t* pos_rowoff = nullptr;  // row m = b*L + t of the positional conv -> element offset into xpad
+  u16* xpad3 = nullptr;           // f32s mode: the padded copy as three bf16 planes (split once, read by 128 taps)
+  int64_t xpad3_plane = 0;
   float* table = nullptr;
   // ---- segmentation: workspace ----
   int maxT[DZN_MAX_CONV]{};
@@ -524,6 +526,10 @@ void finalize_seg(H* h) {
   }
   h->x = dalloc<float>(h, ML * D);
   h->xpad = dalloc<float>(h, B * (n + c.pos_conv_kernel) * D);
+  if (c.precision == DZN_PREC_F32_SPLIT && (D / c.pos_conv_groups) % 32 == 0) {
+    h->xpad3_plane = B * (n + c.pos_conv_kernel) * D;
+    h->xpad3 = dalloc<u16>(h, 3 * h->xpad3_plane);
+  }
   h->y = dalloc<float>(h, ML * D);
   h->ws = dalloc<float>(h, ML * D);
   h->qkv = dalloc<float>(h, ML * 3 * maxQ);
@@ -874,7 +880,13 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     // the LDS-DMA bf16 kernel needs kc % 32 == 0; otherwise (base: 768/16 = 48 channels per group)
     // keep this one contraction on fp32 activations (register-staged kernel converts on the fly)
     const bool pc16 = lp && (cg % 32 == 0);
-    chk(launch_pad_rows(h->x, h->xpad, pc16, B, L, Lp, Kc / 2, D, st), "pad_rows");
+    // f32s: every element of the padded copy feeds 128 taps — split it ONCE here (three bf16 planes) and
+    // let the contraction read the planes (gemm_split_pre.hip) instead of re-splitting it per K tile
+    const bool pre3 = h->xpad3 != nullptr && (int64_t)c.max_batch * Lp * D < (int64_t)1 << 31;
+    if (pre3)
+      chk(launch_pad_rows_split3(h->x, h->xpad3, h->xpad3_plane, B, L, Lp, Kc / 2, D, st), "pad_rows_split3");
+    else
+      chk(launch_pad_rows(h->x, h->xpad, pc16, B, L, Lp, Kc / 2, D, st), "pad_rows");
     // one contraction per channel group over ALL B*L rows (row-offset table into the padded copy), so
     // the 128-row tiles are not padded per window (L = 399 would waste 22 % of every window's last tile)
     const bool tabled = (int64_t)c.max_batch * Lp * D < (int64_t)1 << 31;
@@ -900,6 +912,11 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       d.a_z0 = (int64_t)Lp * D;
       d.c_z0 = (int64_t)L * D;
       d.alg_flops = 2.0 * (double)L * cg * h->posconv.Kt;
+    }
+    if (pre3) {
+      d.A = reinterpret_cast<const float*>(h->xpad3);
+      d.a_split3 = 1;
+      d.a_plane = h->xpad3_plane;
     }
     gemm(d, pc16, false, "pos conv");
   }

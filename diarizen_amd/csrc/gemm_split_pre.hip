@@ -1,0 +1,265 @@
+// gemm_split_pre.hip — the contraction of gemm_split.hip for an A operand that is ALREADY split
+// (dzn_gemm_desc.a_split3): three bf16 planes written once by the producing kernel, in the same
+// k order inside each 32-block as the weight planes.
+//
+// Used where one activation element feeds many K tiles, so splitting it inside the contraction
+// repeats the same VALU work many times: the positional conv (W2V/components.py:366-380: every
+// element of the padded copy is read by 128 taps — pad_rows_split3_kernel writes the planes once).
+// With no split in the loop the kernel is bf16-MFMA + ds_read only: both operands arrive by LDS-DMA
+// as [rows][64 B] plane images (slot XOR g((row >> 2) & 3), conflict free), 6 products per block.
+// Same pipeline as gemm_split.hip (mid-tile raw barrier, younger LDS-DMA tiles stay in flight,
+// fragments of tile kt+1 read during the second half of tile kt), same fused epilogue.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "split.h"
+
+namespace {
+
+__device__ __forceinline__ int pswz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+  static_assert(N >= 0 && N < 64, "vmcnt range");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4));
+}
+
+template <int BM, int BN, int WGM, int WGN, int S>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dzn_gemm_desc d) {
+  constexpr int NW = WGM * WGN;
+  constexpr int BK = 32;
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MI = TM / 16, NI = TN / 16, MH = MI / 2;
+  constexpr int RB = NW * 1024;
+  constexpr int ROWS = NW * 16;           // plane rows per LDS-DMA round (64-B rows)
+  constexpr int AR = BM / ROWS, WR = BN / ROWS;
+  constexpr int APLANE = BM * 64, WPLANE = BN * 64, BUF = 3 * (APLANE + WPLANE);
+  constexpr int LPT = 3 * (AR + WR);
+  static_assert(BM % ROWS == 0 && BN % ROWS == 0, "whole rounds");
+  static_assert(MI % 2 == 0, "two row halves per wavefront tile");
+  static_assert(S >= 2 && (S - 1) * LPT < 64, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tilesN = (d.N + BN - 1) / BN;
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = t / tilesN, tn = t % tilesN;
+  const int z = blockIdx.y;
+  const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
+  const u16* __restrict__ A3 = reinterpret_cast<const u16*>(d.A) + z0 * d.a_z0 + z1 * d.a_z1;
+  const u16* __restrict__ W3 = reinterpret_cast<const u16*>(d.W3) + 3 * (z0 * d.w_z0 + z1 * d.w_z1);
+  const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
+  const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
+
+  // thread -> (row = 16 wave + lane/4 + ROWS i, physical slot lane%4), logical 8-element chunk = slot ^ g
+  const int pr0 = wave * 16 + (lane >> 2);
+  const int psw = (lane & 3) ^ pswz(pr0);
+  const u16* aptr[AR];
+  const u16* wptr[WR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int m = tm * BM + pr0 + ROWS * i;
+    m = m < d.M ? m : d.M - 1;
+    aptr[i] = A3 + (d.a_rowoff ? (int64_t)d.a_rowoff[m] : (int64_t)m * d.lda) + psw * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    int n = tn * BN + pr0 + ROWS * i;
+    n = n < d.N ? n : d.N - 1;
+    wptr[i] = W3 + (int64_t)n * 3 * d.ldw + psw * 8;
+  }
+
+  int ik = 0, irem = 0;
+  int64_t ikoff = 0;
+  auto issue = [&](int stage) {
+    unsigned char* sA = smem + stage * BUF + wave * 1024;
+    unsigned char* sW = sA + 3 * APLANE;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(aptr[i] + p * d.a_plane + ikoff),
+            (__attribute__((address_space(3))) void*)(sA + p * APLANE + i * RB), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < WR; ++i)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wptr[i] + 3 * ik + p * 32),
+            (__attribute__((address_space(3))) void*)(sW + p * WPLANE + i * RB), 16, 0, 0);
+    }
+    ik += BK;
+    irem += BK;
+    ikoff += BK;
+    if (irem == d.kc) { irem = 0; ikoff += d.ldk - d.kc; }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int lr = lane & 15, lq = lane >> 4;
+  int aoff[MI], woff[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * TM + i * 16 + lr;
+    aoff[i] = row * 64 + ((lq ^ pswz(row)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = wn * TN + j * 16 + lr;
+    woff[j] = 3 * APLANE + row * 64 + ((lq ^ pswz(row)) << 4);
+  }
+  auto read_w = [&](int stage, bf16x8 (&wf)[NI][3]) {
+    const unsigned char* base = smem + stage * BUF;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wf[j][p] = *reinterpret_cast<const bf16x8*>(base + p * WPLANE + woff[j]);
+  };
+  auto read_a = [&](int stage, bf16x8 (&af)[MI][3]) {
+    const unsigned char* base = smem + stage * BUF;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(base + p * APLANE + aoff[i]);
+  };
+  auto mma6 = [&](int i, const bf16x8 (&wf)[NI][3], const bf16x8& ah, const bf16x8& am, const bf16x8& al) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][2], ah, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], al, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], am, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], ah, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], am, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], ah, acc[i][j], 0, 0, 0);
+  };
+
+  const int nk = d.K / BK;
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    if (s < nk) issue(s);
+  if (nk >= S) wait_vm_lgkm0<(S - 1) * LPT>();
+  else wait_vm_lgkm0<0>();
+  __builtin_amdgcn_s_barrier();
+  bf16x8 wfa[NI][3], wfb[NI][3], af[MI][3];
+  read_w(0, wfa);
+  read_a(0, af);
+  int stage = 0;
+  auto step = [&](int kt, const bf16x8 (&wc)[NI][3], bf16x8 (&wn_)[NI][3]) {
+    const bool more = kt + 1 < nk;
+#pragma unroll
+    for (int i = 0; i < MH; ++i) mma6(i, wc, af[i][0], af[i][1], af[i][2]);
+    bf16x8 ah[MI - MH], am[MI - MH], al[MI - MH];
+#pragma unroll
+    for (int i = MH; i < MI; ++i) { ah[i - MH] = af[i][0]; am[i - MH] = af[i][1]; al[i - MH] = af[i][2]; }
+    const int nstage = stage + 1 == S ? 0 : stage + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      if (kt + S <= nk) wait_vm_lgkm0<(S - 2) * LPT>();
+      else wait_vm_lgkm0<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + S < nk) issue(stage);
+      read_w(nstage, wn_);
+      read_a(nstage, af);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = MH; i < MI; ++i) mma6(i, wc, ah[i - MH], am[i - MH], al[i - MH]);
+    stage = nstage;
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, wfa, wfb);
+    if (kt + 1 < nk) step(kt + 1, wfb, wfa);
+  }
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz);
+}
+
+template <int BM, int BN, int WGM, int WGN, int S>
+int launch_pre_cfg(const dzn_gemm_desc& d, hipStream_t s) {
+  const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+  const size_t lds = (size_t)S * 3 * (BM + BN) * 64;
+  auto kern = gemm_split_pre_kernel<BM, BN, WGM, WGN, S>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(tilesM * tilesN, d.nz > 0 ? d.nz : 1, 1);
+  int pid = -1;
+  if (prof_enabled()) {
+    char cls[64];
+    static const bool by_shape = getenv("DZN_PROFILE_SHAPES") != nullptr;
+    if (by_shape)
+      snprintf(cls, sizeof(cls), "gemm_f32s_pre_%dx%d M%d N%d K%d z%d", BM, BN, d.M, d.N, d.K, d.nz);
+    else
+      snprintf(cls, sizeof(cls), "gemm_f32s_pre_%dx%d", BM, BN);
+    const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
+    pid = prof_begin(s, cls, fl, 0.0);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, d);
+  prof_end(pid, s);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+// x fp32 [B, L, D] -> three bf16 planes of the zero-padded copy [B, Lp, D] (rows shifted by `pad`), the 32
+// channels of every block stored in fragment order (position 8q+e <-> channel 4q+e, 16+4q+(e-4))
+__global__ __launch_bounds__(256) void pad_rows_split3_kernel(const float* __restrict__ x, u16* __restrict__ planes,
+                                                              int64_t plane_stride, int L, int Lp, int pad, int D) {
+  const int b = blockIdx.y;
+  const int chunks = D / 8;                                   // 16-byte output chunks per row
+  const int64_t n = (int64_t)Lp * chunks;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / chunks), c = (int)(i - (int64_t)r * chunks);
+    const int blk = c >> 2, q = c & 3;
+    const int t = r - pad;
+    f32x4 u = (f32x4){0.f, 0.f, 0.f, 0.f}, v = u;
+    if (t >= 0 && t < L) {
+      const float* src = x + ((int64_t)b * L + t) * D + blk * 32 + 4 * q;
+      const float4 a = *reinterpret_cast<const float4*>(src);
+      const float4 e = *reinterpret_cast<const float4*>(src + 16);
+      u = (f32x4){a.x, a.y, a.z, a.w};
+      v = (f32x4){e.x, e.y, e.z, e.w};
+    }
+    bf16x8 ph, pm, pl;
+    split8(u, v, ph, pm, pl);
+    u16* dst = planes + ((int64_t)b * Lp + r) * D + blk * 32 + q * 8;
+    *reinterpret_cast<bf16x8*>(dst) = ph;
+    *reinterpret_cast<bf16x8*>(dst + plane_stride) = pm;
+    *reinterpret_cast<bf16x8*>(dst + 2 * plane_stride) = pl;
+  }
+}
+
+}  // namespace
+
+// A = plane 0 of the pre-split operand (bf16), planes a_plane elements apart.  Requirements: K % 32 == 0,
+// kc % 32 == 0, ldw == K, all A offsets multiples of 8 elements.
+int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s) {
+  if ((d.K & 31) || (d.kc & 31) || !d.W3 || d.ldw != d.K || !d.a_split3 || d.a_plane <= 0) return DZN_E_INVALID;
+  return launch_pre_cfg<128, 64, 4, 1, 2>(d, s);   // 72 KB of LDS: two workgroups per CU
+}
+
+int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
+                           hipStream_t st) {
+  if (D % 32) return DZN_E_INVALID;
+  int64_t g = cdiv64((int64_t)Lp * (D / 8), 256);
+  g = g > 4096 ? 4096 : g;
+  hipLaunchKernelGGL(pad_rows_split3_kernel, dim3((unsigned)g, B), dim3(256), 0, st, x, static_cast<u16*>(planes),
+                     plane_stride, L, Lp, pad, D);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}

@@ -74,6 +74,10 @@ typedef struct dzn_gemm_desc {
   /* DZN_PREC_F32_SPLIT only: the weights pre-split into three bf16 planes by dzn_op_split_weights
    * (same z / row offsets as W, times 3); NULL, K % 32 or kc % 32 != 0 -> fp32 MFMA kernel */
   const void* W3;
+  /* DZN_PREC_F32_SPLIT only: A is ALREADY split — `A` points at plane 0 of three bf16 planes a_plane
+   * elements apart, written by the producer in the weight planes' k order (csrc/gemm_split_pre.hip) */
+  int32_t a_split3;
+  int64_t a_plane;
 } dzn_gemm_desc;
 
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
