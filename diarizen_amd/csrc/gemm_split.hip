@@ -306,14 +306,17 @@ int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s) {
     if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
     if (!strcmp(force, "256x128")) return launch_split_cfg<256, 128, 4, 2, 2>(d, s);
     if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
+    if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2>(d, s);
     if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2>(d, s);
   }
   if (d.N <= 32) return launch_split_cfg<128, 32, 4, 1, 2>(d, s);
   // 128x64 tiles run 4 wavefronts as 4x1 (32 rows x 64 columns each): the in-register operand
   // split is per A row, so wide-and-short wavefront tiles halve the VALU work per MFMA
   if (d.N <= 64 || d.K <= 512) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
-  // 128-wide column tiles unless 64-wide ones save more than ~1/8 of the (padded) columns
+  // 128-wide column tiles unless 64-wide ones save more than ~1/8 of the (padded) columns; widths that
+  // are multiples of 80 but not of 64 (conv1 of the extractor: 153 -> 160) get exact 80-wide tiles
   const int cols128 = (d.N + 127) / 128 * 128, cols64 = (d.N + 63) / 64 * 64;
+  if (d.N % 80 == 0 && d.N < cols64 && d.N * 9 < cols128 * 8) return launch_split_cfg<128, 80, 4, 1, 2>(d, s);
   if (cols64 * 9 < cols128 * 8) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
   return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
 }
