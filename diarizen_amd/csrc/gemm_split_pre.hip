@@ -251,8 +251,16 @@ __global__ __launch_bounds__(256) void pad_rows_split3_kernel(const float* __res
 // kc % 32 == 0, ldw == K, all A offsets multiples of 8 elements.
 int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s) {
   if ((d.K & 31) || (d.kc & 31) || !d.W3 || d.ldw != d.K || !d.a_split3 || d.a_plane <= 0) return DZN_E_INVALID;
+  static const char* force = getenv("DZN_GEMM_CFG");   // tuning knob
+  if (force && !strcmp(force, "256x128")) return launch_pre_cfg<256, 128, 4, 2, 2>(d, s);
+  if (force && !strcmp(force, "128x128")) return launch_pre_cfg<128, 128, 2, 2, 2>(d, s);
+  if (force && !strcmp(force, "128x64")) return launch_pre_cfg<128, 64, 4, 1, 2>(d, s);
+  if (d.N > 64) return launch_pre_cfg<256, 128, 4, 2, 2>(d, s);   // 144 KB of LDS, 8 wavefronts
   return launch_pre_cfg<128, 64, 4, 1, 2>(d, s);   // 72 KB of LDS: two workgroups per CU
 }
+
+extern "C" int dzn_op_split_rows(const float* x, void* planes, int64_t plane_stride, int64_t rows, int32_t D,
+                                 void* stream);
 
 int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
                            hipStream_t st) {
@@ -262,4 +270,13 @@ int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, i
   hipLaunchKernelGGL(pad_rows_split3_kernel, dim3((unsigned)g, B), dim3(256), 0, st, x, static_cast<u16*>(planes),
                      plane_stride, L, Lp, pad, D);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+// x fp32 [rows, D] -> three bf16 planes [rows, D] (plane_stride elements apart) in fragment order: the
+// pre-split A operand of gemm_split_pre.hip (tests / benchmarks; engines use the fused producers)
+extern "C" int dzn_op_split_rows(const float* x, void* planes, int64_t plane_stride, int64_t rows, int32_t D,
+                                 void* stream) {
+  if (!x || !planes || rows <= 0 || rows > 0x7fffffff) return DZN_E_INVALID;
+  return launch_pad_rows_split3(x, planes, plane_stride, 1, (int)rows, (int)rows, 0, D,
+                                reinterpret_cast<hipStream_t>(stream));
 }

@@ -24,7 +24,7 @@ def _p(t):
 def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None, ws_w=0.0,
          ws_init=False, a_rowoff=None, c_rowoff=None, lda=None, kc=0, ldk=0, ldw=None, ldc=None,
          ldws=0, act=0, alpha=1.0, post_relu=False, nz=1, zdiv=1, zs=None, precision=0,
-         W16=None, W3=None):
+         W16=None, W3=None, a_planes=None):
     """C = epilogue(A @ W^T); see dzn_gemm_desc.  A: [M, K] (or raw buffer with lda / rowoff),
     W: [N, K] fp32 (and optionally W16 bf16)."""
     lib = _lib.load()
@@ -65,6 +65,9 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
     d.c_bf16 = int(C_out.dtype == torch.bfloat16)
     d.r_bf16 = int(R is not None and R.dtype == torch.bfloat16)
     d.W3 = _p(W3)
+    if a_planes is not None:      # A pre-split by split_rows(): [3, M, K] int16 planes
+        d.A = _p(a_planes)
+        d.a_split3, d.a_plane = 1, a_planes.stride(0)
     check(lib.dzn_op_gemm(C.byref(d), _stream()), what="dzn_op_gemm")
     return C_out
 
@@ -78,6 +81,16 @@ def split_weights(W):
     out = torch.empty((rows, K // 32, 3, 32), device=W.device, dtype=torch.int16)
     check(lib.dzn_op_split_weights(_p(W), rows, K, W.stride(0), _p(out), _stream()),
           what="dzn_op_split_weights")
+    return out
+
+
+def split_rows(x):
+    """fp32 [rows, D] -> int16 [3, rows, D]: the three bf16 planes of the exact split, fragment order."""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] % 32 == 0
+    rows, D = x.shape
+    out = torch.empty((3, rows, D), device=x.device, dtype=torch.int16)
+    check(lib.dzn_op_split_rows(_p(x), _p(out), out.stride(0), rows, D, _stream()), what="dzn_op_split_rows")
     return out
 
 

@@ -86,6 +86,10 @@ int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
  * W fp32 [rows][K] (row stride ldw, K % 32 == 0) -> W3 bf16 [rows][K/32][3][32] (3*rows*K u16). */
 int dzn_op_split_weights(const float* W, int64_t rows, int32_t K, int64_t ldw, void* W3, void* stream);
 
+/* fp32 rows [rows, D] (D % 32 == 0) -> three bf16 planes [rows, D], plane_stride elements apart, channels of
+ * every 32-block in fragment order: the pre-split A operand (dzn_gemm_desc.a_split3) */
+int dzn_op_split_rows(const float* x, void* planes, int64_t plane_stride, int64_t rows, int32_t D, void* stream);
+
 /* 3x3 stride-1 convolution 32 -> 32 channels over zero-bordered fp32 NHWC images [B][Hs+2][Ws+2][32]
  * (first ResNet34 stage, wespeaker/resnet.py:139-144 with BatchNorm folded into W / bias) in the fp32-split
  * arithmetic: W3 = dzn_op_split_weights of W [32][(dh*3+dw)*32 + ci]; out = post_relu?max(0,·):(·) of

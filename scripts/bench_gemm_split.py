@@ -18,7 +18,8 @@ for spec in sys.argv[1:]:
     ref = (A[:2048].double() @ W.double().T)
     scale = (A[:2048].double().abs() @ W.double().abs().T)
     res = {}
-    for name, prec, kw in (("f32", 0, {}), ("f32s", 2, {"W3": W3})):
+    A3 = ops.split_rows(A)
+    for name, prec, kw in (("f32", 0, {}), ("f32s", 2, {"W3": W3}), ("f32sp", 2, {"W3": W3, "a_planes": A3})):
         out = torch.empty(M, N, device=dev)
         for _ in range(3):
             ops.gemm(A, W, C_out=out, precision=prec, **kw)

@@ -336,3 +336,21 @@ def test_conv3x3_c32_split(built_lib, gpu, H, W, B):
         assert _rel_err(got, ref) < 1e-5
         assert out[:, 0].abs().max() == 0 and out[:, -1].abs().max() == 0
         assert out[:, :, 0].abs().max() == 0 and out[:, :, -1].abs().max() == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 64, 256), (1000, 200, 1024), (257, 1024, 96)])
+def test_gemm_presplit_operand(built_lib, gpu, M, N, K):
+    """gemm_split_pre.hip: A handed over as three bf16 planes (dzn_op_split_rows) gives the same result as the
+    in-kernel split, to fp32 round-off, for narrow (128x64 tiles) and wide (256x128 tiles) outputs."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g))
+    W = torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T + bias.double()
+    planes = ops.split_rows(A.to(gpu))
+    rec = planes.cpu().view(torch.bfloat16).float().sum(0)                 # hi + mid + lo, fragment order
+    pos = torch.tensor([8 * ((k & 15) >> 2) + (k & 3) + 4 * (k >> 4) for k in range(32)])
+    assert torch.equal(rec.view(M, K // 32, 32)[:, :, pos].reshape(M, K), A)
+    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), precision=2, a_planes=planes)
+    assert _rel_err(out.cpu(), ref) < 1e-5
