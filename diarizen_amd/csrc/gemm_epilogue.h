@@ -1,61 +1,16 @@
 // gemm_epilogue.h — the fused epilogue shared by the fp32 contraction kernels (gemm.hip,
 // gemm_split*.hip): bias, activation, alpha, residual, post-ReLU, store, layer-weighted-sum
-// accumulate.  Operands are fed to the MFMA swapped (W as the "A" operand), so a lane owns 4
-// consecutive output columns of one row -> float4 traffic:
-// lane (lr = lane & 15, lq = lane >> 4) of a 16x16 block holds C[m = ..+lr][n0 = ..+4 lq .. +3].
+// accumulate.  The accumulator block of lane (lr, lq) is C[m = ..+lr][n0 .. n0+3] (operands are
+// fed to the MFMA swapped, so a lane owns 4 consecutive columns -> float4 traffic).
 #pragma once
 #include "common.h"
 
 namespace {
 
-// one row m, columns n0 .. n0+3 (crow = element offset of row m in C / R)
-__device__ __forceinline__ void epilogue_store4(const dzn_gemm_desc& d, const float* __restrict__ bias, bool vec,
-                                                f32x4 v, int m, int64_t crow, int n0) {
-  if (n0 >= d.N) return;
-  if (vec && n0 + 3 < d.N) {
-    if (bias) {
-      const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
-      v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act) * d.alpha;
-    if (d.R) {
-      const float4 r4 = *reinterpret_cast<const float4*>(d.R + crow + n0);
-      v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-    }
-    if (d.post_relu) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-    *reinterpret_cast<float4*>(d.C + crow + n0) = make_float4(v[0], v[1], v[2], v[3]);
-    if (d.WS) {
-      float4* w = reinterpret_cast<float4*>(d.WS + (int64_t)m * d.ldws + n0);
-      float4 a = d.ws_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *w;
-      a.x += d.ws_w * v[0]; a.y += d.ws_w * v[1]; a.z += d.ws_w * v[2]; a.w += d.ws_w * v[3];
-      *w = a;
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int n = n0 + e;
-      if (n >= d.N) continue;
-      float x = v[e];
-      if (bias) x += bias[n];
-      x = apply_act(x, d.act) * d.alpha;
-      if (d.R) x += d.R[crow + n];
-      if (d.post_relu) x = fmaxf(x, 0.f);
-      d.C[crow + n] = x;
-      if (d.WS) {
-        float* w = d.WS + (int64_t)m * d.ldws + n;
-        *w = d.ws_init ? d.ws_w * x : (*w + d.ws_w * x);
-      }
-    }
-  }
-}
-
 template <int BM, int BN, int TM, int TN, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
                                               int wm, int wn, int lr, int lq, int64_t cz, int64_t bz) {
+  // ---- epilogue: lane (lr, lq) of block (i, j) holds row m = ..+lr, columns n0..n0+3 ----
   const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
   const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0;
 #pragma unroll
@@ -64,8 +19,50 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     if (m >= d.M) continue;
     const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-      epilogue_store4(d, bias, vec, acc[i][j], m, crow, tn * BN + wn * TN + j * 16 + lq * 4);
+    for (int j = 0; j < NI; ++j) {
+      const int n0 = tn * BN + wn * TN + j * 16 + lq * 4;
+      if (n0 >= d.N) continue;
+      f32x4 v = acc[i][j];
+      if (vec && n0 + 3 < d.N) {
+        if (bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act) * d.alpha;
+        if (d.R) {
+          const float4 r4 = *reinterpret_cast<const float4*>(d.R + crow + n0);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        if (d.post_relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<float4*>(d.C + crow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+        if (d.WS) {
+          float4* w = reinterpret_cast<float4*>(d.WS + (int64_t)m * d.ldws + n0);
+          float4 a = d.ws_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *w;
+          a.x += d.ws_w * v[0]; a.y += d.ws_w * v[1]; a.z += d.ws_w * v[2]; a.w += d.ws_w * v[3];
+          *w = a;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0 + e;
+          if (n >= d.N) continue;
+          float x = v[e];
+          if (bias) x += bias[n];
+          x = apply_act(x, d.act) * d.alpha;
+          if (d.R) x += d.R[crow + n];
+          if (d.post_relu) x = fmaxf(x, 0.f);
+          d.C[crow + n] = x;
+          if (d.WS) {
+            float* w = d.WS + (int64_t)m * d.ldws + n;
+            *w = d.ws_init ? d.ws_w * x : (*w + d.ws_w * x);
+          }
+        }
+      }
+    }
   }
 }
 
