@@ -259,3 +259,21 @@ def test_seg_config_from_checkpoint_kwargs_matches_named_configs(tmp_path):
     assert m.cfg.ffn_dims == get_seg_config("wavlm_base").ffn_dims and m.num_frames(80000) == 249
     with pytest.raises(RuntimeError):
         m.to("cpu")                      # no CPU fallback, loudly
+
+
+# ----------------------------------------------------------------------------- build hygiene
+@pytest.mark.parametrize("src", ["gemm.hip", "gemm_split.hip", "gemm_split_pre.hip", "conv_split.hip"])
+def test_contraction_kernels_do_not_spill(src):
+    """The contraction kernels keep their accumulators in registers: hipcc must report ScratchSize 0 for every
+    kernel of these files (a fused-epilogue change once sent the 128x192 accumulators to scratch and cost 60 %)."""
+    import re
+    import shutil
+    import subprocess
+    from diarizen_amd import build as b
+    if not shutil.which(b.HIPCC) and not os.path.exists(b.HIPCC):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([b.HIPCC, *b.FLAGS, "-c", str(b.CSRC / src), "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert sizes and max(sizes) == 0, f"scratch in {src}: {sorted(set(sizes))}"
