@@ -261,6 +261,51 @@ def test_seg_config_from_checkpoint_kwargs_matches_named_configs(tmp_path):
         m.to("cpu")                      # no CPU fallback, loudly
 
 
+def test_host_stage_silence_and_single_speaker():
+    """edge cases of the host stage: no active speaker anywhere -> empty Annotation (the reference takes the
+    `max_clusters < 2` exit of BaseClustering.__call__, PA/pipelines/clustering.py:268-276, then every cluster
+    is -2); exactly one active (window, speaker) -> one cluster, one turn."""
+    import warnings
+    from diarizen_amd import clustering as cl
+    from diarizen_amd.core import SlidingWindow
+    from diarizen_amd.postprocess import binarize, receptive_field, reconstruct, speaker_count
+    C, L = 5, 399
+    g = np.random.default_rng(0)
+    emb = g.normal(size=(C, 4, 256)).astype(np.float32)
+    chunks, frames = SlidingWindow(start=0.0, duration=8.0, step=0.8), receptive_field(16000)
+
+    def run(seg):
+        count = speaker_count(seg, chunks, frames)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")       # mean of an empty training set, as in the reference
+            hard, _, _ = cl.AgglomerativeClustering(threshold=0.7)(embeddings=emb.copy(), segmentations=seg,
+                                                                     min_clusters=1, max_clusters=20)
+        count.data = np.minimum(count.data, 20).astype(np.int8)
+        hard = np.array(hard, copy=True)
+        hard[np.sum(seg, axis=1) == 0] = -2
+        disc, _ = reconstruct(seg, chunks, hard, count)
+        return binarize(disc, onset=0.5, offset=0.5, uri="x")
+
+    silent = np.zeros((C, L, 4), np.float32)
+    ann = run(silent)
+    assert len(list(ann.itertracks())) == 0 and ann.to_rttm() == ""
+    # a single (window, speaker) activation is out-voted by the 4 other windows covering the same time
+    one = silent.copy()
+    one[2, 50:200, 1] = 1.0
+    assert len(list(run(one).itertracks())) == 0
+    # the same 2 s of speech seen by all 5 windows, in a different local slot each: one speaker, one turn
+    proto = g.normal(size=256).astype(np.float32)
+    allw = silent.copy()
+    for c in range(C):
+        a, b = int(round((3.5 - 0.8 * c) / 0.02)), int(round((5.5 - 0.8 * c) / 0.02))
+        allw[c, a:b, c % 4] = 1.0
+        emb[c, c % 4] = proto + 0.05 * g.normal(size=256).astype(np.float32)
+    ann = run(allw)
+    tracks = list(ann.itertracks(yield_label=True))
+    assert len(tracks) == 1 and len(ann.labels()) == 1
+    assert abs(tracks[0][0].start - 3.5) < 0.06 and abs(tracks[0][0].end - 5.5) < 0.06
+
+
 # ----------------------------------------------------------------------------- build hygiene
 @pytest.mark.parametrize("src", ["gemm.hip", "gemm_split.hip", "gemm_split_pre.hip", "conv_split.hip"])
 def test_contraction_kernels_do_not_spill(src):
