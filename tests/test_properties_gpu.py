@@ -17,14 +17,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def engine(built_lib, gpu):
+@pytest.fixture(scope="module", params=["f32s", "f32"])
+def engine(built_lib, gpu, request):
     from diarizen_amd.configs import RESNET34, get_seg_config
     from diarizen_amd.engine import Engine
     from diarizen_amd.weights import emb_state_dict, seg_state_dict
     cfg = get_seg_config("wavlm_large_s80_md")
     return Engine(cfg, seg_state_dict(cfg, 0), RESNET34, emb_state_dict(0), max_batch=48,
-                  max_samples=128000, precision="f32", device=gpu)
+                  max_samples=128000, precision=request.param, device=gpu)
 
 
 def _recording(seconds, seed=5):
@@ -99,3 +99,26 @@ def test_ragged_recordings_follow_reference_window_plan(engine, gpu, seconds, ex
     filt, _ = engine.prepare_masks(ml, 11, True, 2, want_masks=False)
     torch.cuda.synchronize()
     assert torch.equal(filt[0], res.segmentations[-1])
+
+
+def test_degenerate_waveforms_match_oracle(engine, gpu):
+    """digital silence, a DC offset and a full-scale clipped square wave: finite outputs, strict parity with the
+    oracle (the waveform LayerNorm divides by sqrt(var + eps) with var == 0 on the first two)."""
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.weights import seg_state_dict
+    from oracle import seg_model
+    cfg = get_seg_config("wavlm_large_s80_md")
+    sd = seg_state_dict(cfg, 0)
+    N = 16000
+    t = torch.arange(N) / 16000.0
+    wave = torch.stack([torch.zeros(N), torch.full((N,), 0.25), torch.sign(torch.sin(2 * np.pi * 220.0 * t))])
+    logp, ml = engine.segment(wave.to(gpu))
+    torch.cuda.synchronize()
+    assert torch.isfinite(logp).all()
+    ref = seg_model.seg_forward(sd, cfg, wave)
+    assert (logp.cpu() - ref).abs().max().item() < 1e-3
+    assert torch.equal(ml.cpu(), seg_model.to_multilabel(ref, cfg).to(torch.uint8))
+    masks = torch.ones(3, 4, logp.shape[1], device=gpu)
+    emb = engine.embed(wave.to(gpu), masks)
+    torch.cuda.synchronize()
+    assert torch.isfinite(emb).all()
