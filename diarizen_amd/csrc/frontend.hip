@@ -36,11 +36,15 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
   const float* wp = wave + (int64_t)b * N + (int64_t)f0 * s;
   for (int i = tid; i < nsamp; i += 256) sx[i] = (wp[i] - mean) * rstd;
 
+  // lane -> channels 4*lane + e + 256*g (e = j % 4, g = j / 4): four consecutive channels per lane, so a
+  // frame leaves as 16-byte stores (1 KiB contiguous per wavefront instruction; dword stores ran the
+  // HBM write stream at 2.8 TB/s, float4 stores reach > 4)
+  static_assert(CPL % 4 == 0, "channels per lane in groups of 4");
   float wr[CPL][10];
   float gr[CPL], br[CPL];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
-    const int c = lane + 64 * j;
+    const int c = 256 * (j >> 2) + 4 * lane + (j & 3);
 #pragma unroll
     for (int t = 0; t < 10; ++t) wr[j][t] = (c < C0 && t < k) ? w[c * k + t] : 0.f;
     gr[j] = (LN && c < C0) ? gamma[c] : 1.f;
@@ -63,31 +67,35 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
       sum += a;  // channels >= C0 have zero taps -> contribute 0
     }
     TO* op = out + ((int64_t)b * T0 + f0 + f) * Cp;
+    float mu = 0.f, rs = 1.f;
     if constexpr (LN) {
-      const float mu = wave_sum(sum) / (float)C0;
+      mu = wave_sum(sum) / (float)C0;
       float sq = 0.f;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        const float d = (lane + 64 * j < C0) ? acc[j] - mu : 0.f;
+        const float d = (256 * (j >> 2) + 4 * lane + (j & 3) < C0) ? acc[j] - mu : 0.f;
         sq += d * d;
       }
-      const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)C0 + eps);
+      rs = 1.0f / sqrtf(wave_sum(sq) / (float)C0 + eps);
+    }
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const int c = lane + 64 * j;
-        if (c < C0)
-          st_act(op, c, gelu_erf((acc[j] - mu) * rs * gr[j] + br[j]));
-        else if (c < Cp)
-          st_act(op, c, 0.f);
+    for (int g = 0; g < CPL / 4; ++g) {
+      const int c0 = 256 * g + 4 * lane;
+      if (c0 >= Cp) continue;          // Cp % 4 == 0: a group is entirely inside or outside the padded row
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = 4 * g + e;
+        float v = LN ? gelu_erf((acc[j] - mu) * rs * gr[j] + br[j]) : acc[j];
+        o[e] = (c0 + e < C0) ? v : 0.f;
       }
-    } else {
+      if constexpr (sizeof(TO) == 4) {
+        *reinterpret_cast<float4*>(op + c0) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        u16 h[4];
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const int c = lane + 64 * j;
-        if (c < C0)
-          st_act(op, c, acc[j]);
-        else if (c < Cp)
-          st_act(op, c, 0.f);
+        for (int e = 0; e < 4; ++e) st_act(h, e, o[e]);
+        *reinterpret_cast<ushort4*>(op + c0) = make_ushort4(h[0], h[1], h[2], h[3]);
       }
     }
   }
@@ -203,7 +211,7 @@ int conv0_dispatch(const float* wave, int B, int N, const float* stats, const fl
                    const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
                    int layer_norm, float eps, TO* out, hipStream_t st) {
   dim3 grid((T0 + FR_PER_BLOCK - 1) / FR_PER_BLOCK, B);
-  const int cpl = (max(C0, Cp) + 63) / 64;
+  const int width = max(C0, Cp);   // a lane owns 4 consecutive channels per 256-channel group
 #define DZN_C0(CPLV)                                                                                  \
   do {                                                                                                \
     if (layer_norm)                                                                                   \
@@ -213,9 +221,7 @@ int conv0_dispatch(const float* wave, int B, int N, const float* stats, const fl
       hipLaunchKernelGGL((conv0_kernel<CPLV, false, TO>), grid, dim3(256), 0, st, wave, N, stats, w,  \
                          gamma, beta, C0, Cp, k, s, T0, eps, out);                                    \
   } while (0)
-  if (cpl <= 1) DZN_C0(1);
-  else if (cpl <= 2) DZN_C0(2);
-  else if (cpl <= 4) DZN_C0(4);
+  if (width <= 256) DZN_C0(4);
   else DZN_C0(8);
 #undef DZN_C0
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
