@@ -6,7 +6,7 @@
 // lo needs <= 8 significant bits, so the decomposition is EXACT).  A product a*w is then
 //     a_hi w_hi + (a_hi w_mid + a_mid w_hi) + (a_hi w_lo + a_mid w_mid + a_lo w_hi)  [+ O(2^-24) terms]
 // i.e. six v_mfma_f32_16x16x32_bf16 products accumulated in fp32; the three dropped cross terms
-// (mid*lo, lo*mid, lo*lo) are bounded by 2^-23 |a w| — the size of one fp32 rounding of the
+// (mid*lo, lo*mid, lo*lo) are bounded by 2^-22 |a w| — the size of one or two fp32 roundings of the
 // product.  6 bf16 MFMAs of 16 cycles replace 8 fp32 MFMAs (16x16x4) of 32 cycles for the same
 // 16x16x32 block: 2.67x less matrix-pipe time at fp32-grade accuracy (tests/test_ops_gpu.py
 // measures both kernels against a float64 product).
