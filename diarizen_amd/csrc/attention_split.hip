@@ -280,13 +280,12 @@ int launch_attention_split(const float* qkv, float* out, const float* gate, cons
   const bool bias = gate && table && head_idx;
   const size_t lds = 6 * ATT_PLANE + (bias ? (2 * L - 1) : 0) * sizeof(float);
   if (lds > 160 * 1024) return DZN_E_INVALID;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
+  if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   dim3 grid((L + 63) / 64, h, B);
   const int pid = prof_begin(s, bias ? "attention_relpos_f32s" : "attention_f32s",

@@ -146,5 +146,15 @@ bool prof_enabled();
 int prof_begin(hipStream_t st, const char* cls, double flops, double bytes);
 void prof_end(int id, hipStream_t st);
 
+// true exactly once per (call site, HIP device): hipFuncSetAttribute is per device
+static inline bool first_use_on_device(unsigned long long& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -200,12 +200,11 @@ int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias,
                              int Hs, int Ws, int relu, int post_relu, hipStream_t s) {
   if (B <= 0 || Hs <= 0 || Ws <= 0) return DZN_OK;
   if (!in || !W3 || !bias || !out) return DZN_E_INVALID;
-  static bool attr_set = false;
+  static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
   const size_t lds = 3 * CS_PLANE;
-  if (!attr_set) {
+  if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_split_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   ConvArgs a{in, static_cast<const u16*>(W3), bias, R, out, B, Hs, Ws, relu, post_relu};
   const int64_t ntiles = (int64_t)((Hs * (Ws + 2) + CS_TP - 1) / CS_TP) * B;

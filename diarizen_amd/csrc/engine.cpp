@@ -41,6 +41,21 @@ struct EngineError : std::runtime_error {
   EngineError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
 
+// Makes the handle's device current for the duration of a C-ABI call and restores the caller's
+// (lazy allocations, table uploads and kernel launches must not land on whatever device the calling
+// thread happens to have current — e.g. DiariZenPipeline(device="cuda:1") in a process at device 0).
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 struct HostT {
   std::vector<float> v;
   std::vector<int64_t> shape;
@@ -91,6 +106,7 @@ std::string last_create_error;
 
 struct dzn_handle {
   dzn_config cfg{};
+  int device = 0;  // HIP device current at dzn_create: every entry point makes it current again
   std::string err;
   std::map<std::string, HostT> sd;
   std::set<std::string> used;
@@ -147,8 +163,13 @@ struct dzn_handle {
   float* sbuf[4][3]{};
   int64_t sbuf_elems[4]{};  // allocation per image at the largest geometry
   int64_t simg[4]{};        // elements per image at the current geometry
-  int32_t* tab1[4]{};
+  int32_t* tab1[4]{};   // tables of the CURRENT geometry (owned by geoms)
   int32_t* tab2[4]{};
+  struct EmbGeom {      // per fbank-frame-count T: row-offset tables stay resident, so alternating window
+    int32_t* t1[4]{};   // lengths (full windows / a ragged tail) neither re-upload nor synchronise
+    int32_t* t2[4]{};
+  };
+  std::map<int, EmbGeom> geoms;
   float *frames = nullptr, *spec = nullptr, *pw = nullptr, *fb = nullptr, *pool = nullptr;
 };
 
@@ -670,19 +691,22 @@ void finalize_emb(H* h) {
     }
     h->sbuf_elems[s] = (int64_t)(Hs + 2) * (Ws + 2) * h->sC[s];
     for (int k = 0; k < 3; ++k) h->sbuf[s][k] = dalloc<float>(h, B * h->sbuf_elems[s]);
-    h->tab1[s] = dalloc<int32_t>(h, (int64_t)Hs * Ws);
-    h->tab2[s] = dalloc<int32_t>(h, (int64_t)Hs * Ws);
   }
   h->pool = dalloc<float>(h, B * 8 * feat);
 }
 
-// bake the geometry of T fbank frames into the row-offset tables and re-zero image borders
+// bake the geometry of T fbank frames into the row-offset tables and re-zero the image borders.
+// Tables are built once per T and stay on the device; a later switch back to that T is two async
+// operations on the caller's stream (no host synchronisation, no upload).
 void emb_set_geometry(H* h, int T, hipStream_t st) {
   if (T == h->emb_T) return;
-  HIPCHK(hipStreamSynchronize(st));
   const int64_t B = h->cfg.max_batch;
   int Hs = h->cfg.num_mel_bins, Ws = T;
   int Hp = 0, Wp = 0;
+  auto it = h->geoms.find(T);
+  const bool fresh = it == h->geoms.end();
+  if (fresh && h->geoms.size() >= 64) throw EngineError(DZN_E_INVALID, "too many distinct window lengths on one handle");
+  H::EmbGeom& gm = h->geoms[T];
   for (int s = 0; s < 4; ++s) {
     if (s > 0) {
       Hp = Hs;
@@ -694,16 +718,22 @@ void emb_set_geometry(H* h, int T, hipStream_t st) {
     h->sW[s] = Ws;
     const int Cc = h->sC[s];
     h->simg[s] = (int64_t)(Hs + 2) * (Ws + 2) * Cc;
-    std::vector<int32_t> t1((size_t)Hs * Ws), t2((size_t)Hs * Ws, 0);
-    for (int y = 0; y < Hs; ++y)
-      for (int x = 0; x < Ws; ++x) {
-        t1[(size_t)y * Ws + x] = (y * (Ws + 2) + x) * Cc;  // top-left of the 3x3 patch
-        if (s > 0) t2[(size_t)y * Ws + x] = ((2 * y) * (Wp + 2) + 2 * x) * h->sC[s - 1];
-      }
-    HIPCHK(hipMemcpy(h->tab1[s], t1.data(), t1.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->tab2[s], t2.data(), t2.size() * 4, hipMemcpyHostToDevice));
+    if (fresh) {
+      std::vector<int32_t> t1((size_t)Hs * Ws), t2((size_t)Hs * Ws, 0);
+      for (int y = 0; y < Hs; ++y)
+        for (int x = 0; x < Ws; ++x) {
+          t1[(size_t)y * Ws + x] = (y * (Ws + 2) + x) * Cc;  // top-left of the 3x3 patch
+          if (s > 0) t2[(size_t)y * Ws + x] = ((2 * y) * (Wp + 2) + 2 * x) * h->sC[s - 1];
+        }
+      gm.t1[s] = dalloc<int32_t>(h, (int64_t)Hs * Ws, false);
+      gm.t2[s] = dalloc<int32_t>(h, (int64_t)Hs * Ws, false);
+      HIPCHK(hipMemcpy(gm.t1[s], t1.data(), t1.size() * 4, hipMemcpyHostToDevice));  // synchronous, first use only
+      HIPCHK(hipMemcpy(gm.t2[s], t2.data(), t2.size() * 4, hipMemcpyHostToDevice));
+    }
+    h->tab1[s] = gm.t1[s];
+    h->tab2[s] = gm.t2[s];
     for (int k = 0; k < 3; ++k)
-      HIPCHK(hipMemset(h->sbuf[s][k], 0, B * h->sbuf_elems[s] * sizeof(float)));
+      HIPCHK(hipMemsetAsync(h->sbuf[s][k], 0, B * h->sbuf_elems[s] * sizeof(float), st));
   }
   h->emb_T = T;
 }
@@ -1218,6 +1248,7 @@ int dzn_create(const dzn_config* cfg, dzn_handle** out) {
   dzn_handle* h = new (std::nothrow) dzn_handle();
   if (!h) return DZN_E_NOMEM;
   h->cfg = *cfg;
+  if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
   const char* dbg = getenv("DZN_DEBUG_TAPS");
   h->debug = dbg && dbg[0] == '1';
   *out = h;
@@ -1261,6 +1292,7 @@ int dzn_finalize_weights(dzn_handle* h) {
     h->err = "already finalized";
     return DZN_E_STATE;
   }
+  DeviceGuard dg(h->device);
   int rc = guarded(h, [&] {
     finalize_seg(h);
     h->has_emb = h->cfg.has_embedding != 0;
@@ -1293,6 +1325,7 @@ int dzn_segment_forward(dzn_handle* h, const float* d_wave, int32_t B, int32_t N
     h->err = "bad B / N (exceeds max_batch / max_samples?)";
     return DZN_E_INVALID;
   }
+  DeviceGuard dg(h->device);
   return guarded(h, [&] {
     seg_forward(h, d_wave, B, N, d_logp, d_multilabel, reinterpret_cast<hipStream_t>(hip_stream));
   });
@@ -1310,6 +1343,7 @@ int dzn_embed_forward(dzn_handle* h, const float* d_wave, const float* d_masks, 
     h->err = "bad arguments to dzn_embed_forward";
     return DZN_E_INVALID;
   }
+  DeviceGuard dg(h->device);
   return guarded(h, [&] {
     emb_forward(h, d_wave, d_masks, B, S, N, L, d_emb, reinterpret_cast<hipStream_t>(hip_stream));
   });
@@ -1319,6 +1353,15 @@ int dzn_prepare_masks(dzn_handle* h, const uint8_t* d_multilabel, int32_t B, int
                       int32_t median_size, int32_t exclude_overlap, int32_t min_num_frames,
                       uint8_t* d_filtered, float* d_masks, void* hip_stream) {
   if (!h || !d_multilabel) return DZN_E_INVALID;
+  if (!h->finalized) {
+    h->err = "dzn_prepare_masks before dzn_finalize_weights";
+    return DZN_E_STATE;
+  }
+  if (B < 1 || B > h->cfg.max_batch || L < 1 || (!d_filtered && !d_masks)) {
+    h->err = "bad arguments to dzn_prepare_masks (B exceeds max_batch?)";
+    return DZN_E_INVALID;
+  }
+  DeviceGuard dg(h->device);
   return guarded(h, [&] {
     chk(launch_prepare_masks(d_multilabel, B, L, h->cfg.max_speakers_per_chunk, median_size,
                              exclude_overlap, min_num_frames, d_filtered, d_masks,
@@ -1351,6 +1394,7 @@ const char* dzn_last_error(const dzn_handle* h) {
 
 int dzn_destroy(dzn_handle* h) {
   if (!h) return DZN_OK;
+  DeviceGuard dg(h->device);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return DZN_OK;

@@ -354,14 +354,13 @@ int launch_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   static const int lds_pad = getenv("DZN_GEMM_LDS_PAD") ? atoi(getenv("DZN_GEMM_LDS_PAD")) : 0;
   const size_t lds = 2 * (BM + BN) * 128 + lds_pad;
   auto kern = gemm_kernel<BM, BN, WGM, WGN, LOWP>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
+  if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (!LOWP)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<BM, BN, WGM, WGN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   static const bool no_glds = getenv("DZN_NO_GLDS") != nullptr;
   const bool use_glds = !LOWP && !no_glds && (d.K % 32 == 0) && (d.kc % 32 == 0);

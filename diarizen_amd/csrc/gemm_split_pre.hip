@@ -194,11 +194,10 @@ int launch_pre_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
   const size_t lds = (size_t)S * 3 * (BM + BN) * 64;
   auto kern = gemm_split_pre_kernel<BM, BN, WGM, WGN, S>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
+  if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    attr_set = true;
   }
   dim3 grid(tilesM * tilesN, d.nz > 0 ? d.nz : 1, 1);
   int pid = -1;

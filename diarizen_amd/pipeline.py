@@ -43,6 +43,24 @@ def _load_checkpoint(path: str) -> Dict[str, torch.Tensor]:
     return ckpt
 
 
+def run_host_stage(seg: np.ndarray, emb: np.ndarray, *, chunks: SlidingWindow, clustering, min_speakers: int,
+                   max_speakers: int, sample_rate: int = 16000, sess_name: Optional[str] = None) -> Annotation:
+    """The host half of `DiariZenPipeline.__call__` (diarizen/pipelines/inference.py:137-185): speaker
+    counting -> clustering -> inactive speakers to -2 -> reconstruction -> Binarize.  Needs no device, so
+    it is checked on the CPU against the oracle's loop-for-loop restatement (tests/test_host.py)."""
+    frames = receptive_field(sample_rate)
+    segf = seg.astype(np.float32)
+    count = speaker_count(segf, chunks, frames)
+    hard, _, _ = clustering(embeddings=emb.astype(np.float64) if emb.dtype != np.float32 else emb,
+                            segmentations=segf, min_clusters=min_speakers, max_clusters=max_speakers)
+    count.data = np.minimum(count.data, max_speakers).astype(np.int8)
+    inactive = np.sum(segf, axis=1) == 0
+    hard = np.array(hard, copy=True)
+    hard[inactive] = -2
+    discrete, _ = reconstruct(segf, chunks, hard, count)
+    return binarize(discrete, onset=0.5, offset=0.5, uri=sess_name)
+
+
 class DiariZenPipeline:
     def __init__(self, diarizen_hub, embedding_model, config_parse: Optional[Dict[str, Any]] = None,
                  rttm_out_dir: Optional[str] = None, *, device: Optional[torch.device] = None,
@@ -147,19 +165,9 @@ class DiariZenPipeline:
 
     def host_stage(self, seg: np.ndarray, emb: np.ndarray, sess_name: Optional[str] = None) -> Annotation:
         """counting -> clustering -> reconstruction -> Annotation (inference.py:137-185)."""
-        chunks = self.chunks_window()
-        frames = receptive_field(self.segmentation_model.sample_rate)
-        segf = seg.astype(np.float32)
-        count = speaker_count(segf, chunks, frames)
-        hard, _, _ = self.clustering(embeddings=emb.astype(np.float64) if emb.dtype != np.float32 else emb,
-                                     segmentations=segf, min_clusters=self.min_speakers,
-                                     max_clusters=self.max_speakers)
-        count.data = np.minimum(count.data, self.max_speakers).astype(np.int8)
-        inactive = np.sum(segf, axis=1) == 0
-        hard = np.array(hard, copy=True)
-        hard[inactive] = -2
-        discrete, _ = reconstruct(segf, chunks, hard, count)
-        return binarize(discrete, onset=0.5, offset=0.5, uri=sess_name)
+        return run_host_stage(seg, emb, chunks=self.chunks_window(), clustering=self.clustering,
+                              min_speakers=self.min_speakers, max_speakers=self.max_speakers,
+                              sample_rate=self.segmentation_model.sample_rate, sess_name=sess_name)
 
     # ------------------------------------------------------------------ __call__
     def __call__(self, in_wav, sess_name: Optional[str] = None) -> Annotation:

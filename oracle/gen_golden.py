@@ -138,6 +138,45 @@ def gen_seg():
               f"{np.bincount(logp.argmax(-1).flatten().numpy(), minlength=cfg.n_classes).tolist()}")
 
 
+def tt_windows(starts, N: int) -> torch.Tensor:
+    """windows of tests/golden/EN2002a_30s.wav starting at `starts` (samples)"""
+    from diarizen_amd.audio import first_channel_16k
+    wave = torch.from_numpy(first_channel_16k(str(GOLD / "EN2002a_30s.wav")))
+    return torch.stack([wave[s:s + N] for s in starts])
+
+
+# turn-taking (non-degenerate) fixtures: config -> (N, window starts).  Includes BASELINE configs[1] at full
+# size (wavlm-base-s80, 5 s windows, batch 32) and the bench geometry (large-s80, 8 s windows).
+TT_CASES = {
+    "tiny_ln": (8000, [32000, 96000]),
+    "tiny_gn": (8000, [48000, 160000]),
+    "wavlm_large_s80_md": (128000, [0, 192000]),
+    "wavlm_base_s80_md": (80000, [8000 * i for i in range(32)]),
+}
+
+
+def gen_seg_tt():
+    """Reference modules (strict state_dict load) with the seeded turn-taking weights on real audio: logp
+    goldens whose argmax is NOT constant (asserted), at the sizes BASELINE.json names."""
+    from diarizen_amd.weights import turn_taking_state_dict
+    for name, (N, starts) in TT_CASES.items():
+        cfg = get_seg_config(name)
+        sd = turn_taking_state_dict(cfg, 0)
+        fwd = build_reference_seg(cfg, sd)
+        wave = tt_windows(starts, N)
+        outs = [fwd(wave[b0:b0 + 8])[0] for b0 in range(0, len(starts), 8)]
+        logp = torch.cat(outs)
+        am = logp.argmax(-1).numpy()
+        hist = np.bincount(am.ravel(), minlength=cfg.n_classes)
+        srt = np.sort(logp.numpy(), -1)
+        margin = srt[..., -1] - srt[..., -2]
+        print(f"seg_tt_{name}: logp {tuple(logp.shape)} argmax hist {hist.tolist()} "
+              f"transitions/window {(am[:, 1:] != am[:, :-1]).sum(1).mean():.1f} min top-2 margin {margin.min():.2e}")
+        assert (hist > 0).sum() >= 5, "degenerate fixture"
+        np.savez_compressed(GOLD / f"seg_tt_{name}.npz", N=N, starts=np.array(starts), weight_seed=0,
+                            logp=logp.numpy(), min_margin=margin.min())
+
+
 # ------------------------------------------------------------------ embedding model
 def load_reference_resnet():
     """wespeaker/resnet.py + blocks/pooling.py + utils/receptive_field.py by file path, with
@@ -318,17 +357,49 @@ E2E_CONFIG = {
     "inference": {"args": {"seg_duration": 8, "segmentation_step": 0.1, "batch_size": 32,
                            "apply_median_filtering": True}},
     "clustering": {"args": {"method": "AgglomerativeClustering", "min_speakers": 1, "max_speakers": 20,
-                            "ahc_criterion": "distance", "ahc_threshold": 0.7, "min_cluster_size": 3}},
+                            "ahc_criterion": "distance", "ahc_threshold": 0.1, "min_cluster_size": 3}},
 }
 
 
+def mask_branches(seg: np.ndarray, window: int):
+    """(number of (window, speaker) pairs that use the overlap-excluded mask, number that fall back to
+    the full mask although active) — PA/pipelines/speaker_diarization.py:268-322."""
+    import math
+    L = seg.shape[1]
+    min_num_frames = math.ceil(L * 400 / window)
+    segf = seg.astype(np.float32)
+    clean = segf * (segf.sum(2, keepdims=True) < 2)
+    use_clean = clean.sum(1) > min_num_frames
+    active = segf.sum(1) > 0
+    return int(use_clean.sum()), int((active & ~use_clean).sum())
+
+
+def decision_stats(seg: np.ndarray) -> dict:
+    """non-degeneracy report of hard decisions [C, L, S] (VERDICT r1 'next' #1)."""
+    code = (seg.astype(np.int64) * (1 << np.arange(seg.shape[2]))).sum(2)       # one int per powerset class
+    vals, cnt = np.unique(code, return_counts=True)
+    frac = cnt / code.size
+    trans = (code[:, 1:] != code[:, :-1]).sum(1)
+    return {"classes": int(len(vals)), "classes_ge_5pct": int((frac >= 0.05).sum()),
+            "min_transitions_per_window": int(trans.min()), "mean_transitions_per_window": float(trans.mean()),
+            "overlap_frac": float((seg.sum(2) >= 2).mean()), "silence_frac": float((seg.sum(2) == 0).mean())}
+
+
+E2E_VBX = {"ahc_threshold": 0.1, "Fa": 0.07, "Fb": 0.8, "lda_dim": 128, "max_iters": 20}
+
+
 def gen_e2e():
-    """example/EN2002a_30s.wav through the oracle device stage (reference execution order, seeded
-    random weights) -> per-window decisions, embeddings.  The wav itself (a data fixture of the
-    reference, not source) is copied next to the goldens so the GPU box can read it."""
+    """example/EN2002a_30s.wav through the oracle device stage (reference execution order) with the
+    seeded TURN-TAKING weights (diarizen_amd/weights.py:turn_taking_state_dict — plain random weights emit one
+    class for every frame) -> per-window decisions + embeddings; then the host stage: the REFERENCE's own
+    clustering module on those outputs + the loop-for-loop restatement oracle/host_stage.py -> golden RTTM.
+    The wav itself (a data fixture of the reference, not source) sits next to the goldens so the GPU box
+    can read it."""
+    import copy
     import shutil
     from diarizen_amd.audio import first_channel_16k
-    from diarizen_amd.weights import emb_state_dict
+    from diarizen_amd.weights import emb_state_dict, turn_taking_state_dict
+    from oracle import host_stage
     from oracle.pipeline import device_stage_reference
     _ref_path()
     src = REF / "example" / "EN2002a_30s.wav"
@@ -337,14 +408,56 @@ def gen_e2e():
         shutil.copyfile(src, dst)
     wave = torch.from_numpy(first_channel_16k(str(dst)))
     cfg = get_seg_config("wavlm_large_s80_md")
-    sd = seg_model.seg_state_dict(cfg, 0)
+    sd = turn_taking_state_dict(cfg, 0)
     esd = emb_state_dict(0)
     seg, emb = device_stage_reference(wave, cfg, sd, esd, duration=8.0, verbose=True)
-    np.savez_compressed(GOLD / "e2e_EN2002a_30s.npz", seg=seg, emb=emb, weight_seed=0)
-    print("e2e:", seg.shape, emb.shape, "active (window,speaker) pairs:", int((seg.sum(1) > 0).sum()))
+    st = decision_stats(seg)
+    n_clean, n_fallback = mask_branches(seg, 128000)
+    print("e2e decisions:", st, "mask branches clean/fallback:", n_clean, n_fallback)
+    assert st["classes_ge_5pct"] >= 6 and st["min_transitions_per_window"] >= 5, "degenerate fixture"
+    assert n_clean > 0 and n_fallback > 0, "both mask branches must occur in the fixture"
+    # host stage: reference clustering (PA/pipelines/clustering.py) + restated loops
+    cl = load_reference_clustering()
+    clu = E2E_CONFIG["clustering"]["args"]
+    ahc = cl.AgglomerativeClustering(metric="cosine")
+    ahc.method, ahc.threshold, ahc.min_cluster_size = "centroid", clu["ahc_threshold"], clu["min_cluster_size"]
+    swf = types.SimpleNamespace(data=seg.astype(np.float32))
+    hard, _, _ = ahc(embeddings=emb.copy(), segmentations=swf, min_clusters=clu["min_speakers"],
+                     max_clusters=clu["max_speakers"])
+    # the seeded ResNet's embeddings carry little speaker structure (pairwise distances 0.1-0.2), hence the
+    # low ahc_threshold of E2E_CONFIG; the fixture must not sit on a clustering near-tie: 100x the GPU's
+    # embedding error must leave the hard clusters unchanged
+    r = np.random.default_rng(0)
+    for _ in range(8):
+        pert = (emb * (1 + 1e-4 * r.normal(size=emb.shape))).astype(np.float32)
+        h2, _, _ = ahc(embeddings=pert, segmentations=swf, min_clusters=clu["min_speakers"],
+                       max_clusters=clu["max_speakers"])
+        assert np.array_equal(h2, hard), "clustering of the fixture is not robust to 1e-4 perturbations"
+    rttm = host_stage.host_stage(seg, hard, 8.0, 0.1, clu["max_speakers"], "EN2002a")
+    speakers = sorted({ln.split()[7] for ln in rttm.splitlines()})
+    print("e2e:", seg.shape, emb.shape, "clusters:", int(hard.max()) + 1, "RTTM speakers:", speakers,
+          "lines:", len(rttm.splitlines()))
+    assert len(speakers) >= 3, "fixture must have >= 3 speakers in the RTTM"
+    # same outputs through the reference VBxClustering (diarizen/clustering/VBx.py) with the seeded PLDA model of
+    # host_clustering.npz -> second golden RTTM (the from_pretrained / VBx test)
+    import tempfile
+    hc = np.load(GOLD / "host_clustering.npz")
+    with tempfile.TemporaryDirectory() as td:
+        for f in ("xvec_transform", "plda"):
+            open(f"{td}/{f}.npz", "wb").write(hc["plda_" + f].tobytes())
+        vb = cl.VBxClustering(metric="cosine", plda_dir=td, lda_dim=128, maxIters=20)
+        vb.ahc_criterion, vb.ahc_threshold, vb.Fa, vb.Fb = "distance", E2E_VBX["ahc_threshold"], E2E_VBX["Fa"], E2E_VBX["Fb"]
+        hard_vbx, _, _ = vb(embeddings=emb.copy(), segmentations=swf)
+    rttm_vbx = host_stage.host_stage(seg, hard_vbx, 8.0, 0.1, clu["max_speakers"], "EN2002a")
+    print("e2e VBx: clusters", int(hard_vbx.max()) + 1, "lines", len(rttm_vbx.splitlines()))
+    (GOLD / "e2e_EN2002a_30s_vbx.rttm").write_text(rttm_vbx)
+    np.savez_compressed(GOLD / "e2e_EN2002a_30s.npz", seg=seg, emb=emb, hard_clusters=hard, hard_clusters_vbx=hard_vbx,
+                        weight_seed=0,
+                        weights="turn_taking", stats=np.array(repr(st)), mask_branches=np.array([n_clean, n_fallback]))
+    (GOLD / "e2e_EN2002a_30s.rttm").write_text(rttm)
 
 
-GENERATORS = {"seg": gen_seg, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
+GENERATORS = {"seg": gen_seg, "seg_tt": gen_seg_tt, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
               "e2e": gen_e2e}
 
 if __name__ == "__main__":

@@ -82,6 +82,36 @@ def test_seg_fp32_matches_reference_golden(built_lib, gpu, name, precision):
     assert eng.num_ignored_keys <= cfg.conf_layers + 2
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32s"])
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
+def test_seg_fp32_matches_reference_golden_turn_taking(built_lib, gpu, name, precision):
+    """NON-degenerate goldens (reference modules + seeded turn-taking weights on real audio): many powerset
+    classes and ~15 transitions per window, at BASELINE configs[1] size for base-s80 (5 s x 32) and the bench
+    geometry for large-s80 (8 s).  Strict bar: max |dlogp| <= 1e-3 AND every argmax / u8 decision identical."""
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from diarizen_amd.weights import turn_taking_state_dict
+    from oracle import seg_model
+    from oracle.gen_golden import tt_windows
+    cfg = get_seg_config(name)
+    g = np.load(os.path.join(GOLD, f"seg_tt_{name}.npz"))
+    ref = torch.from_numpy(g["logp"])
+    assert len(torch.unique(ref.argmax(-1))) >= 5
+    wave = tt_windows(g["starts"].tolist(), int(g["N"]))
+    B = wave.shape[0]
+    eng = Engine(cfg, turn_taking_state_dict(cfg, int(g["weight_seed"])), max_batch=B, max_samples=int(g["N"]),
+                 precision=precision, device=gpu)
+    logp, ml = eng.segment(wave.to(gpu))
+    torch.cuda.synchronize()
+    logp, ml = logp.cpu(), ml.cpu()
+    err = (logp - ref).abs().max().item()
+    top2 = ref.topk(2, dim=-1).values
+    print(f"[{name} {precision}] max|dlogp|={err:.2e}  min top-2 margin of the reference={float((top2[..., 0] - top2[..., 1]).min()):.2e}")
+    assert err <= 1e-3
+    assert torch.equal(logp.argmax(-1), ref.argmax(-1))
+    assert torch.equal(ml, seg_model.to_multilabel(ref, cfg).to(torch.uint8))
+
+
 @pytest.mark.parametrize("name", ["tiny_ln", "wavlm_large_s80_md"])
 def test_seg_bf16_within_tolerance(built_lib, gpu, name):
     cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, "bf16")
