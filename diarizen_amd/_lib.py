@@ -17,6 +17,7 @@ DZN_MAX_HEADS = 16
 DZN_PREC_F32 = 0
 DZN_PREC_BF16 = 1
 DZN_PREC_F32_SPLIT = 2
+DZN_PREC_F32_H2 = 3
 
 DZN_ACT_NONE, DZN_ACT_GELU, DZN_ACT_SWISH, DZN_ACT_RELU = 0, 1, 2, 3
 
@@ -88,6 +89,8 @@ class DznGemmDesc(C.Structure):
         ("a_bf16", C.c_int32), ("c_bf16", C.c_int32), ("r_bf16", C.c_int32),
         ("W3", C.c_void_p),
         ("a_split3", C.c_int32), ("a_plane", C.c_int64),
+        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
+        ("W2h", C.c_void_p), ("col_scale", C.c_void_p), ("a_amax", C.c_void_p), ("c_amax", C.c_void_p),
     ]
 
 
@@ -147,10 +150,14 @@ def load() -> C.CDLL:
     sig("dzn_linkage_centroid", i32, [vp, i32, i32, vp, i32])
     sig("dzn_op_gemm", i32, [C.POINTER(DznGemmDesc), vp])
     sig("dzn_op_split_weights", i32, [vp, i64, i32, i64, vp, vp])
+    sig("dzn_op_split_weights_h2", i32, [vp, i64, i32, i64, vp, vp, vp])
+    sig("dzn_op_amax", i32, [vp, i64, vp, vp])
     sig("dzn_op_split_rows", i32, [vp, vp, i64, i64, i32, vp])
     sig("dzn_op_conv3x3_c32", i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp])
     sig("dzn_op_layernorm", i32, [vp, i64, vp, i64, vp, vp, i64, i32, i32, f32, i32, vp])
     sig("dzn_op_gate", i32, [vp, i64, vp, vp, vp, vp, i64, i32, vp])
+    sig("dzn_op_row_stats", i32, [vp, i64, i64, i32, f32, vp, vp])
+    sig("dzn_op_gate_stats", i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp])
     sig("dzn_op_attention", i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp])
     _LIB = lib
     return lib
@@ -160,7 +167,7 @@ EXPORTED = [
     "dzn_create", "dzn_load_tensor", "dzn_finalize_weights", "dzn_num_frames",
     "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_debug_fetch", "dzn_num_ignored",
     "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid",
-    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_conv3x3_c32", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_gate", "dzn_op_attention",
+    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention",
     "dzn_profile_enable", "dzn_profile_collect", "dzn_op_relpos_bucket",
 ]
 

@@ -238,7 +238,124 @@ __global__ __launch_bounds__(256) void gate_kernel(const TI* __restrict__ y, int
   }
 }
 
+// Pre-norm layers (W2V/components.py:920-925 with layer_norm_first): ONE pass over the residual row x that
+//   * computes the LayerNorm statistics (mean, rstd) consumed by the q/k/v contraction, whose weights carry
+//     gamma / beta (dzn_gemm_desc.ln_stats) — the normalised copy y is never written;
+//   * applies that LayerNorm in registers and evaluates the gate of the relative position bias on it
+//     (components.py:702-710): t = Linear(64->8)(y_h); a = sigmoid(t[0:4].sum()), b = sigmoid(t[4:8].sum()).
+//     The two 4-sums are linear in y_h, so the weights are pre-summed into wa = sum Wg[0:4], wb = sum Wg[4:8].
+// One wavefront per row; element lane + 64 i of the row is channel `lane` of head i, staged through a padded
+// LDS row so that lane (H = lane/4, sub = lane%4) reads 16 consecutive channels of head H without bank conflicts.
+template <int MAXI>
+__global__ __launch_bounds__(256) void gate_stats_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                         const float* __restrict__ cst, float* __restrict__ gate,
+                                                         float* __restrict__ stats, int64_t rows, int Htot, float eps) {
+  constexpr int ROW = MAXI * 64 + MAXI * 4;          // one pad float per 16 channels
+  __shared__ float sy[4][ROW];
+  __shared__ float sw[2 * 64 + 2];                   // wa[64], wb[64], ba, bb
+  if (threadIdx.x < 128) {
+    const int o0 = threadIdx.x < 64 ? 0 : 4, dch = threadIdx.x & 63;
+    sw[threadIdx.x] = (Wg[(o0 + 0) * 64 + dch] + Wg[(o0 + 1) * 64 + dch]) + (Wg[(o0 + 2) * 64 + dch] + Wg[(o0 + 3) * 64 + dch]);
+  } else if (threadIdx.x < 130) {
+    const int o0 = threadIdx.x == 128 ? 0 : 4;
+    sw[threadIdx.x] = (bg[o0] + bg[o0 + 1]) + (bg[o0 + 2] + bg[o0 + 3]);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 3;
+  float wa[16], wb[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    wa[j] = sw[sub * 16 + j];
+    wb[j] = sw[64 + sub * 16 + j];
+  }
+  const float ba = sw[128], bb = sw[129];
+  const int C = Htot * 64;
+  // gamma / beta of this lane's channels stay in registers across the rows of the wave
+  float gm[MAXI], bt[MAXI];
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    gm[i] = i < Htot ? gamma[lane + 64 * i] : 0.f;
+    bt[i] = i < Htot ? beta[lane + 64 * i] : 0.f;
+  }
+  float* sr = sy[wave];
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float* xp = x + row * ldx;
+    float v[MAXI];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      v[i] = i < Htot ? xp[lane + 64 * i] : 0.f;
+      sum += v[i];
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const float dv = i < Htot ? v[i] - mean : 0.f;
+      sq += dv * dv;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+    if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mean, rstd);
+    __builtin_amdgcn_wave_barrier();      // the previous row's LDS reads are done (in-order LDS queue of the wave)
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+      if (i < Htot) {
+        const int e = lane + 64 * i;
+        sr[e + (e >> 4)] = (v[i] - mean) * rstd * gm[i] + bt[i];
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave have landed
+    __builtin_amdgcn_wave_barrier();      // and the compiler keeps the cross-lane reads below them
+    for (int H0 = 0; H0 < Htot; H0 += 16) {
+      const int H = H0 + (lane >> 2);
+      float ta = 0.f, tb = 0.f;
+      if (H < Htot) {
+        const int e0 = H * 64 + sub * 16;
+        const float* yp = sr + e0 + (e0 >> 4);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          ta = fmaf(yp[j], wa[j], ta);
+          tb = fmaf(yp[j], wb[j], tb);
+        }
+      }
+      ta = dpp_add<0xB1, 0xF>(ta);   // quad_perm [1,0,3,2]
+      ta = dpp_add<0x4E, 0xF>(ta);   // quad_perm [2,3,0,1] -> every lane of the quad holds the head's sum
+      tb = dpp_add<0xB1, 0xF>(tb);
+      tb = dpp_add<0x4E, 0xF>(tb);
+      if (H < Htot && sub == 0) {
+        const float ga = 1.0f / (1.0f + expf(-(ta + ba)));
+        const float gb = 1.0f / (1.0f + expf(-(tb + bb)));
+        gate[row * Htot + H] = ga * (gb * cst[H] - 1.0f) + 2.0f;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+int launch_gate_stats(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* Wg,
+                      const float* bg, const float* cst, float* gate, float* stats, int64_t rows, int Htot, float eps,
+                      hipStream_t s) {
+  if (rows <= 0) return DZN_OK;
+  if (Htot < 1 || Htot > 16) return DZN_E_INVALID;
+  int pid = prof_enabled() ? prof_begin(s, "gate_ln_stats", 0.0, (double)rows * Htot * 64 * 4.0) : -1;
+  int64_t grid = cdiv64(rows, 4);
+  grid = grid > 256 * 8 ? 256 * 8 : grid;   // waves walk rows grid-stride: per-wave constants are loaded once
+  hipLaunchKernelGGL(gate_stats_kernel<16>, dim3((unsigned)grid), dim3(256), 0, s, x, ldx, gamma, beta, Wg,
+                     bg, cst, gate, stats, rows, Htot, eps);
+  prof_end(pid, s);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+extern "C" int dzn_op_gate_stats(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* Wg,
+                                 const float* bg, const float* cst, float* gate, float* stats, int64_t rows,
+                                 int32_t Htot, float eps, void* stream) {
+  if (!x || !gamma || !beta || !Wg || !bg || !cst || !gate || !stats) return DZN_E_INVALID;
+  return launch_gate_stats(x, ldx, gamma, beta, Wg, bg, cst, gate, stats, rows, Htot, eps,
+                           reinterpret_cast<hipStream_t>(stream));
+}
 
 int launch_attention_t(const float* qkv, void* out, int out_bf16, const float* gate, const float* table,
                        const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
@@ -267,13 +384,14 @@ int launch_attention_t(const float* qkv, void* out, int out_bf16, const float* g
 int launch_attention(const float* qkv, float* out, const float* gate, const float* table,
                      const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
                      float scale, int precision, hipStream_t s) {
-  if (precision == DZN_PREC_F32_SPLIT)
+  if (prec_is_split(precision))
     return launch_attention_split(qkv, out, gate, table, head_idx, B, L, h, Htot, ldqkv, ldo, scale, s);
   return launch_attention_t(qkv, out, 0, gate, table, head_idx, B, L, h, Htot, ldqkv, ldo, scale, s);
 }
 
 int launch_gate_t(const void* y, int y_bf16, int64_t ldy, const float* Wg, const float* bg,
                   const float* cst, float* gate, int64_t rows, int Htot, hipStream_t s) {
+  ProfScope prof_scope_(s, "gate");
   if (rows <= 0) return DZN_OK;
   if (y_bf16)
     hipLaunchKernelGGL(gate_kernel<u16>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s,

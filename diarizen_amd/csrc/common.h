@@ -76,6 +76,9 @@ static inline u16 f32_to_bf16_host(float f) {
   return (u16)((u + r) >> 16);
 }
 
+// DZN_PREC_F32_H2 is DZN_PREC_F32_SPLIT for every kernel that has no two-term fp16 variant
+static inline bool prec_is_split(int p) { return p == DZN_PREC_F32_SPLIT || p == DZN_PREC_F32_H2; }
+
 // ---- kernel launchers (implemented in the .hip files) ----
 int launch_gemm(const dzn_gemm_desc& d, hipStream_t s);
 int launch_gemm_lowp(const dzn_gemm_desc& d, hipStream_t s);  // gemm_lowp.hip: A and W both bf16
@@ -84,13 +87,19 @@ int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s);  // gemm_split
 int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
                            hipStream_t st);
 int launch_split_weights(const float* W, int64_t rows, int K, int64_t ldw, void* W3, hipStream_t s);
+int launch_split_weights_h2(const float* W, int64_t rows, int K, int64_t ldw, void* W2, float* col_scale, hipStream_t s);
+int launch_amax(const float* x, int64_t n, float* amax, hipStream_t s);
 int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* g,
                      const float* b, int64_t rows, int C, int Cpad, float eps, int gelu,
                      hipStream_t s);
 int launch_layernorm_t(const void* x, int x_bf16, int64_t ldx, void* y, int y_bf16, int64_t ldy,
                        const float* g, const float* b, const float* post, int64_t rows, int C, int Cpad,
-                       float eps, int gelu, hipStream_t s);
+                       float eps, int gelu, hipStream_t s, float* amax = nullptr);
 int launch_cast_bf16(const float* x, void* y, int64_t n, hipStream_t s);
+int launch_row_stats(const float* x, int64_t ldx, int64_t rows, int C, float eps, float* stats, hipStream_t s);
+int launch_gate_stats(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* Wg,
+                      const float* bg, const float* cst, float* gate, float* stats, int64_t rows, int Htot, float eps,
+                      hipStream_t s);
 int launch_wave_stats(const float* w, int B, int N, float eps, float* stats, hipStream_t s);
 int launch_gate(const float* y, int64_t ldy, const float* Wg, const float* bg, const float* cst,
                 float* gate, int64_t rows, int Htot, hipStream_t s);
@@ -155,6 +164,17 @@ static inline bool first_use_on_device(unsigned long long& mask) {
   mask |= bit;
   return true;
 }
+
+// brackets everything a launcher enqueues with one profiler record (no-op unless dzn_profile_enable(1))
+struct ProfScope {
+  int id;
+  hipStream_t st;
+  ProfScope(hipStream_t s, const char* cls, double flops = 0.0, double bytes = 0.0)
+      : id(prof_enabled() ? prof_begin(s, cls, flops, bytes) : -1), st(s) {}
+  ~ProfScope() { prof_end(id, st); }
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
+};
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

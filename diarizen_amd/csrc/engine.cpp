@@ -66,6 +66,9 @@ struct Lin {       // y = x W^T + b with W [N, K] (rows zero-padded to Np, cols 
   u16* W16 = nullptr;
   u16* W3 = nullptr;   // exact 3-way bf16 split planes (DZN_PREC_F32_SPLIT), gemm_split.hip layout
   float* b = nullptr;
+  u16* W2h = nullptr;  // two-term fp16 planes of W * 2^e_row (DZN_PREC_F32_H2) ...
+  float* wsc = nullptr;   // ... and 2^-e_row per output row (dzn_gemm_desc.col_scale)
+  float* csum = nullptr;  // LayerNorm folded into W (make_lin_ln): column sums of W diag(gamma), dzn_gemm_desc.ln_colsum
   int N = 0, K = 0;    // padded sizes
   int Nt = 0, Kt = 0;  // reference (un-padded) sizes, for algorithmic flop accounting
 };
@@ -150,6 +153,12 @@ struct dzn_handle {
   float *x = nullptr, *xpad = nullptr, *y = nullptr, *ws = nullptr, *qkv = nullptr, *ao = nullptr,
         *gate = nullptr, *mid = nullptr;
   float *hz = nullptr, *ht = nullptr, *hmid = nullptr, *hv = nullptr;
+  float* rstat = nullptr;   // [max_batch * maxL][2] (mean, rstd) of the LayerNorm folded into the next contraction
+  // |max| trackers of activation tensors (DZN_PREC_F32_H2): written by the producer's epilogue / LayerNorm,
+  // read by the consuming contraction to scale its fp16 split (gemm_split.hip).  Zeroed at every forward.
+  enum { AM_CONVA, AM_CONVB, AM_X, AM_Y, AM_MID, AM_QKV, AM_HZ, AM_HMID, AM_IMG0, AM_COUNT = AM_IMG0 + 12 };
+  float* amax = nullptr;
+  bool fold_ln = false;     // fp32 engine modes: LayerNorms that feed only linears are folded (make_lin_ln)
 
   // ---- embedding ----
   bool has_emb = false;
@@ -231,10 +240,16 @@ Lin make_lin(H* h, const std::vector<float>& W, const float* bias, int N, int K,
   l.Kt = K;
   l.W = upload(h, wp);
   if (h->cfg.precision == DZN_PREC_BF16) l.W16 = upload_bf16(h, wp);
-  if (h->cfg.precision == DZN_PREC_F32_SPLIT && Kp % 32 == 0) {
+  if (prec_is_split(h->cfg.precision) && Kp % 32 == 0) {
     l.W3 = dalloc<u16>(h, (int64_t)3 * Np * Kp, false);
     if (launch_split_weights(l.W, Np, Kp, Kp, l.W3, nullptr) != DZN_OK)
       throw EngineError(DZN_E_HIP, "split_weights launch failed");
+    if (h->cfg.precision == DZN_PREC_F32_H2) {
+      l.W2h = dalloc<u16>(h, (int64_t)2 * Np * Kp, false);
+      l.wsc = dalloc<float>(h, Np, false);
+      if (launch_split_weights_h2(l.W, Np, Kp, Kp, l.W2h, l.wsc, nullptr) != DZN_OK)
+        throw EngineError(DZN_E_HIP, "split_weights_h2 launch failed");
+    }
     HIPCHK(hipDeviceSynchronize());
   }
   if (bias) {
@@ -255,6 +270,42 @@ Lin linear_from_sd(H* h, const std::string& prefix, int N, int K, int Np, int Kp
     b = bt.v.data();
   }
   return make_lin(h, w.v, b, N, K, Np, Kp);
+}
+
+// y = LN(x; gamma, beta) W^T + bias  ==  rstd (x W'^T - mean colsum(W')) + (bias + W beta),  W' = W diag(gamma):
+// the contraction reads the RAW rows and its epilogue finishes the norm from (mean, rstd) per row
+// (dzn_gemm_desc.ln_stats).  Used where a LayerNorm feeds only linears (pre-norm encoder layers
+// W2V/components.py:920-935, feature projection :305-306, Conformer sub-blocks conformer.py:136-214).
+Lin make_lin_ln(H* h, const std::vector<float>& W, const float* bias, const std::vector<float>& gamma,
+                const std::vector<float>& beta, int N, int K, int Np, int Kp) {
+  std::vector<float> wf((size_t)N * K), bf(N), cs(Np, 0.f);
+  for (int n = 0; n < N; ++n) {
+    double sb = bias ? (double)bias[n] : 0.0, sc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const float w = W[(size_t)n * K + k];
+      const float wg = w * gamma[k];
+      wf[(size_t)n * K + k] = wg;
+      sc += (double)wg;
+      sb += (double)w * (double)beta[k];
+    }
+    bf[n] = (float)sb;
+    cs[n] = (float)sc;
+  }
+  Lin l = make_lin(h, wf, bf.data(), N, K, Np, Kp);
+  l.csum = upload(h, cs);
+  return l;
+}
+
+Lin linear_ln_from_sd(H* h, const std::string& prefix, const std::string& ln_prefix, int N, int K, int Np, int Kp) {
+  const HostT& w = need(h, prefix + ".weight");
+  const HostT& bt = need(h, prefix + ".bias");
+  const HostT& g = need(h, ln_prefix + ".weight");
+  const HostT& b = need(h, ln_prefix + ".bias");
+  expect_numel(w, (int64_t)N * K, prefix + ".weight");
+  expect_numel(bt, N, prefix + ".bias");
+  expect_numel(g, K, ln_prefix + ".weight");
+  expect_numel(b, K, ln_prefix + ".bias");
+  return make_lin_ln(h, w.v, bt.v.data(), g.v, b.v, N, K, Np, Kp);
 }
 
 LNp ln_from_sd(H* h, const std::string& prefix, int Cn) {
@@ -301,6 +352,7 @@ int64_t lnx_raw_elems(H* h, int64_t B) {
 void finalize_seg(H* h) {
   const dzn_config& c = h->cfg;
   const std::string P = "wavlm_model.";
+  h->fold_ln = c.precision != DZN_PREC_BF16 && !getenv("DZN_NO_LN_FOLD");
   h->nconv = c.n_conv;
   h->D = c.embed_dim;
   h->H = c.total_heads;
@@ -347,8 +399,12 @@ void finalize_seg(H* h) {
   }
   const int D = h->D;
   h->fp_ln = ln_from_sd(h, P + "encoder.feature_projection.layer_norm", h->C[last]);
-  h->fp = linear_from_sd(h, P + "encoder.feature_projection.projection", D, h->C[last], D,
-                         h->Cp[last]);
+  if (h->fold_ln)
+    h->fp = linear_ln_from_sd(h, P + "encoder.feature_projection.projection",
+                              P + "encoder.feature_projection.layer_norm", D, h->C[last], D, h->Cp[last]);
+  else
+    h->fp = linear_from_sd(h, P + "encoder.feature_projection.projection", D, h->C[last], D,
+                           h->Cp[last]);
   // positional conv: fold weight norm  W = g * v / ||v||_{dims 0,1}   (components.py:344)
   {
     const std::string pc = P + "encoder.transformer.pos_conv_embed.conv";
@@ -399,7 +455,11 @@ void finalize_seg(H* h) {
         std::copy(w.v.begin(), w.v.end(), wq.begin() + (size_t)t * hd * D);
         std::copy(b.v.begin(), b.v.end(), bq.begin() + (size_t)t * hd);
       }
-      L.qkv = make_lin(h, wq, bq.data(), 3 * hd, D, 3 * hd, D);
+      if (h->fold_ln && c.layer_norm_first)
+        L.qkv = make_lin_ln(h, wq, bq.data(), need(h, lp + ".layer_norm.weight").v,
+                            need(h, lp + ".layer_norm.bias").v, 3 * hd, D, 3 * hd, D);
+      else
+        L.qkv = make_lin(h, wq, bq.data(), 3 * hd, D, 3 * hd, D);
       L.out = linear_from_sd(h, lp + ".attention.out_proj", D, hd, D, hd);
       const HostT& wg = need(h, lp + ".attention.gru_rel_pos_linear.weight");
       const HostT& bg = need(h, lp + ".attention.gru_rel_pos_linear.bias");
@@ -425,7 +485,11 @@ void finalize_seg(H* h) {
       L.F = c.ffn_dim[i];
       L.Fp = pad32(L.F);
       maxF = std::max(maxF, L.Fp);
-      L.f1 = linear_from_sd(h, lp + ".feed_forward.intermediate_dense", L.F, D, L.Fp, D);
+      if (h->fold_ln && c.layer_norm_first)
+        L.f1 = linear_ln_from_sd(h, lp + ".feed_forward.intermediate_dense", lp + ".final_layer_norm", L.F, D,
+                                 L.Fp, D);
+      else
+        L.f1 = linear_from_sd(h, lp + ".feed_forward.intermediate_dense", L.F, D, L.Fp, D);
       L.f2 = linear_from_sd(h, lp + ".feed_forward.output_dense", D, L.F, D, L.Fp);
     }
   }
@@ -444,10 +508,12 @@ void finalize_seg(H* h) {
     ConfLayer& L = h->conf[i];
     const std::string cp = "conformer.conformer_layer." + std::to_string(i);
     L.ffn1_ln = ln_from_sd(h, cp + ".ffn1.ln_norm", A);
-    L.ffn1_w1 = linear_from_sd(h, cp + ".ffn1.w_1", Fh, A, Fh, A);
+    L.ffn1_w1 = h->fold_ln ? linear_ln_from_sd(h, cp + ".ffn1.w_1", cp + ".ffn1.ln_norm", Fh, A, Fh, A)
+                           : linear_from_sd(h, cp + ".ffn1.w_1", Fh, A, Fh, A);
     L.ffn1_w2 = linear_from_sd(h, cp + ".ffn1.w_2", A, Fh, A, Fh);
     L.ffn2_ln = ln_from_sd(h, cp + ".ffn2.ln_norm", A);
-    L.ffn2_w1 = linear_from_sd(h, cp + ".ffn2.w_1", Fh, A, Fh, A);
+    L.ffn2_w1 = h->fold_ln ? linear_ln_from_sd(h, cp + ".ffn2.w_1", cp + ".ffn2.ln_norm", Fh, A, Fh, A)
+                           : linear_from_sd(h, cp + ".ffn2.w_1", Fh, A, Fh, A);
     L.ffn2_w2 = linear_from_sd(h, cp + ".ffn2.w_2", A, Fh, A, Fh);
     L.mha_ln = ln_from_sd(h, cp + ".mha.ln_norm", A);
     {
@@ -461,11 +527,16 @@ void finalize_seg(H* h) {
         std::copy(w.v.begin(), w.v.end(), wq.begin() + (size_t)t * A * A);
         std::copy(b.v.begin(), b.v.end(), bq.begin() + (size_t)t * A);
       }
-      L.qkv = make_lin(h, wq, bq.data(), 3 * A, A, 3 * A, A);
+      if (h->fold_ln)
+        L.qkv = make_lin_ln(h, wq, bq.data(), need(h, cp + ".mha.ln_norm.weight").v,
+                            need(h, cp + ".mha.ln_norm.bias").v, 3 * A, A, 3 * A, A);
+      else
+        L.qkv = make_lin(h, wq, bq.data(), 3 * A, A, 3 * A, A);
     }
     L.o = linear_from_sd(h, cp + ".mha.mha.linearO", A, A, A, A);
     L.conv_ln = ln_from_sd(h, cp + ".conv.ln_norm", A);
-    L.pw1 = linear_from_sd(h, cp + ".conv.pointwise_conv1", 2 * A, A, 2 * A, A);
+    L.pw1 = h->fold_ln ? linear_ln_from_sd(h, cp + ".conv.pointwise_conv1", cp + ".conv.ln_norm", 2 * A, A, 2 * A, A)
+                       : linear_from_sd(h, cp + ".conv.pointwise_conv1", 2 * A, A, 2 * A, A);
     L.pw2 = linear_from_sd(h, cp + ".conv.pointwise_conv2", A, A, A, A);
     {
       // fold eval BatchNorm1d into the depthwise taps (conformer.py:205)
@@ -547,7 +618,7 @@ void finalize_seg(H* h) {
   }
   h->x = dalloc<float>(h, ML * D);
   h->xpad = dalloc<float>(h, B * (n + c.pos_conv_kernel) * D);
-  if (c.precision == DZN_PREC_F32_SPLIT && (D / c.pos_conv_groups) % 32 == 0) {
+  if (prec_is_split(c.precision) && (D / c.pos_conv_groups) % 32 == 0) {
     h->xpad3_plane = B * (n + c.pos_conv_kernel) * D;
     h->xpad3 = dalloc<u16>(h, 3 * h->xpad3_plane);
   }
@@ -561,6 +632,8 @@ void finalize_seg(H* h) {
   h->ht = dalloc<float>(h, ML * A);
   h->hmid = dalloc<float>(h, ML * std::max(Fh, 3 * A));
   h->hv = dalloc<float>(h, ML * A);
+  h->rstat = dalloc<float>(h, ML * 2);
+  h->amax = dalloc<float>(h, dzn_handle::AM_COUNT);
 }
 
 // ------------------------------------------------------------------ embedding: finalize
@@ -777,6 +850,8 @@ dzn_gemm_desc gd(H* h, const float* A, const Lin& l, float* C, int64_t M, int64_
   d.W = l.W;
   d.W16 = l.W16;
   d.W3 = l.W3;
+  d.W2h = l.W2h;
+  d.col_scale = l.wsc;
   d.C = C;
   d.bias = l.b;
   d.M = (int)M;
@@ -797,8 +872,8 @@ dzn_gemm_desc gd(H* h, const float* A, const Lin& l, float* C, int64_t M, int64_
 
 // LayerNorm with typed input / output (fp32, or bf16 in the bf16 engine mode)
 void ln_t(const float* x, bool x16, int64_t ldx, float* y, bool y16, int64_t ldy, const LNp& p, int64_t rows,
-          int Cpad, int gelu, hipStream_t st, const float* post = nullptr) {
-  chk(launch_layernorm_t(x, x16, ldx, y, y16, ldy, p.g, p.b, post, rows, p.C, Cpad, 1e-5f, gelu, st),
+          int Cpad, int gelu, hipStream_t st, const float* post = nullptr, float* amax = nullptr) {
+  chk(launch_layernorm_t(x, x16, ldx, y, y16, ldy, p.g, p.b, post, rows, p.C, Cpad, 1e-5f, gelu, st, amax),
       "layernorm");
 }
 
@@ -854,6 +929,12 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     d.c_bf16 = c16;
     chk(launch_gemm(d, st), what);
   };
+  // DZN_PREC_F32_H2: |max| trackers (see dzn_handle::amax).  am(slot) is NULL in the other modes, which makes
+  // every contraction take its bf16 three-term / fp32 kernel.
+  const bool h2 = c.precision == DZN_PREC_F32_H2;
+  if (h2) HIPCHK(hipMemsetAsync(h->amax, 0, dzn_handle::AM_IMG0 * sizeof(float), st));
+  auto am = [&](int slot) -> float* { return h2 ? h->amax + slot : nullptr; };
+  auto conv_slot = [&](const float* buf) { return buf == h->bufA ? dzn_handle::AM_CONVA : dzn_handle::AM_CONVB; };
 
   // ---- conv feature extractor ----
   const float* stats = nullptr;
@@ -886,10 +967,12 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     d.a_z0 = (int64_t)T[i - 1] * h->Cp[i - 1];
     d.c_z0 = (int64_t)T[i] * h->Cp[i];
     if (!lnx) d.act = DZN_ACT_GELU;
+    if (i > 1) d.a_amax = am(conv_slot(cur));     // conv0's kernel has no tracker: conv1 stays on the bf16 split
+    if (!lnx) d.c_amax = am(conv_slot(nxt));
     gemm(d, lp, lp && !lnx, "conv gemm");
     if (lnx)  // channel LayerNorm + GELU (+ dummy_weight after the last conv, components.py:208)
       ln_t(dst, false, h->Cp[i], nxt, lp, h->Cp[i], h->conv_ln[i], (int64_t)B * T[i], h->Cp[i], 1, st,
-           i == last ? h->dummy_w : nullptr);
+           i == last ? h->dummy_w : nullptr, am(conv_slot(nxt)));
     std::swap(cur, nxt);
   }
   if (!lnx || c.n_conv == 1)
@@ -897,9 +980,24 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   tap(h, "features", cur, ML, h->C[last], h->Cp[last], st, lp);
 
   // ---- feature projection (components.py:305-306) ----
-  ln_t(cur, lp, h->Cp[last], nxt, lp, h->Cp[last], h->fp_ln, ML, h->Cp[last], 0, st);
-  {
+  const bool fold = h->fold_ln;   // LayerNorms feeding only linears are folded into those contractions
+  auto folded = [&](dzn_gemm_desc& d, const Lin& l) {
+    d.ln_stats = h->rstat;
+    d.ln_colsum = l.csum;
+  };
+  if (fold) {
+    chk(launch_row_stats(cur, h->Cp[last], ML, h->C[last], 1e-5f, h->rstat, st), "row_stats");
+    dzn_gemm_desc d = gd(h, cur, h->fp, h->x, ML, h->Cp[last], D);
+    folded(d, h->fp);
+    // (col_scale of the base model multiplies conv6's output AFTER its tracker: |dummy_weight| ~ 1, and the
+    // tracker only needs to bound the magnitude within the 2^15 / 65504 headroom -> skip the fp16 path there)
+    if (lnx && c.n_conv > 1) d.a_amax = am(conv_slot(cur));
+    d.c_amax = am(dzn_handle::AM_X);
+    gemm(d, false, false, "feature projection");
+  } else {
+    ln_t(cur, lp, h->Cp[last], nxt, lp, h->Cp[last], h->fp_ln, ML, h->Cp[last], 0, st);
     dzn_gemm_desc d = gd(h, nxt, h->fp, h->x, ML, h->Cp[last], D);
+    d.c_amax = am(dzn_handle::AM_X);
     gemm(d, lp, false, "feature projection");
   }
   tap(h, "featproj", h->x, ML, D, D, st);
@@ -948,9 +1046,10 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       d.a_split3 = 1;
       d.a_plane = h->xpad3_plane;
     }
+    d.c_amax = am(dzn_handle::AM_X);
     gemm(d, pc16, false, "pos conv");
   }
-  if (!c.layer_norm_first) ln_t(h->x, false, D, h->x, false, D, h->enc_ln, ML, D, 0, st);
+  if (!c.layer_norm_first) ln_t(h->x, false, D, h->x, false, D, h->enc_ln, ML, D, 0, st, nullptr, am(dzn_handle::AM_X));
   chk(launch_ws_accum(h->x, h->ws, h->wsum_w[0], 1, ML * D, st), "ws_accum");
   tap(h, "rep0", h->x, ML, D, D, st);
 
@@ -962,8 +1061,14 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     if (Ly.attn) {
       const float* yin = h->x;
       bool y16 = false;
-      if (c.layer_norm_first) {
-        ln_t(h->x, false, D, h->y, lp, D, Ly.ln1, ML, D, 0, st);
+      const bool fold1 = fold && c.layer_norm_first;
+      if (fold1) {
+        // one pass over x: LN statistics for the folded q/k/v contraction + the gate on LN(x) (never written)
+        chk(launch_gate_stats(h->x, D, Ly.ln1.g, Ly.ln1.b, Ly.Wg, Ly.bg, Ly.cst, h->gate, h->rstat, ML, h->H, 1e-5f,
+                              st),
+            "gate_stats");
+      } else if (c.layer_norm_first) {
+        ln_t(h->x, false, D, h->y, lp, D, Ly.ln1, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y));
         yin = h->y;
         y16 = lp;
       } else if (lp) {
@@ -971,11 +1076,14 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
         yin = h->y;
         y16 = true;
       }
-      chk(launch_gate_t(yin, y16, D, Ly.Wg, Ly.bg, Ly.cst, h->gate, ML, h->H, st), "gate");
+      if (!fold1) chk(launch_gate_t(yin, y16, D, Ly.Wg, Ly.bg, Ly.cst, h->gate, ML, h->H, st), "gate");
       const int hd = Ly.h * 64;
       dzn_gemm_desc d = gd(h, yin, Ly.qkv, h->qkv, ML, D, 3 * hd);
+      if (fold1) folded(d, Ly.qkv);
+      d.a_amax = am(yin == h->x ? dzn_handle::AM_X : dzn_handle::AM_Y);
+      d.c_amax = am(dzn_handle::AM_QKV);
       gemm(d, y16, false, "qkv");
-      if (c.precision == DZN_PREC_F32_SPLIT)
+      if (prec_is_split(c.precision))
         chk(launch_attention_split(h->qkv, h->ao, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd, hd,
                                    0.125f, st),
             "attention");
@@ -985,25 +1093,38 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
             "attention");
       dzn_gemm_desc o = gd(h, h->ao, Ly.out, h->x, ML, hd, D);
       o.R = h->x;
+      o.a_amax = am(dzn_handle::AM_QKV);   // rows of ao are convex combinations of v rows: |ao| <= max |qkv|
+      o.c_amax = am(dzn_handle::AM_X);
       gemm(o, lp, false, "out_proj");
     }
     if (c.layer_norm_first) {
       if (Ly.ffn) {
-        ln_t(h->x, false, D, h->y, lp, D, Ly.ln2, ML, D, 0, st);
-        dzn_gemm_desc f1 = gd(h, h->y, Ly.f1, h->mid, ML, D, Ly.Fp);
+        const float* fin = h->y;
+        if (fold) {
+          chk(launch_row_stats(h->x, D, ML, D, 1e-5f, h->rstat, st), "row_stats");
+          fin = h->x;
+        } else {
+          ln_t(h->x, false, D, h->y, lp, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y));
+        }
+        dzn_gemm_desc f1 = gd(h, fin, Ly.f1, h->mid, ML, D, Ly.Fp);
+        if (fold) folded(f1, Ly.f1);
         f1.act = DZN_ACT_GELU;
+        f1.a_amax = am(fin == h->x ? dzn_handle::AM_X : dzn_handle::AM_Y);
+        f1.c_amax = am(dzn_handle::AM_MID);
         gemm(f1, lp, lp, "ffn1");
         dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, h->x, ML, Ly.Fp, D);
         f2.R = h->x;
         f2.WS = h->ws;
         f2.ldws = D;
         f2.ws_w = wl;
+        f2.a_amax = am(dzn_handle::AM_MID);
+        f2.c_amax = am(dzn_handle::AM_X);
         gemm(f2, lp, false, "ffn2");
       } else {
         chk(launch_ws_accum(h->x, h->ws, wl, 0, ML * D, st), "ws_accum");
       }
     } else {
-      ln_t(h->x, false, D, h->x, false, D, Ly.ln1, ML, D, 0, st);
+      ln_t(h->x, false, D, h->x, false, D, Ly.ln1, ML, D, 0, st, nullptr, am(dzn_handle::AM_X));
       if (Ly.ffn) {
         const float* fin = h->x;
         if (lp) {
@@ -1012,12 +1133,16 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
         }
         dzn_gemm_desc f1 = gd(h, fin, Ly.f1, h->mid, ML, D, Ly.Fp);
         f1.act = DZN_ACT_GELU;
+        f1.a_amax = am(dzn_handle::AM_X);
+        f1.c_amax = am(dzn_handle::AM_MID);
         gemm(f1, lp, lp, "ffn1");
         dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, h->x, ML, Ly.Fp, D);
         f2.R = h->x;
+        f2.a_amax = am(dzn_handle::AM_MID);
+        f2.c_amax = am(dzn_handle::AM_X);
         gemm(f2, lp, false, "ffn2");
       }
-      ln_t(h->x, false, D, h->x, false, D, Ly.ln2, ML, D, 0, st);
+      ln_t(h->x, false, D, h->x, false, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_X));
       chk(launch_ws_accum(h->x, h->ws, wl, 0, ML * D, st), "ws_accum");
     }
     if (h->debug) {
@@ -1035,29 +1160,46 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       pin = h->y;
     }
     dzn_gemm_desc d = gd(h, pin, h->proj, h->hz, ML, D, A);
-    gemm(d, lp, false, "proj");
-    ln_t(h->hz, false, A, h->hz, false, A, h->lnorm, ML, A, 0, st);
+    gemm(d, lp, false, "proj");   // (ws has no tracker: bf16 split)
+    ln_t(h->hz, false, A, h->hz, false, A, h->lnorm, ML, A, 0, st, nullptr, am(dzn_handle::AM_HZ));
   }
   tap(h, "head_in", h->hz, ML, A, A, st);
   for (int i = 0; i < c.conf_layers; ++i) {
     ConfLayer& Cl = h->conf[i];
     auto half_ffn = [&](const LNp& ln, const Lin& w1, const Lin& w2) {
-      ln_t(h->hz, false, A, h->ht, lp, A, ln, ML, A, 0, st);
-      dzn_gemm_desc a = gd(h, h->ht, w1, h->hmid, ML, A, Fh);
+      const float* in = h->ht;
+      if (fold) {
+        chk(launch_row_stats(h->hz, A, ML, A, 1e-5f, h->rstat, st), "row_stats");
+        in = h->hz;
+      } else {
+        ln_t(h->hz, false, A, h->ht, lp, A, ln, ML, A, 0, st);
+      }
+      dzn_gemm_desc a = gd(h, in, w1, h->hmid, ML, A, Fh);
+      if (fold) folded(a, w1);
       a.act = DZN_ACT_SWISH;
+      if (in == h->hz) a.a_amax = am(dzn_handle::AM_HZ);
+      a.c_amax = am(dzn_handle::AM_HMID);
       gemm(a, lp, lp, "conf ffn w1");
       dzn_gemm_desc b = gd(h, h->hmid, w2, h->hz, ML, Fh, A);
       b.alpha = 0.5f;
       b.R = h->hz;
+      b.a_amax = am(dzn_handle::AM_HMID);
+      b.c_amax = am(dzn_handle::AM_HZ);
       gemm(b, lp, false, "conf ffn w2");
     };
     half_ffn(Cl.ffn1_ln, Cl.ffn1_w1, Cl.ffn1_w2);
     // MHSA
-    ln_t(h->hz, false, A, h->ht, lp, A, Cl.mha_ln, ML, A, 0, st);
+    if (fold) chk(launch_row_stats(h->hz, A, ML, A, 1e-5f, h->rstat, st), "row_stats");
+    else ln_t(h->hz, false, A, h->ht, lp, A, Cl.mha_ln, ML, A, 0, st);
     {
-      dzn_gemm_desc q = gd(h, h->ht, Cl.qkv, h->hmid, ML, A, 3 * A);
+      dzn_gemm_desc q = gd(h, fold ? h->hz : h->ht, Cl.qkv, h->hmid, ML, A, 3 * A);
+      if (fold) {
+        folded(q, Cl.qkv);
+        q.a_amax = am(dzn_handle::AM_HZ);
+      }
+      q.c_amax = am(dzn_handle::AM_HMID);
       gemm(q, lp, false, "conf qkv");
-      if (c.precision == DZN_PREC_F32_SPLIT)
+      if (prec_is_split(c.precision))
         chk(launch_attention_split(h->hmid, h->hv, nullptr, nullptr, nullptr, B, L, c.conf_heads, 0, 3 * A, A,
                                    0.125f, st),
             "conf attention");
@@ -1067,21 +1209,30 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
             "conf attention");
       dzn_gemm_desc o = gd(h, h->hv, Cl.o, h->hz, ML, A, A);
       o.R = h->hz;
+      o.a_amax = am(dzn_handle::AM_HMID);   // attention output <= max |q/k/v| (convex combinations of v)
+      o.c_amax = am(dzn_handle::AM_HZ);
       gemm(o, lp, false, "conf out");
     }
     // conv module
-    ln_t(h->hz, false, A, h->ht, lp, A, Cl.conv_ln, ML, A, 0, st);
+    if (fold) chk(launch_row_stats(h->hz, A, ML, A, 1e-5f, h->rstat, st), "row_stats");
+    else ln_t(h->hz, false, A, h->ht, lp, A, Cl.conv_ln, ML, A, 0, st);
     {
-      dzn_gemm_desc p1 = gd(h, h->ht, Cl.pw1, h->hmid, ML, A, 2 * A);
+      dzn_gemm_desc p1 = gd(h, fold ? h->hz : h->ht, Cl.pw1, h->hmid, ML, A, 2 * A);
+      if (fold) {
+        folded(p1, Cl.pw1);
+        p1.a_amax = am(dzn_handle::AM_HZ);
+      }
+      p1.c_amax = am(dzn_handle::AM_HMID);
       gemm(p1, lp, false, "conf pw1");
       chk(launch_glu_dwconv(h->hmid, 2 * A, Cl.dw, Cl.dwb, h->hv, lp, A, B, L, A, c.conf_kernel, st),
           "glu_dwconv");
       dzn_gemm_desc p2 = gd(h, h->hv, Cl.pw2, h->hz, ML, A, A);
       p2.R = h->hz;
+      p2.c_amax = am(dzn_handle::AM_HZ);    // (glu_dwconv output has no tracker: bf16 split)
       gemm(p2, lp, false, "conf pw2");
     }
     half_ffn(Cl.ffn2_ln, Cl.ffn2_w1, Cl.ffn2_w2);
-    ln_t(h->hz, false, A, h->hz, false, A, Cl.out_ln, ML, A, 0, st);
+    ln_t(h->hz, false, A, h->hz, false, A, Cl.out_ln, ML, A, 0, st, nullptr, am(dzn_handle::AM_HZ));
     if (h->debug) {
       const std::string nm = "conf" + std::to_string(i);
       tap(h, nm.c_str(), h->hz, ML, A, A, st);
@@ -1123,6 +1274,17 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
   chk(launch_stem_conv(h->fb, B, T, NB, h->sC[0], h->stem_w, h->stem_b, h->sbuf[0][0], lp, st), "stem");
   const float* prev = nullptr;  // output image of the previous stage
   int cur = 0;
+  // DZN_PREC_F32_H2: one |max| tracker per image buffer (sbuf[s][k] -> slot AM_IMG0 + 3 s + k); images written
+  // by the stem / the dedicated stage-1 kernel have none, so their consumers take the bf16 split
+  const bool h2 = c.precision == DZN_PREC_F32_H2;
+  if (h2) HIPCHK(hipMemsetAsync(h->amax + dzn_handle::AM_IMG0, 0, 12 * sizeof(float), st));
+  auto img_am = [&](const float* buf) -> float* {
+    if (!h2 || !buf) return nullptr;
+    for (int s2 = 1; s2 < 4; ++s2)
+      for (int k = 0; k < 3; ++k)
+        if (buf == h->sbuf[s2][k]) return h->amax + dzn_handle::AM_IMG0 + 3 * s2 + k;
+    return nullptr;
+  };
   for (int s = 0; s < 4; ++s) {
     const int Hs = h->sH[s], Ws = h->sW[s], Cc = h->sC[s];
     const int64_t img = h->simg[s];
@@ -1130,7 +1292,7 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
     const int M = Hs * Ws;
     auto conv3 = [&](const float* in, const ResConv& rc, float* out, const float* R, int act,
                      int post_relu) {
-      if (c.precision == DZN_PREC_F32_SPLIT && rc.cin == 32 && rc.cout == 32 && rc.l.W3 &&
+      if (prec_is_split(c.precision) && rc.cin == 32 && rc.cout == 32 && rc.l.W3 &&
           (act == DZN_ACT_NONE || act == DZN_ACT_RELU)) {
         // first ResNet stage: dedicated kernel, every input pixel split once instead of once per tap
         chk(launch_conv3x3_c32_split(in, rc.l.W3, rc.l.b, R, out, B, Hs, Ws, act == DZN_ACT_RELU, post_relu, st),
@@ -1150,6 +1312,8 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
       d.a_z0 = img;
       d.c_z0 = img;
       d.a_bf16 = d.c_bf16 = d.r_bf16 = lp;
+      d.a_amax = img_am(in);
+      d.c_amax = img_am(out);
       chk(launch_gemm(d, st), "resnet conv3x3");
     };
     for (size_t j = 0; j < h->stages[s].size(); ++j) {
@@ -1171,6 +1335,8 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
         d.a_z0 = pimg;
         d.c_z0 = img;
         d.a_bf16 = d.c_bf16 = lp;
+        d.a_amax = img_am(prev);
+        d.c_amax = img_am(midb);
         chk(launch_gemm(d, st), "resnet conv3x3 s2");
         dzn_gemm_desc e = gd(h, eoff(prev, ((int64_t)(Wp + 2) + 1) * Cpv, lp), rb.sc.l,
                              eoff(scb, interior, lp), M, 0, 0);
@@ -1180,6 +1346,8 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
         e.a_z0 = pimg;
         e.c_z0 = img;
         e.a_bf16 = e.c_bf16 = lp;
+        e.a_amax = img_am(prev);
+        e.c_amax = img_am(scb);
         chk(launch_gemm(e, st), "resnet shortcut");
         conv3(midb, rb.c2, outb, scb, DZN_ACT_NONE, 1);
         cur = 1;
@@ -1236,7 +1404,7 @@ int dzn_create(const dzn_config* cfg, dzn_handle** out) {
   }
   if (cfg->max_batch < 1 || cfg->max_samples < 400 ||
       (cfg->precision != DZN_PREC_F32 && cfg->precision != DZN_PREC_BF16 &&
-       cfg->precision != DZN_PREC_F32_SPLIT)) {
+       cfg->precision != DZN_PREC_F32_SPLIT && cfg->precision != DZN_PREC_F32_H2)) {
     last_create_error = "bad max_batch / max_samples / precision";
     return DZN_E_INVALID;
   }

@@ -250,6 +250,7 @@ int launch_conv0(const float* wave, int B, int N, const float* stats, const floa
 
 int launch_groupnorm_gelu(const float* x, void* y, int y_bf16, int B, int T, int C, int Cp, int64_t ld,
                           const float* gamma, const float* beta, float eps, float* stats, hipStream_t st) {
+  ProfScope prof_scope_(st, "groupnorm_gelu");
   hipLaunchKernelGGL(col_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, T, C, ld, eps, stats);
   if (y_bf16)
     hipLaunchKernelGGL(gn_gelu_kernel<u16>, dim3(grid_for((int64_t)T * Cp), B), dim3(256), 0, st, x,
@@ -262,6 +263,7 @@ int launch_groupnorm_gelu(const float* x, void* y, int y_bf16, int B, int T, int
 
 int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int Lp, int pad, int D,
                     hipStream_t st) {
+  ProfScope prof_scope_(st, "pad_rows");
   if (out_bf16)
     hipLaunchKernelGGL(pad_rows_kernel<u16>, dim3(grid_for((int64_t)Lp * (D / 4)), B), dim3(256), 0, st,
                        x, static_cast<u16*>(xpad), L, Lp, pad, D / 4);
@@ -272,12 +274,14 @@ int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int 
 }
 
 int launch_ws_accum(const float* x, float* ws, float w, int init, int64_t n, hipStream_t st) {
+  ProfScope prof_scope_(st, "ws_accum");
   hipLaunchKernelGGL(ws_accum_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, ws, w, init, n / 4);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
 int launch_col_scale(void* x, int x_bf16, int64_t rows, int C, int64_t ld, const float* scale,
                      hipStream_t st) {
+  ProfScope prof_scope_(st, "col_scale");
   if (x_bf16)
     hipLaunchKernelGGL(col_scale_kernel<u16>, dim3(grid_for(rows * C)), dim3(256), 0, st,
                        static_cast<u16*>(x), rows, C, ld, scale);

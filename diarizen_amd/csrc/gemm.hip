@@ -438,8 +438,8 @@ int launch_gemm(const dzn_gemm_desc& din, hipStream_t s) {
     return launch_prec<true>(d, s);
   }
   if (!d.W) return DZN_E_INVALID;
-  if (d.a_split3) return d.precision == DZN_PREC_F32_SPLIT ? launch_gemm_split_pre(d, s) : DZN_E_INVALID;
-  if (d.precision == DZN_PREC_F32_SPLIT && d.W3 && !(d.K & 31) && !(d.kc & 31) && d.ldw == d.K)
+  if (d.a_split3) return prec_is_split(d.precision) ? launch_gemm_split_pre(d, s) : DZN_E_INVALID;
+  if (prec_is_split(d.precision) && d.W3 && !(d.K & 31) && !(d.kc & 31) && d.ldw == d.K)
     return launch_gemm_split(d, s);
   return launch_prec<false>(d, s);
 }

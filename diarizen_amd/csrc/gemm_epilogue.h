@@ -9,21 +9,39 @@ namespace {
 
 template <int BM, int BN, int TM, int TN, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
-                                              int wm, int wn, int lr, int lq, int64_t cz, int64_t bz) {
+                                              int wm, int wn, int lr, int lq, int64_t cz, int64_t bz,
+                                              float acc_scale = 1.f, const float* col_scale = nullptr) {
   // ---- epilogue: lane (lr, lq) of block (i, j) holds row m = ..+lr, columns n0..n0+3 ----
   const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
   const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0;
+  float amax = 0.f;   // running |max| of what this lane stores (d.c_amax: the scale of the fp16 split of the consumer)
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = tm * BM + wm * TM + i * 16 + lr;
     if (m >= d.M) continue;
     const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
+    // LayerNorm folded into the weights: finish it with the row statistics (dzn_ops.h)
+    float ln_mu = 0.f, ln_rs = 1.f;
+    if (d.ln_stats) {
+      const float2 st = *reinterpret_cast<const float2*>(d.ln_stats + 2 * (int64_t)m);
+      ln_mu = st.x;
+      ln_rs = st.y;
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n0 = tn * BN + wn * TN + j * 16 + lq * 4;
       if (n0 >= d.N) continue;
       f32x4 v = acc[i][j];
       if (vec && n0 + 3 < d.N) {
+        if (col_scale) {   // fp16 two-term operands were scaled by exact powers of two: undo (exact)
+          const float4 c4 = *reinterpret_cast<const float4*>(col_scale + n0);
+          v[0] *= acc_scale * c4.x; v[1] *= acc_scale * c4.y; v[2] *= acc_scale * c4.z; v[3] *= acc_scale * c4.w;
+        }
+        if (d.ln_stats) {
+          const float4 s4 = *reinterpret_cast<const float4*>(d.ln_colsum + n0);
+          v[0] = ln_rs * (v[0] - ln_mu * s4.x); v[1] = ln_rs * (v[1] - ln_mu * s4.y);
+          v[2] = ln_rs * (v[2] - ln_mu * s4.z); v[3] = ln_rs * (v[3] - ln_mu * s4.w);
+        }
         if (bias) {
           const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
           v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
@@ -39,6 +57,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         *reinterpret_cast<float4*>(d.C + crow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         if (d.WS) {
           float4* w = reinterpret_cast<float4*>(d.WS + (int64_t)m * d.ldws + n0);
           float4 a = d.ws_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *w;
@@ -51,11 +70,14 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
           const int n = n0 + e;
           if (n >= d.N) continue;
           float x = v[e];
+          if (col_scale) x *= acc_scale * col_scale[n];
+          if (d.ln_stats) x = ln_rs * (x - ln_mu * d.ln_colsum[n]);
           if (bias) x += bias[n];
           x = apply_act(x, d.act) * d.alpha;
           if (d.R) x += d.R[crow + n];
           if (d.post_relu) x = fmaxf(x, 0.f);
           d.C[crow + n] = x;
+          amax = fmaxf(amax, fabsf(x));
           if (d.WS) {
             float* w = d.WS + (int64_t)m * d.ldws + n;
             *w = d.ws_init ? d.ws_w * x : (*w + d.ws_w * x);
@@ -63,6 +85,11 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
         }
       }
     }
+  }
+  if (d.c_amax) {
+    amax = wave_max(amax);
+    // |x| >= 0: the IEEE bit patterns order like unsigned integers, so the max is order independent (deterministic)
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(d.c_amax), __float_as_uint(amax));
   }
 }
 

@@ -22,6 +22,18 @@
 //       of a W tile is a [BN][64 B] LDS image; slot s of row r is stored at s ^ g((r>>2)&3),
 //       g = (0,2,3,1), which makes the four 16-lane groups of ds_read_b128 conflict free.
 // Requires K % 32 == 0 and kc % 32 == 0 (else the caller falls back to the fp32 MFMA kernel).
+//
+// NP = 2 ("f32h", DZN_PREC_F32_H2): the same kernel with a TWO-term fp16 split and THREE products
+// (hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16) — the error-corrected tensor-core scheme of Ootomo &
+// Yokota (and of "3xTF32": fp16 and TF32 both carry 11 significant bits).  x*s = hi + lo + r with
+// hi = fp16(x*s), lo = fp16(x*s - hi), |r| <= 2^-22 |x*s|; the dropped terms (lo*lo and the two residuals) are
+// <= 3 * 2^-22 |a w| — the size of a few fp32 roundings of the product — and half the matrix-pipe work of
+// NP = 3.  fp16's 5-bit exponent is handled by EXACT power-of-two scaling on both sides: the weights are
+// scaled per output row when they are split (max |w| of the row lands in [2^14, 2^15), dzn_op_split_weights_h2),
+// the activations by s = 2^(14 - floor(log2 amax)) from the running |max| the PRODUCER of the tensor tracked
+// (dzn_gemm_desc.a_amax / c_amax); the epilogue multiplies the accumulator by the exact inverse powers of two.
+// Elements more than 2^17 below the tensor's maximum keep a lo term in fp16's subnormal range: their ABSOLUTE
+// error stays <= 2^-25 * max / 2^14, i.e. below fp32 resolution of any dot product that contains the maximum.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -52,7 +64,45 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 //     rows is multiplied, then [wait tile kt+1, barrier, refill the stage of tile kt], then the
 //     fragments of tile kt+1 are read into the second register set while the second half of
 //     tile kt is multiplied — the matrix pipe has work queued across the barrier.
-template <int BM, int BN, int WGM, int WGN, int S>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// a 128-bit MFMA operand fragment of either element type
+template <int NP>
+__device__ __forceinline__ f32x4 mfma_np(const u32x4& a, const u32x4& b, f32x4 c) {
+  if constexpr (NP == 3)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// 8 fp32 values (two float4), pre-scaled by the exact power of two s -> two fp16x8 fragments (hi, lo)
+__device__ __forceinline__ void split8_h2(const f32x4& u, const f32x4& v, float s, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 x;
+    x[0] = (p < 2 ? u[2 * p] : v[2 * p - 4]) * s;
+    x[1] = (p < 2 ? u[2 * p + 1] : v[2 * p - 3]) * s;
+    const f16x2 h = __builtin_convertvector(x, f16x2);        // v_cvt_pk_f16_f32 (round to nearest even)
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    f32x2 r;
+    r[0] = x[0] - hf[0];                                      // exact in fp32
+    r[1] = x[1] - hf[1];
+    hi[p] = __builtin_bit_cast(unsigned, h);
+    lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+  }
+}
+
+// exact power-of-two scale that puts `amax` into [2^14, 2^15) (fp16 max is 65504), and its inverse
+__device__ __forceinline__ void h2_scale(float amax, float& s, float& inv) {
+  int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;   // floor(log2 amax) for normal amax
+  if (!(amax > 0.f) || e > 100) e = 14;                         // empty / non-finite tracker: scale 1
+  e = e < -100 ? -100 : e;
+  s = __uint_as_float((unsigned)(14 - e + 127) << 23);
+  inv = __uint_as_float((unsigned)(e - 14 + 127) << 23);
+}
+
+template <int BM, int BN, int WGM, int WGN, int S, int NP>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_gemm_desc d) {
   constexpr int NW = WGM * WGN;           // wavefronts per workgroup
   constexpr int BK = 32;
@@ -62,8 +112,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
   constexpr int ACH = BM * 128 / RB;      // rounds of the A tile (BM rows x 128 B)
   constexpr int WROWS = NW * 16;          // rows of one W plane per round (64-B rows)
   constexpr int WR = (BN + WROWS - 1) / WROWS;
-  constexpr int ABYTES = BM * 128, WPLANE = BN * 64, BUF = ABYTES + 3 * WPLANE;
-  constexpr int LPT = ACH + 3 * WR;       // LDS-DMA instructions per thread per tile (3 fewer for the
+  constexpr int ABYTES = BM * 128, WPLANE = BN * 64, BUF = ABYTES + NP * WPLANE;
+  constexpr int LPT = ACH + NP * WR;      // LDS-DMA instructions per thread per tile (NP fewer for the
                                           // wavefronts that sit out a partial last W round)
   constexpr bool WPART = BN % WROWS != 0;
   static_assert(BM * 128 % RB == 0, "A tile must be whole rounds");
@@ -85,7 +135,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
   const int z = blockIdx.y;
   const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
   const float* __restrict__ A = d.A + z0 * d.a_z0 + z1 * d.a_z1;
-  const u16* __restrict__ W3 = reinterpret_cast<const u16*>(d.W3) + 3 * (z0 * d.w_z0 + z1 * d.w_z1);
+  const u16* __restrict__ W3 =
+      reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + NP * (z0 * d.w_z0 + z1 * d.w_z1);
+  float a_scale = 1.f, acc_scale = 1.f;
+  if constexpr (NP == 2) h2_scale(*d.a_amax, a_scale, acc_scale);
   const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
   const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
 
@@ -109,7 +162,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
   for (int i = 0; i < WR; ++i) {
     int n = tn * BN + wr0 + WROWS * i;
     n = n < d.N ? n : d.N - 1;
-    wptr[i] = W3 + (int64_t)n * 3 * d.ldw + wsw * 8;
+    wptr[i] = W3 + (int64_t)n * NP * d.ldw + wsw * 8;
   }
 
   // the next K tile to fetch: k index and its A element offset (two-level K addressing), advanced
@@ -124,12 +177,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[i] + ikoff),
                                        (__attribute__((address_space(3))) void*)(sA + i * RB), 16, 0, 0);
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int i = 0; i < WR; ++i)
         if (i + 1 < WR || wfull)
           __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(wptr[i] + 3 * ik + p * 32),
+              (const __attribute__((address_space(1))) void*)(wptr[i] + NP * ik + p * 32),
               (__attribute__((address_space(3))) void*)(sW + p * WPLANE + i * RB), 16, 0, 0);
     ik += BK;
     irem += BK;
@@ -158,12 +211,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
     aoff0[i] = row * 128 + ((lq ^ sw) << 4);
     aoff1[i] = row * 128 + (((4 + lq) ^ sw) << 4);
   }
-  auto read_w = [&](int stage, bf16x8 (&wf)[NI][3]) {
+  auto read_w = [&](int stage, u32x4 (&wf)[NI][NP]) {
     const unsigned char* base = smem + stage * BUF;
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wf[j][p] = *reinterpret_cast<const bf16x8*>(base + p * WPLANE + woff[j]);
+      for (int p = 0; p < NP; ++p) wf[j][p] = *reinterpret_cast<const u32x4*>(base + p * WPLANE + woff[j]);
   };
   auto read_a = [&](int stage, f32x4 (&ar)[MI][2]) {
     const unsigned char* base = smem + stage * BUF;
@@ -173,24 +226,33 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
       ar[i][1] = *reinterpret_cast<const f32x4*>(base + aoff1[i]);
     }
   };
-  // six products of one 16-row block against all NI column blocks: smallest terms first, NI
-  // independent accumulators between dependent MFMAs
-  auto mma6 = [&](int i, const bf16x8 (&wf)[NI][3], const bf16x8& ah, const bf16x8& am, const bf16x8& al) {
+  // the products of one 16-row block against all NI column blocks: smallest terms first, NI independent
+  // accumulators between dependent MFMAs.  af[] = A terms (hi, [mid,] lo), wf[j][] = W planes (hi, [mid,] lo).
+  auto mma = [&](int i, const u32x4 (&wf)[NI][NP], const u32x4 (&af)[NP]) {
+    if constexpr (NP == 3) {
+      constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};   // lo*hi hi*lo mid*mid mid*hi hi*mid hi*hi
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][2], ah, acc[i][j], 0, 0, 0);
+      for (int t = 0; t < 6; ++t)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], al, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][PW[t]], af[PA[t]], acc[i][j]);
+    } else {
+      constexpr int PW[3] = {1, 0, 0}, PA[3] = {0, 1, 0};                     // lo*hi hi*lo hi*hi
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], am, acc[i][j], 0, 0, 0);
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], ah, acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], am, acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], ah, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][PW[t]], af[PA[t]], acc[i][j]);
+    }
   };
-  auto split = [&](const f32x4 (&a)[2], bf16x8& ah, bf16x8& am, bf16x8& al) {
-    split8(a[0], a[1], ah, am, al);
+  auto split = [&](const f32x4 (&a)[2], u32x4 (&af)[NP]) {
+    if constexpr (NP == 3) {
+      bf16x8 h_, m_, l_;
+      split8(a[0], a[1], h_, m_, l_);
+      af[0] = __builtin_bit_cast(u32x4, h_);
+      af[1] = __builtin_bit_cast(u32x4, m_);
+      af[2] = __builtin_bit_cast(u32x4, l_);
+    } else {
+      split8_h2(a[0], a[1], a_scale, af[0], af[1]);
+    }
   };
 
   const int nk = d.K / BK;
@@ -201,29 +263,29 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
   auto wait_tiles = [&](auto tiles) {
     constexpr int T = decltype(tiles)::value;
     if (wfull) wait_vm_lgkm0<T * LPT>();
-    else wait_vm_lgkm0<T * (LPT - 3)>();
+    else wait_vm_lgkm0<T * (LPT - NP)>();
   };
   if (nk >= S) wait_tiles(std::integral_constant<int, S - 1>{});
   else wait_vm_lgkm0<0>();
   __builtin_amdgcn_s_barrier();
-  bf16x8 wfa[NI][3], wfb[NI][3];
+  u32x4 wfa[NI][NP], wfb[NI][NP];
   f32x4 ar[MI][2];
   read_w(0, wfa);
   read_a(0, ar);
   int stage = 0;
 
   // one K tile: `wc` holds its W fragments, `ar` its raw A fragments; leaves tile kt+1 in (wn_, ar)
-  auto step = [&](int kt, const bf16x8 (&wc)[NI][3], bf16x8 (&wn_)[NI][3]) {
+  auto step = [&](int kt, const u32x4 (&wc)[NI][NP], u32x4 (&wn_)[NI][NP]) {
     const bool more = kt + 1 < nk;
 #pragma unroll
     for (int i = 0; i < MH; ++i) {
-      bf16x8 ah, am, al;
-      split(ar[i], ah, am, al);
-      mma6(i, wc, ah, am, al);
+      u32x4 af[NP];
+      split(ar[i], af);
+      mma(i, wc, af);
     }
-    bf16x8 ah[MI - MH], am[MI - MH], al[MI - MH];
+    u32x4 af2[MI - MH][NP];
 #pragma unroll
-    for (int i = MH; i < MI; ++i) split(ar[i], ah[i - MH], am[i - MH], al[i - MH]);
+    for (int i = MH; i < MI; ++i) split(ar[i], af2[i - MH]);
     const int nstage = stage + 1 == S ? 0 : stage + 1;
     __builtin_amdgcn_sched_barrier(0);  // keep the second half of the MFMAs BEHIND the barrier block
     if (more) {
@@ -237,21 +299,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = MH; i < MI; ++i) mma6(i, wc, ah[i - MH], am[i - MH], al[i - MH]);
+    for (int i = MH; i < MI; ++i) mma(i, wc, af2[i - MH]);
     stage = nstage;
   };
   for (int kt = 0; kt < nk; kt += 2) {
     step(kt, wfa, wfb);
     if (kt + 1 < nk) step(kt + 1, wfb, wfa);
   }
-  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz);
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, acc_scale, NP == 2 ? d.col_scale : nullptr);
 }
 
-template <int BM, int BN, int WGM, int WGN, int S>
+template <int BM, int BN, int WGM, int WGN, int S, int NP>
 int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-  const size_t lds = (size_t)S * (BM * 128 + 3 * BN * 64);
-  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S>;
+  const size_t lds = (size_t)S * (BM * 128 + NP * BN * 64);
+  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, NP>;
   static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
   if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -263,9 +325,9 @@ int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     char cls[64];
     static const bool by_shape = getenv("DZN_PROFILE_SHAPES") != nullptr;
     if (by_shape)
-      snprintf(cls, sizeof(cls), "gemm_f32s_%dx%d M%d N%d K%d z%d", BM, BN, d.M, d.N, d.K, d.nz);
+      snprintf(cls, sizeof(cls), "gemm_f32%s_%dx%d M%d N%d K%d z%d", NP == 3 ? "s" : "h", BM, BN, d.M, d.N, d.K, d.nz);
     else
-      snprintf(cls, sizeof(cls), "gemm_f32s_%dx%d", BM, BN);
+      snprintf(cls, sizeof(cls), "gemm_f32%s_%dx%d", NP == 3 ? "s" : "h", BM, BN);
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
     pid = prof_begin(s, cls, fl, 0.0);
   }
@@ -296,28 +358,78 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
-}  // namespace
-
-int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s) {
-  if ((d.K & 31) || (d.kc & 31) || !d.W3 || d.ldw != d.K) return DZN_E_INVALID;
+template <int NP>
+int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   static const char* force = getenv("DZN_GEMM_CFG");   // tuning knob: force one tile shape
   if (force) {
-    if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
-    if (!strcmp(force, "256x128")) return launch_split_cfg<256, 128, 4, 2, 2>(d, s);
-    if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
-    if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2>(d, s);
-    if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2>(d, s);
+    if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
+    if (!strcmp(force, "256x128")) return launch_split_cfg<256, 128, 4, 2, 2, NP>(d, s);
+    if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
+    if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2, NP>(d, s);
+    if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
   }
-  if (d.N <= 32) return launch_split_cfg<128, 32, 4, 1, 2>(d, s);
+  if (d.N <= 32) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
   // 128x64 tiles run 4 wavefronts as 4x1 (32 rows x 64 columns each): the in-register operand
   // split is per A row, so wide-and-short wavefront tiles halve the VALU work per MFMA
-  if (d.N <= 64 || d.K <= 512) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
+  if (d.N <= 64 || d.K <= 512) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
   // 128-wide column tiles unless 64-wide ones save more than ~1/8 of the (padded) columns; widths that
   // are multiples of 80 but not of 64 (conv1 of the extractor: 153 -> 160) get exact 80-wide tiles
   const int cols128 = (d.N + 127) / 128 * 128, cols64 = (d.N + 63) / 64 * 64;
-  if (d.N % 80 == 0 && d.N < cols64 && d.N * 9 < cols128 * 8) return launch_split_cfg<128, 80, 4, 1, 2>(d, s);
-  if (cols64 * 9 < cols128 * 8) return launch_split_cfg<128, 64, 4, 1, 2>(d, s);
-  return launch_split_cfg<128, 128, 2, 2, 2>(d, s);
+  if (d.N % 80 == 0 && d.N < cols64 && d.N * 9 < cols128 * 8) return launch_split_cfg<128, 80, 4, 1, 2, NP>(d, s);
+  if (cols64 * 9 < cols128 * 8) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
+  return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
+}
+
+// W [rows][K] fp32 -> W2h [rows][K/32][2][32] fp16 (k permuted as above) of w * 2^e_row, e_row chosen so that
+// the row's max |w| lands in [2^14, 2^15); col_scale[row] = 2^-e_row (exact).  One wavefront per row.
+__global__ __launch_bounds__(256) void split_weights_h2_kernel(const float* __restrict__ W, int64_t rows, int K,
+                                                               int64_t ldw, u16* __restrict__ W2, float* __restrict__ col_scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float m = 0.f;
+  for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(W[r * ldw + k]));
+  m = wave_max(m);
+  float sc, inv;
+  h2_scale(m, sc, inv);
+  if (lane == 0) col_scale[r] = inv;
+  for (int k = lane; k < K; k += 64) {
+    const float x = W[r * ldw + k] * sc;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    const int kk = k & 31;
+    const int pos = 8 * ((kk & 15) >> 2) + (kk & 3) + 4 * (kk >> 4);
+    u16* o = W2 + r * 2 * K + (int64_t)(k >> 5) * 64 + pos;
+    o[0] = __builtin_bit_cast(u16, h);
+    o[32] = __builtin_bit_cast(u16, l);
+  }
+}
+
+}  // namespace
+
+int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s) {
+  if ((d.K & 31) || (d.kc & 31) || d.ldw != d.K) return DZN_E_INVALID;
+  // fp16 two-term path: needs the fp16 planes + their row scales, the producer-tracked |max| of A, and weights
+  // that do not move with z (col_scale is indexed by the output column alone)
+  static const bool no_h2 = getenv("DZN_NO_H2") != nullptr;
+  if (d.precision == DZN_PREC_F32_H2 && d.W2h && d.col_scale && d.a_amax && !d.w_z0 && !d.w_z1 && !no_h2)
+    return launch_gemm_split_np<2>(d, s);
+  if (!d.W3) return DZN_E_INVALID;
+  return launch_gemm_split_np<3>(d, s);
+}
+
+int launch_split_weights_h2(const float* W, int64_t rows, int K, int64_t ldw, void* W2, float* col_scale, hipStream_t s) {
+  if (rows <= 0) return DZN_OK;
+  if (K <= 0 || (K & 31)) return DZN_E_INVALID;
+  hipLaunchKernelGGL(split_weights_h2_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, W, rows, K, ldw,
+                     static_cast<u16*>(W2), col_scale);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+extern "C" int dzn_op_split_weights_h2(const float* W, int64_t rows, int32_t K, int64_t ldw, void* W2, float* col_scale,
+                                       void* stream) {
+  if (!W || !W2 || !col_scale) return DZN_E_INVALID;
+  return launch_split_weights_h2(W, rows, K, ldw, W2, col_scale, reinterpret_cast<hipStream_t>(stream));
 }
 
 int launch_split_weights(const float* W, int64_t rows, int K, int64_t ldw, void* W3, hipStream_t s) {

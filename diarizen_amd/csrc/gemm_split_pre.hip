@@ -263,6 +263,7 @@ extern "C" int dzn_op_split_rows(const float* x, void* planes, int64_t plane_str
 
 int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
                            hipStream_t st) {
+  ProfScope prof_scope_(st, "pad_rows_split3");
   if (D % 32) return DZN_E_INVALID;
   int64_t g = cdiv64((int64_t)Lp * (D / 8), 256);
   g = g > 4096 ? 4096 : g;

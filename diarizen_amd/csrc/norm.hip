@@ -18,10 +18,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         const float* __restrict__ post, int64_t rows,
-                                                        int C, int Cpad, float eps, int gelu) {
+                                                        int C, int Cpad, float eps, int gelu,
+                                                        float* __restrict__ amax_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= rows) return;
+  float amax = 0.f;
   const TI* xp = x + row * ldx;
   float v[MAXI];
   float sum = 0.f;
@@ -51,10 +53,50 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
       if (gelu) o = gelu_erf(o);
       if (post) o *= post[idx];
       st_act(yp, idx, o);
+      amax = fmaxf(amax, fabsf(o));
     } else if (idx < Cpad) {
       st_act(yp, idx, 0.f);
     }
   }
+  if (amax_out) {   // |max| tracker of the output tensor (scale of the consumer's fp16 split, gemm_split.hip)
+    amax = wave_max(amax);
+    if (lane == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(amax));
+  }
+}
+
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ amax_out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+}
+
+// (mean, rstd) of each row — the LayerNorm whose affine part is folded into the consuming contraction
+// (dzn_gemm_desc.ln_stats): one read of x, no write of a normalised copy.
+template <int MAXI>
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int C,
+                                                        float eps, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const float* xp = x + row * ldx;
+  float v[MAXI];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int idx = lane + 64 * i;
+    v[i] = idx < C ? xp[idx] : 0.f;
+    sum += v[i];
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const float dv = lane + 64 * i < C ? v[i] - mean : 0.f;
+    sq += dv * dv;
+  }
+  const float var = wave_sum(sq) / (float)C;
+  if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mean, 1.0f / sqrtf(var + eps));
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y,
@@ -103,12 +145,13 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(const float* __restric
 
 template <typename TI, typename TO>
 int launch_ln_typed(const TI* x, int64_t ldx, TO* y, int64_t ldy, const float* g, const float* b,
-                    const float* post, int64_t rows, int C, int Cpad, float eps, int gelu, hipStream_t s) {
+                    const float* post, int64_t rows, int C, int Cpad, float eps, int gelu, hipStream_t s,
+                    float* amax) {
   const unsigned grid = (unsigned)cdiv64(rows, 4);
   const int need = (Cpad > C ? Cpad : C);
 #define DZN_LN(MAXI)                                                                               \
   hipLaunchKernelGGL((layernorm_kernel<MAXI, TI, TO>), dim3(grid), dim3(256), 0, s, x, ldx, y, ldy, g, \
-                     b, post, rows, C, Cpad, eps, gelu)
+                     b, post, rows, C, Cpad, eps, gelu, amax)
   if (need <= 256) DZN_LN(4);
   else if (need <= 512) DZN_LN(8);
   else if (need <= 1024) DZN_LN(16);
@@ -121,17 +164,18 @@ int launch_ln_typed(const TI* x, int64_t ldx, TO* y, int64_t ldy, const float* g
 
 int launch_layernorm_t(const void* x, int x_bf16, int64_t ldx, void* y, int y_bf16, int64_t ldy,
                        const float* g, const float* b, const float* post, int64_t rows, int C, int Cpad,
-                       float eps, int gelu, hipStream_t s) {
+                       float eps, int gelu, hipStream_t s, float* amax) {
+  ProfScope prof_scope_(s, "layernorm", 0.0, (double)rows * C * 8.0);
   if (rows <= 0) return DZN_OK;
   if (C <= 0 || C > 2048 || Cpad > 2048) return DZN_E_INVALID;
   const float* xf = static_cast<const float*>(x);
   const u16* xh = static_cast<const u16*>(x);
   float* yf = static_cast<float*>(y);
   u16* yh = static_cast<u16*>(y);
-  if (!x_bf16 && !y_bf16) return launch_ln_typed(xf, ldx, yf, ldy, g, b, post, rows, C, Cpad, eps, gelu, s);
-  if (!x_bf16 && y_bf16) return launch_ln_typed(xf, ldx, yh, ldy, g, b, post, rows, C, Cpad, eps, gelu, s);
-  if (x_bf16 && !y_bf16) return launch_ln_typed(xh, ldx, yf, ldy, g, b, post, rows, C, Cpad, eps, gelu, s);
-  return launch_ln_typed(xh, ldx, yh, ldy, g, b, post, rows, C, Cpad, eps, gelu, s);
+  if (!x_bf16 && !y_bf16) return launch_ln_typed(xf, ldx, yf, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax);
+  if (!x_bf16 && y_bf16) return launch_ln_typed(xf, ldx, yh, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax);
+  if (x_bf16 && !y_bf16) return launch_ln_typed(xh, ldx, yf, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax);
+  return launch_ln_typed(xh, ldx, yh, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax);
 }
 
 int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* g,
@@ -140,7 +184,42 @@ int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const f
   return launch_layernorm_t(x, 0, ldx, y, 0, ldy, g, b, nullptr, rows, C, Cpad, eps, gelu, s);
 }
 
+int launch_amax(const float* x, int64_t n, float* amax, hipStream_t s) {
+  if (n <= 0) return DZN_OK;
+  int64_t g = cdiv64(n, 256 * 8);
+  g = g > 4096 ? 4096 : g;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)g), dim3(256), 0, s, x, n, amax);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+extern "C" int dzn_op_amax(const float* x, int64_t n, float* amax, void* stream) {
+  if (!x || !amax) return DZN_E_INVALID;
+  return launch_amax(x, n, amax, reinterpret_cast<hipStream_t>(stream));
+}
+
+int launch_row_stats(const float* x, int64_t ldx, int64_t rows, int C, float eps, float* stats, hipStream_t s) {
+  if (rows <= 0) return DZN_OK;
+  if (C <= 0 || C > 2048) return DZN_E_INVALID;
+  const unsigned grid = (unsigned)cdiv64(rows, 4);
+  int pid = prof_enabled() ? prof_begin(s, "row_stats", 0.0, (double)rows * C * 4.0) : -1;
+#define DZN_RS(MAXI) hipLaunchKernelGGL((row_stats_kernel<MAXI>), dim3(grid), dim3(256), 0, s, x, ldx, rows, C, eps, stats)
+  if (C <= 256) DZN_RS(4);
+  else if (C <= 512) DZN_RS(8);
+  else if (C <= 1024) DZN_RS(16);
+  else DZN_RS(32);
+#undef DZN_RS
+  prof_end(pid, s);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+extern "C" int dzn_op_row_stats(const float* x, int64_t ldx, int64_t rows, int32_t C, float eps, float* stats,
+                                void* stream) {
+  if (!x || !stats) return DZN_E_INVALID;
+  return launch_row_stats(x, ldx, rows, C, eps, stats, reinterpret_cast<hipStream_t>(stream));
+}
+
 int launch_cast_bf16(const float* x, void* y, int64_t n, hipStream_t s) {
+  ProfScope prof_scope_(s, "cast_bf16");
   if (n <= 0) return DZN_OK;
   if (n & 3) return DZN_E_INVALID;
   int64_t g = cdiv64(n / 4, 256);
@@ -150,6 +229,7 @@ int launch_cast_bf16(const float* x, void* y, int64_t n, hipStream_t s) {
 }
 
 int launch_wave_stats(const float* w, int B, int N, float eps, float* stats, hipStream_t s) {
+  ProfScope prof_scope_(s, "wave_stats");
   if (B <= 0) return DZN_OK;
   hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(1024), 0, s, w, N, eps, stats);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void prepare_masks_kernel(const uint8_t* __res
 
 int launch_prepare_masks(const uint8_t* ml, int B, int L, int S, int median, int exclude_overlap,
                          int min_num_frames, uint8_t* filtered, float* masks, hipStream_t st) {
+  ProfScope prof_scope_(st, "prepare_masks");
   if (B <= 0) return DZN_OK;
   if (S < 1 || S > 8 || L < 1 || (median > 1 && !(median & 1))) return DZN_E_INVALID;
   const size_t lds = 2 * (((size_t)L * S + 3) & ~(size_t)3) + 8 * sizeof(int);

@@ -24,7 +24,8 @@ def _p(t):
 def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None, ws_w=0.0,
          ws_init=False, a_rowoff=None, c_rowoff=None, lda=None, kc=0, ldk=0, ldw=None, ldc=None,
          ldws=0, act=0, alpha=1.0, post_relu=False, nz=1, zdiv=1, zs=None, precision=0,
-         W16=None, W3=None, a_planes=None):
+         W16=None, W3=None, a_planes=None, ln_stats=None, ln_colsum=None, W2h=None, col_scale=None,
+         a_amax=None, c_amax=None):
     """C = epilogue(A @ W^T); see dzn_gemm_desc.  A: [M, K] (or raw buffer with lda / rowoff),
     W: [N, K] fp32 (and optionally W16 bf16)."""
     lib = _lib.load()
@@ -46,7 +47,7 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
         C_out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     if ldc is None:
         ldc = C_out.stride(0) if C_out.dim() == 2 else N
-    if precision == _lib.DZN_PREC_F32_SPLIT and W3 is None and K % 32 == 0 and ldw == K and W.is_contiguous():
+    if precision in (_lib.DZN_PREC_F32_SPLIT, _lib.DZN_PREC_F32_H2) and W3 is None and K % 32 == 0 and ldw == K and W.is_contiguous():
         W3 = split_weights(W.reshape(-1, K))   # convenience for tests: engines split once at load
     d = DznGemmDesc()
     d.A, d.W, d.W16, d.C = _p(A), _p(W), _p(W16), _p(C_out)
@@ -68,6 +69,12 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
     if a_planes is not None:      # A pre-split by split_rows(): [3, M, K] int16 planes
         d.A = _p(a_planes)
         d.a_split3, d.a_plane = 1, a_planes.stride(0)
+    d.ln_stats, d.ln_colsum = _p(ln_stats), _p(ln_colsum)
+    if precision == _lib.DZN_PREC_F32_H2 and W2h is None and K % 32 == 0 and ldw == K and W.is_contiguous():
+        W2h, col_scale = split_weights_h2(W.reshape(-1, K))
+        if a_amax is None:
+            a_amax = amax(A)
+    d.W2h, d.col_scale, d.a_amax, d.c_amax = _p(W2h), _p(col_scale), _p(a_amax), _p(c_amax)
     check(lib.dzn_op_gemm(C.byref(d), _stream()), what="dzn_op_gemm")
     return C_out
 
@@ -81,6 +88,28 @@ def split_weights(W):
     out = torch.empty((rows, K // 32, 3, 32), device=W.device, dtype=torch.int16)
     check(lib.dzn_op_split_weights(_p(W), rows, K, W.stride(0), _p(out), _stream()),
           what="dzn_op_split_weights")
+    return out
+
+
+def split_weights_h2(W):
+    """two-term fp16 split for precision=DZN_PREC_F32_H2: (planes int16 [rows, K // 32, 2, 32], col_scale f32 [rows])"""
+    lib = _lib.load()
+    assert W.is_cuda and W.dtype == torch.float32 and W.dim() == 2 and W.shape[1] % 32 == 0
+    rows, K = W.shape
+    out = torch.empty((rows, K // 32, 2, 32), device=W.device, dtype=torch.int16)
+    sc = torch.empty((rows,), device=W.device, dtype=torch.float32)
+    check(lib.dzn_op_split_weights_h2(_p(W), rows, K, W.stride(0), _p(out), _p(sc), _stream()),
+          what="dzn_op_split_weights_h2")
+    return out, sc
+
+
+def amax(x, out=None):
+    """device scalar max(out, max |x|) — the tracker a producer without a fused one would keep"""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    if out is None:
+        out = torch.zeros((1,), device=x.device, dtype=torch.float32)
+    check(lib.dzn_op_amax(_p(x), x.numel(), _p(out), _stream()), what="dzn_op_amax")
     return out
 
 
@@ -131,6 +160,27 @@ def layernorm(x, gamma, beta, C_true=None, eps=1e-5, gelu=False, out=None):
     check(lib.dzn_op_layernorm(_p(x), ld, _p(out), out.stride(0), _p(gamma), _p(beta), rows,
                                C_true, Cpad, eps, int(gelu), _stream()), what="dzn_op_layernorm")
     return out
+
+
+def row_stats(x, C_true=None, eps=1e-5):
+    """(mean, rstd) per row of x[:, :C_true] -> f32 [rows, 2] (the LayerNorm folded into a contraction)"""
+    lib = _lib.load()
+    rows = x.shape[0]
+    out = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    check(lib.dzn_op_row_stats(_p(x), x.stride(0), rows, C_true or x.shape[1], eps, _p(out), _stream()),
+          what="dzn_op_row_stats")
+    return out
+
+
+def gate_stats(x, gamma, beta, Wg, bg, cst, eps=1e-5):
+    """one pass over raw rows x [rows, Htot*64]: (gate [rows, Htot] on LayerNorm(x), stats [rows, 2])"""
+    lib = _lib.load()
+    rows, Htot = x.shape[0], cst.numel()
+    gate_ = torch.empty((rows, Htot), device=x.device, dtype=torch.float32)
+    stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    check(lib.dzn_op_gate_stats(_p(x), x.stride(0), _p(gamma), _p(beta), _p(Wg), _p(bg), _p(cst), _p(gate_), _p(stats),
+                                rows, Htot, eps, _stream()), what="dzn_op_gate_stats")
+    return gate_, stats
 
 
 def gate(y, Wg, bg, cst):

@@ -63,6 +63,11 @@ extern "C" {
 #define DZN_PREC_F32_SPLIT 2 /* fp32 data everywhere; contractions split both operands exactly into
                                 3 bf16 terms and run 6 bf16 MFMA products with fp32 accumulate
                                 (fp32-grade accuracy, csrc/gemm_split.hip) */
+#define DZN_PREC_F32_H2 3 /* fp32 data everywhere; contractions split both operands into TWO fp16 terms
+                           * (exact power-of-two scaling, 22 significant bits) and sum three
+                           * v_mfma_f32_16x16x32_f16 products in fp32 ("3xFP16", the error-corrected scheme
+                           * known from 3xTF32): csrc/gemm_split.hip NP = 2.  Kernels without an fp16
+                           * variant run as DZN_PREC_F32_SPLIT. */
 
 /*
  * Architecture description.  Mirrors the kwargs of

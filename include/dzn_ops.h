@@ -30,6 +30,7 @@ extern "C" {
  *   A(m,k)   = A[ zA + rowbase(m) + (k / kc) * ldk + (k % kc) ]
  *   rowbase  = a_rowoff ? a_rowoff[m] : m * lda            (element offsets)
  *   W[n,k]   = W[ zW + n * ldw + k ]                        (torch Linear / packed conv layout)
+ *   acc      = rstd[m] * (acc - mean[m] * ln_colsum[n])      if ln_stats  (LayerNorm folded into the weights)
  *   v        = act(acc + bias[zB + n]) * alpha
  *   v       += R[ zC + crow(m) + n ]        if R            crow = c_rowoff ? c_rowoff[m] : m*ldc
  *   v        = max(v, 0)                    if post_relu
@@ -78,6 +79,20 @@ typedef struct dzn_gemm_desc {
    * elements apart, written by the producer in the weight planes' k order (csrc/gemm_split_pre.hip) */
   int32_t a_split3;
   int64_t a_plane;
+  /* LayerNorm folded into this contraction (pre-norm sites: y = LN(x) feeds only linears): A is the RAW row x,
+   * W already carries gamma (W' = W diag(gamma)), bias carries W beta, and the epilogue finishes the norm with the
+   * per-row statistics: acc = rstd[m] * (acc - mean[m] * ln_colsum[n]), ln_colsum[n] = sum_k W'[n,k].
+   * ln_stats = f32 [M][2] (mean, rstd) written by dzn_op_row_stats / the fused gate kernel; NULL = plain. */
+  const float* ln_stats;
+  const float* ln_colsum;
+  /* DZN_PREC_F32_H2 ("f32h"): two-term fp16 split, three products (csrc/gemm_split.hip, NP = 2).
+   * W2h = planes from dzn_op_split_weights_h2 ([rows][K/32][2][32] fp16 of w * 2^e_row), col_scale[n] = 2^-e_row,
+   * a_amax = device scalar >= max |A| (tracked by the producer of A through c_amax, or dzn_op_amax).  Any of them
+   * NULL -> the bf16 three-term kernel (W3).  c_amax (any mode): atomically max'ed with |C| as stored. */
+  const void* W2h;
+  const float* col_scale;
+  const float* a_amax;
+  float* c_amax;
 } dzn_gemm_desc;
 
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
@@ -85,6 +100,14 @@ int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
 /* Exact 3-way bf16 split of fp32 weights for DZN_PREC_F32_SPLIT (csrc/gemm_split.hip):
  * W fp32 [rows][K] (row stride ldw, K % 32 == 0) -> W3 bf16 [rows][K/32][3][32] (3*rows*K u16). */
 int dzn_op_split_weights(const float* W, int64_t rows, int32_t K, int64_t ldw, void* W3, void* stream);
+
+/* fp16 two-term split of fp32 weights for DZN_PREC_F32_H2: W2h fp16 [rows][K/32][2][32] (2*rows*K u16) of
+ * W * 2^e_row with max|row| in [2^14, 2^15), col_scale f32 [rows] = 2^-e_row. */
+int dzn_op_split_weights_h2(const float* W, int64_t rows, int32_t K, int64_t ldw, void* W2h, float* col_scale,
+                            void* stream);
+
+/* amax[0] = max(amax[0], max |x[0..n)|) — the |max| tracker of a tensor whose producer has no fused tracker */
+int dzn_op_amax(const float* x, int64_t n, float* amax, void* stream);
 
 /* fp32 rows [rows, D] (D % 32 == 0) -> three bf16 planes [rows, D], plane_stride elements apart, channels of
  * every 32-block in fragment order: the pre-split A operand (dzn_gemm_desc.a_split3) */
@@ -103,6 +126,10 @@ int dzn_op_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const f
                      const float* beta, int64_t rows, int32_t C, int32_t Cpad, float eps,
                      int32_t gelu, void* stream);
 
+/* stats[r] = (mean, 1/sqrt(var + eps)) of x[r, :C] (biased variance, two passes over registers): the row
+ * statistics of torch F.layer_norm for a LayerNorm that is folded into the consuming contraction. */
+int dzn_op_row_stats(const float* x, int64_t ldx, int64_t rows, int32_t C, float eps, float* stats, void* stream);
+
 /* gate_a_1[row, H] of WavLM's gated relative position bias (W2V/components.py:702-710):
  * y f32 [rows, ldy] (attention input, Htot*64 wide), Wg [8,64], bg [8], cst [Htot]. */
 int dzn_op_gate(const float* y, int64_t ldy, const float* Wg, const float* bg, const float* cst,
@@ -117,6 +144,13 @@ int dzn_op_gate(const float* y, int64_t ldy, const float* Wg, const float* bg, c
  *   table f32 [Htot, 2L-1] or NULL: rel-pos bias by (key - query + L - 1)
  *   head_idx i32 [h] device: original head index of kept head j
  */
+/* pre-norm fusion of the two above: one pass over the raw residual rows x [rows, Htot*64] writes the LayerNorm
+ * statistics stats [rows][2] (for a contraction with folded gamma / beta) and gate[rows, Htot] evaluated on
+ * LayerNorm(x) * gamma + beta. */
+int dzn_op_gate_stats(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* Wg,
+                      const float* bg, const float* cst, float* gate, float* stats, int64_t rows, int32_t Htot,
+                      float eps, void* stream);
+
 int dzn_op_attention(const float* qkv, float* out, const float* gate, const float* table,
                      const int32_t* head_idx, int32_t B, int32_t L, int32_t h,
                      int32_t Htot, int32_t ldqkv, int32_t ldo, float scale,

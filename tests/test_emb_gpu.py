@@ -29,7 +29,7 @@ def _engine(gpu, B, N, precision="f32", taps=False):
         os.environ.pop("DZN_DEBUG_TAPS", None)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32s"])
+@pytest.mark.parametrize("precision", ["f32", "f32s", "f32h"])
 def test_embedding_matches_reference_golden(built_lib, gpu, precision):
     from oracle import emb_model
     from oracle.gen_golden import synth_wave

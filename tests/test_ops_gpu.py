@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 # fp32 contraction kernels: 0 = fp32 MFMA, 2 = exact 3-way bf16 split + 6 bf16 MFMA products
-F32_MODES = [0, 2]
+F32_MODES = [0, 2, 3]   # fp32 MFMA, bf16 three-term split, fp16 two-term split: one strict tolerance
 
 
 def _rel_err(a, b):
@@ -139,13 +139,25 @@ def test_gemm_split_is_fp32_grade(built_lib, gpu):
         out = ops.gemm(A.to(gpu), W.to(gpu), precision=prec).cpu().double()
         e = (out - ref).abs() / scale
         errs[prec] = (e.max().item(), e.pow(2).mean().sqrt().item())
+    print("error vs float64 / sum|a||w|  (max, rms):", {{0: "fp32 MFMA", 2: "bf16x3 (6 products)", 3: "fp16x2 (3 products)"}[k]: v
+                                                      for k, v in errs.items()})
     assert errs[2][0] <= 1.5 * errs[0][0] and errs[2][1] <= 1.5 * errs[0][1], errs
     assert errs[2][0] < 2e-6, errs
+    # the two-term fp16 split ("3xFP16"): 22 significant bits per operand -> must also stay at the level of the
+    # hardware fp32 MFMA on this wide-dynamic-range data (activations span 5 decades inside one tensor)
+    assert errs[3][0] <= 1.5 * errs[0][0] and errs[3][1] <= 1.5 * errs[0][1], errs
     # the split itself is exact: hi + mid + lo == x bit for bit
     W3 = ops.split_weights(W.to(gpu)).cpu().view(torch.bfloat16).float()      # [N, K/32, 3, 32]
     pos = torch.tensor([8 * ((k & 15) >> 2) + (k & 3) + 4 * (k >> 4) for k in range(32)])
     rec = (W3[:, :, 0] + W3[:, :, 1] + W3[:, :, 2])[:, :, pos].reshape(N, K)
     assert torch.equal(rec, W)
+    # two-term fp16 planes: (hi + lo) * col_scale reproduces W to 2^-22 (power-of-two row scales are exact)
+    W2, cs = ops.split_weights_h2(W.to(gpu))
+    W2 = W2.cpu().view(torch.float16).double()                                  # [N, K/32, 2, 32]
+    rec2 = ((W2[:, :, 0] + W2[:, :, 1])[:, :, pos].reshape(N, K)) * cs.cpu().double()[:, None]
+    assert ((rec2 - W.double()).abs() <= 2.0 ** -22 * W.double().abs() + 1e-30).all()
+    assert torch.equal(torch.log2(cs.cpu()).round(), torch.log2(cs.cpu()))       # exact powers of two
+    assert (W2[:, :, 0].abs().amax(dim=(1, 2)) < 2.0 ** 15).all() and (W2[:, :, 0].abs().amax(dim=(1, 2)) >= 2.0 ** 14).all()
 
 
 def test_gemm_bf16(built_lib, gpu):
@@ -230,6 +242,55 @@ def test_gate(built_lib, gpu):
     ref = a * (b * cst.double() - 1.0) + 2.0
     out = ops.gate(y.to(gpu), Wg.to(gpu), bg.to(gpu), cst.to(gpu))
     assert (out.cpu().double() - ref).abs().max() < 1e-5
+
+
+def test_gate_stats_fused_layernorm(built_lib, gpu):
+    """pre-norm fusion: one pass over the raw residual rows gives the LayerNorm statistics AND the gate evaluated
+    on LayerNorm(x) (W2V/components.py:702-710 after :923), vs float64; rows with a large common offset too."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(12)
+    rows, Htot = 203, 16
+    x = torch.randn(rows, Htot * 64, generator=g) * 2.5 + torch.randn(rows, 1, generator=g) * 4
+    gamma, beta = 1 + 0.2 * torch.randn(Htot * 64, generator=g), 0.2 * torch.randn(Htot * 64, generator=g)
+    Wg, bg = torch.randn(8, 64, generator=g) * 0.2, torch.randn(8, generator=g)
+    cst = torch.rand(Htot, generator=g) + 0.5
+    y = torch.nn.functional.layer_norm(x.double(), (Htot * 64,), gamma.double(), beta.double())
+    t = (y.view(rows, Htot, 64) @ Wg.double().T + bg.double()).view(rows, Htot, 2, 4).sum(-1)
+    a, b = torch.sigmoid(t)[..., 0], torch.sigmoid(t)[..., 1]
+    ref = a * (b * cst.double() - 1.0) + 2.0
+    gate, stats = ops.gate_stats(x.to(gpu), gamma.to(gpu), beta.to(gpu), Wg.to(gpu), bg.to(gpu), cst.to(gpu))
+    assert (gate.cpu().double() - ref).abs().max() < 2e-5
+    mean = x.double().mean(1)
+    rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-5)
+    assert (stats.cpu()[:, 0].double() - mean).abs().max() < 1e-5
+    assert ((stats.cpu()[:, 1].double() - rstd) / rstd).abs().max() < 1e-5
+    st2 = ops.row_stats(x.to(gpu))
+    assert torch.equal(st2.cpu(), stats.cpu())
+
+
+@pytest.mark.parametrize("prec", F32_MODES)
+@pytest.mark.parametrize("M,N,K,Kt", [(700, 960, 1024, 1024), (333, 1024, 256, 256), (500, 256, 224, 211)])
+def test_gemm_layernorm_folded(built_lib, gpu, M, N, K, Kt, prec):
+    """LayerNorm folded into the contraction (dzn_gemm_desc.ln_stats): raw rows in, W' = W diag(gamma),
+    bias' = bias + W beta, epilogue rstd * (acc - mean * colsum(W')) -> == Linear(LayerNorm(x)) in float64,
+    to fp32 grade, incl. rows with a mean 4x their spread and a padded K (feature projection: 211 -> 224)."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.zeros(M, K)
+    x[:, :Kt] = torch.randn(M, Kt, generator=g) * 1.5 + torch.randn(M, 1, generator=g) * 6
+    gamma, beta = 1 + 0.3 * torch.randn(Kt, generator=g), 0.3 * torch.randn(Kt, generator=g)
+    W = torch.randn(N, Kt, generator=g) / Kt ** 0.5
+    bias = torch.randn(N, generator=g)
+    ref = torch.nn.functional.layer_norm(x[:, :Kt].double(), (Kt,), gamma.double(), beta.double()) @ W.double().T + bias.double()
+    Wf = torch.zeros(N, K)
+    Wf[:, :Kt] = W * gamma
+    colsum = Wf.double().sum(1).float()
+    bias_f = (bias.double() + W.double() @ beta.double()).float()
+    stats = ops.row_stats(x.to(gpu), C_true=Kt)
+    out = ops.gemm(x.to(gpu), Wf.to(gpu), bias=bias_f.to(gpu), precision=prec, ln_stats=stats, ln_colsum=colsum.to(gpu),
+                   act=1)
+    err = (out.cpu().double() - torch.nn.functional.gelu(ref)).abs().max().item()
+    assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 256), (513, 1024, 1056), (257, 64, 96), (1000, 32, 288)])

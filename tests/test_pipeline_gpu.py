@@ -21,7 +21,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 WAV = os.path.join(GOLD, "EN2002a_30s.wav")
 
 
-@pytest.fixture(scope="module", params=["f32", "f32s"])
+@pytest.fixture(scope="module", params=["f32", "f32s", "f32h"])
 def pipeline(built_lib, gpu, request):
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.pipeline import DiariZenPipeline

@@ -64,7 +64,7 @@ def _tap_report(cfg, sd, wave, eng):
 
 # "f32"  = fp32 MFMA (v_mfma_f32_16x16x4_f32); "f32s" = fp32 by exact 3-way bf16 operand split, six
 # bf16 MFMA products, fp32 accumulate (csrc/gemm_split.hip).  Same strict tolerance for both.
-@pytest.mark.parametrize("precision", ["f32", "f32s"])
+@pytest.mark.parametrize("precision", ["f32", "f32s", "f32h"])
 @pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
 def test_seg_fp32_matches_reference_golden(built_lib, gpu, name, precision):
     cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, precision, want_taps=True)
@@ -82,7 +82,7 @@ def test_seg_fp32_matches_reference_golden(built_lib, gpu, name, precision):
     assert eng.num_ignored_keys <= cfg.conf_layers + 2
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32s"])
+@pytest.mark.parametrize("precision", ["f32", "f32s", "f32h"])
 @pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
 def test_seg_fp32_matches_reference_golden_turn_taking(built_lib, gpu, name, precision):
     """NON-degenerate goldens (reference modules + seeded turn-taking weights on real audio): many powerset
@@ -146,7 +146,7 @@ def test_seg_batch_and_ragged_lengths(built_lib, gpu):
         eng.segment(torch.zeros(6, 12000, device=gpu))  # B > max_batch must fail loudly
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32s"])
+@pytest.mark.parametrize("precision", ["f32", "f32s", "f32h"])
 def test_seg_16s_window_cli_default(built_lib, gpu, precision):
     """the reference CLI default is 16 s windows (diarizen/pipelines/inference.py:224-228): L = 799"""
     from diarizen_amd.configs import get_seg_config
@@ -165,7 +165,7 @@ def test_seg_16s_window_cli_default(built_lib, gpu, precision):
     assert torch.equal(ml.cpu(), seg_model.to_multilabel(ref, cfg).to(torch.uint8))
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32s"])
+@pytest.mark.parametrize("precision", ["f32", "f32s", "f32h"])
 def test_seg_dense_wavlm_base(built_lib, gpu, precision):
     """un-pruned wavlm_base (12 x 12 heads, FFN 3072, 512-channel extractor, post-norm, group-norm)"""
     from diarizen_amd.configs import get_seg_config
