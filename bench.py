@@ -33,9 +33,12 @@ import torch  # noqa: E402
 
 # MI355X dense MFMA peaks (MI355X_MICROARCH.md).  "f32s" contractions run fp32 arithmetic as 6 bf16 MFMA
 # products per block (exact 3-way operand split, csrc/gemm_split.hip): their ALGORITHMIC peak is bf16 / 6.
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32s": 2500.0 / 6.0}
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32s": 2500.0 / 6.0, "f32h": 2500.0 / 3.0}
 DTYPE_NOTE = {"f32": "f32 (fp32 MFMA v_mfma_f32_16x16x4_f32)",
               "f32s": "f32 (operands split exactly into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate)",
+              "f32h": "f32 (operands split into 2 fp16 terms with exact power-of-two scaling = 22 significant bits, 3 fp16 MFMA "
+                      "products, fp32 accumulate: the error-corrected '3xFP16/3xTF32' scheme; kernels without an fp16 variant "
+                      "use the 3-term bf16 split)",
               "bf16": "bf16 (bf16 MFMA operands, fp32 accumulate / residual stream / norms)"}
 PEAK_HBM_GBS = 8000.0
 
@@ -88,7 +91,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default=os.environ.get("DZN_BENCH_PRECISION", "f32s"),
-                    choices=["f32s", "f32", "bf16"],
+                    choices=["f32s", "f32h", "f32", "bf16"],
                     help="f32s (default) and f32 are both fp32 arithmetic held to the strict parity tolerance; "
                          "f32 runs the contractions on the fp32 MFMA instead of the split bf16 products")
     ap.add_argument("--minutes", type=float, default=30.0)
@@ -195,7 +198,8 @@ def main():
                 kernels.append(e)
             top = max(prof, key=lambda p: p["ms"])
             if top["flops"] > 0:
-                prec = "bf16" if "bf16" in top["name"] else ("f32s" if "f32s" in top["name"] else "f32")
+                prec = ("bf16" if "bf16" in top["name"] else "f32s" if "f32s" in top["name"] else
+                        "f32h" if "f32h" in top["name"] else "f32")
                 ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
                 roofline = {"kernel": top["name"], "bound": "mfma", "achieved": round(ach, 2),
                             "peak": round(PEAK_TFLOPS[prec], 1), "unit": "TFLOP/s",
@@ -204,6 +208,11 @@ def main():
                             "launches": top["launches"],
                             "avg_launch_ms": round(top["ms"] / top["launches"], 4),
                             "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 3)}
+                if prec == "f32h":
+                    roofline["note"] = ("achieved = algorithmic fp32 flops / s; every 16x16x32 block costs 3 fp16 MFMAs "
+                                        "(hi*hi + hi*lo + lo*hi), so peak = fp16 dense peak 2500 / 3; executed MFMA rate = "
+                                        "3 x achieved")
+                    roofline["executed_tflops"] = round(3 * ach, 1)
                 if prec == "f32s":
                     roofline["note"] = ("achieved = algorithmic fp32 flops / s; every 16x16x32 block costs 6 bf16 "
                                         "MFMAs, so peak = bf16 dense peak 2500 / 6; executed MFMA rate = 6 x achieved")

@@ -39,6 +39,7 @@ struct ConvArgs {
   float* out;
   int B, Hs, Ws;       // interior size; images are [Hs+2][Ws+2][32]
   int relu, post_relu;
+  float* amax;         // |max| tracker of `out` (DZN_PREC_F32_H2 consumers) or nullptr
 };
 
 __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArgs a) {
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
       for (int p = 0; p < 3; ++p) wf[t][p] = *reinterpret_cast<const bf16x8*>(wp + t * 96 + p * 32);
   }
   const float4 b4 = *reinterpret_cast<const float4*>(a.bias + nb * 16 + lq * 4);
+  float out_amax = 0.f;
 
   // staging registers: 7 items per thread (3 segments x 130 pixels x 4 chunks of 8 channels = 1560 items);
   // the strip of tile t+1 is fetched into them while tile t is multiplied
@@ -187,17 +189,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         *reinterpret_cast<float4*>(ob + o) = make_float4(v[0], v[1], v[2], v[3]);
+        out_amax = fmaxf(fmaxf(out_amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
     }
     __syncthreads();  // the strip is free for the next tile's staging
   }
+  if (a.amax) track_amax(a.amax, out_amax);
 }
 
 }  // namespace
 
 // in / out / R: zero-bordered fp32 NHWC images [B][Hs+2][Ws+2][32] (image bases, not interior pointers)
 int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias, const float* R, float* out, int B,
-                             int Hs, int Ws, int relu, int post_relu, hipStream_t s) {
+                             int Hs, int Ws, int relu, int post_relu, hipStream_t s, float* amax) {
   if (B <= 0 || Hs <= 0 || Ws <= 0) return DZN_OK;
   if (!in || !W3 || !bias || !out) return DZN_E_INVALID;
   static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
@@ -206,7 +210,7 @@ int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_split_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  ConvArgs a{in, static_cast<const u16*>(W3), bias, R, out, B, Hs, Ws, relu, post_relu};
+  ConvArgs a{in, static_cast<const u16*>(W3), bias, R, out, B, Hs, Ws, relu, post_relu, amax};
   const int64_t ntiles = (int64_t)((Hs * (Ws + 2) + CS_TP - 1) / CS_TP) * B;
   (void)ntiles;
   const int grid = 512;   // persistent: 2 workgroups per CU; XCD-major work distribution inside the kernel
@@ -219,5 +223,5 @@ int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias,
 extern "C" int dzn_op_conv3x3_c32(const float* in, const void* W3, const float* bias, const float* R, float* out,
                                   int32_t B, int32_t Hs, int32_t Ws, int32_t relu, int32_t post_relu, void* stream) {
   return launch_conv3x3_c32_split(in, W3, bias, R, out, B, Hs, Ws, relu, post_relu,
-                                  reinterpret_cast<hipStream_t>(stream));
+                                  reinterpret_cast<hipStream_t>(stream), nullptr);
 }

@@ -156,7 +156,8 @@ struct dzn_handle {
   float* rstat = nullptr;   // [max_batch * maxL][2] (mean, rstd) of the LayerNorm folded into the next contraction
   // |max| trackers of activation tensors (DZN_PREC_F32_H2): written by the producer's epilogue / LayerNorm,
   // read by the consuming contraction to scale its fp16 split (gemm_split.hip).  Zeroed at every forward.
-  enum { AM_CONVA, AM_CONVB, AM_X, AM_Y, AM_MID, AM_QKV, AM_HZ, AM_HMID, AM_IMG0, AM_COUNT = AM_IMG0 + 12 };
+  enum { AM_CONVA, AM_CONVB, AM_X, AM_XPAD, AM_Y, AM_MID, AM_QKV, AM_HZ, AM_HMID, AM_IMG0, AM_COUNT = AM_IMG0 + 12 };
+  float conv0_bound = 0.f;  // sqrt(C0) max|gamma| + max|beta| >= |GELU(LN(conv0))|: static |max| of conv0's output
   float* amax = nullptr;
   bool fold_ln = false;     // fp32 engine modes: LayerNorms that feed only linears are folded (make_lin_ln)
 
@@ -376,6 +377,12 @@ void finalize_seg(H* h) {
     expect_numel(w, (int64_t)h->C[0] * c.conv_k[0], pre + ".conv.weight");
     h->conv0_w = upload(h, w.v);
     h->conv_ln[0] = ln_from_sd(h, pre + ".layer_norm", h->C[0]);
+    if (c.extractor_layer_norm) {   // |LN(x)_c| <= sqrt(C - 1), |GELU(t)| <= |t|
+      float mg = 0.f, mb = 0.f;
+      for (float v : need(h, pre + ".layer_norm.weight").v) mg = std::max(mg, std::fabs(v));
+      for (float v : need(h, pre + ".layer_norm.bias").v) mb = std::max(mb, std::fabs(v));
+      h->conv0_bound = std::sqrt((float)h->C[0]) * mg + mb;
+    }
   }
   for (int i = 1; i < c.n_conv; ++i) {
     const std::string pre = P + "feature_extractor.conv_layers." + std::to_string(i);
@@ -932,7 +939,14 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   // DZN_PREC_F32_H2: |max| trackers (see dzn_handle::amax).  am(slot) is NULL in the other modes, which makes
   // every contraction take its bf16 three-term / fp32 kernel.
   const bool h2 = c.precision == DZN_PREC_F32_H2;
-  if (h2) HIPCHK(hipMemsetAsync(h->amax, 0, dzn_handle::AM_IMG0 * sizeof(float), st));
+  if (h2) {
+    HIPCHK(hipMemsetAsync(h->amax, 0, dzn_handle::AM_IMG0 * sizeof(float), st));
+    if (lnx && h->conv0_bound > 0.f) {   // conv0 (LN + GELU) writes bufA: static bound instead of a tracker
+      uint32_t bits;
+      memcpy(&bits, &h->conv0_bound, 4);
+      HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->amax + dzn_handle::AM_CONVA), (int)bits, 1, st));
+    }
+  }
   auto am = [&](int slot) -> float* { return h2 ? h->amax + slot : nullptr; };
   auto conv_slot = [&](const float* buf) { return buf == h->bufA ? dzn_handle::AM_CONVA : dzn_handle::AM_CONVB; };
 
@@ -967,7 +981,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     d.a_z0 = (int64_t)T[i - 1] * h->Cp[i - 1];
     d.c_z0 = (int64_t)T[i] * h->Cp[i];
     if (!lnx) d.act = DZN_ACT_GELU;
-    if (i > 1) d.a_amax = am(conv_slot(cur));     // conv0's kernel has no tracker: conv1 stays on the bf16 split
+    if (i > 1 || lnx) d.a_amax = am(conv_slot(cur));   // (group-norm conv0 has neither tracker nor bound: bf16 split)
     if (!lnx) d.c_amax = am(conv_slot(nxt));
     gemm(d, lp, lp && !lnx, "conv gemm");
     if (lnx)  // channel LayerNorm + GELU (+ dummy_weight after the last conv, components.py:208)
@@ -1011,7 +1025,12 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     // f32s: every element of the padded copy feeds 128 taps — split it ONCE here (three bf16 planes) and
     // let the contraction read the planes (gemm_split_pre.hip) instead of re-splitting it per K tile
     const bool pre3 = h->xpad3 != nullptr && (int64_t)c.max_batch * Lp * D < (int64_t)1 << 31;
-    if (pre3)
+    const bool pre2 = pre3 && h2 && h->posconv.W2h;   // two fp16 planes, scaled by the |max| of x (snapshotted)
+    if (pre2)
+      chk(launch_pad_rows_split2(h->x, h->xpad3, h->xpad3_plane, B, L, Lp, Kc / 2, D, am(dzn_handle::AM_X),
+                                 am(dzn_handle::AM_XPAD), st),
+          "pad_rows_split2");
+    else if (pre3)
       chk(launch_pad_rows_split3(h->x, h->xpad3, h->xpad3_plane, B, L, Lp, Kc / 2, D, st), "pad_rows_split3");
     else
       chk(launch_pad_rows(h->x, h->xpad, pc16, B, L, Lp, Kc / 2, D, st), "pad_rows");
@@ -1043,8 +1062,9 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     }
     if (pre3) {
       d.A = reinterpret_cast<const float*>(h->xpad3);
-      d.a_split3 = 1;
+      d.a_split3 = pre2 ? 2 : 1;
       d.a_plane = h->xpad3_plane;
+      if (pre2) d.a_amax = am(dzn_handle::AM_XPAD);
     }
     d.c_amax = am(dzn_handle::AM_X);
     gemm(d, pc16, false, "pos conv");
@@ -1274,13 +1294,13 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
   chk(launch_stem_conv(h->fb, B, T, NB, h->sC[0], h->stem_w, h->stem_b, h->sbuf[0][0], lp, st), "stem");
   const float* prev = nullptr;  // output image of the previous stage
   int cur = 0;
-  // DZN_PREC_F32_H2: one |max| tracker per image buffer (sbuf[s][k] -> slot AM_IMG0 + 3 s + k); images written
-  // by the stem / the dedicated stage-1 kernel have none, so their consumers take the bf16 split
+  // DZN_PREC_F32_H2: one |max| tracker per image buffer (sbuf[s][k] -> slot AM_IMG0 + 3 s + k), running over the
+  // forward; the stem's image has no writer with a tracker, but its only consumer is the dedicated bf16 stage-1 kernel
   const bool h2 = c.precision == DZN_PREC_F32_H2;
   if (h2) HIPCHK(hipMemsetAsync(h->amax + dzn_handle::AM_IMG0, 0, 12 * sizeof(float), st));
   auto img_am = [&](const float* buf) -> float* {
     if (!h2 || !buf) return nullptr;
-    for (int s2 = 1; s2 < 4; ++s2)
+    for (int s2 = 0; s2 < 4; ++s2)
       for (int k = 0; k < 3; ++k)
         if (buf == h->sbuf[s2][k]) return h->amax + dzn_handle::AM_IMG0 + 3 * s2 + k;
     return nullptr;
@@ -1295,7 +1315,8 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
       if (prec_is_split(c.precision) && rc.cin == 32 && rc.cout == 32 && rc.l.W3 &&
           (act == DZN_ACT_NONE || act == DZN_ACT_RELU)) {
         // first ResNet stage: dedicated kernel, every input pixel split once instead of once per tap
-        chk(launch_conv3x3_c32_split(in, rc.l.W3, rc.l.b, R, out, B, Hs, Ws, act == DZN_ACT_RELU, post_relu, st),
+        chk(launch_conv3x3_c32_split(in, rc.l.W3, rc.l.b, R, out, B, Hs, Ws, act == DZN_ACT_RELU, post_relu, st,
+                                     img_am(out)),
             "resnet conv3x3 c32");
         return;
       }

@@ -86,11 +86,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
       }
     }
   }
-  if (d.c_amax) {
-    amax = wave_max(amax);
-    // |x| >= 0: the IEEE bit patterns order like unsigned integers, so the max is order independent (deterministic)
-    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(d.c_amax), __float_as_uint(amax));
-  }
+  if (d.c_amax) track_amax(d.c_amax, amax);
 }
 
 }  // namespace

@@ -64,44 +64,6 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 //     rows is multiplied, then [wait tile kt+1, barrier, refill the stage of tile kt], then the
 //     fragments of tile kt+1 are read into the second register set while the second half of
 //     tile kt is multiplied — the matrix pipe has work queued across the barrier.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-// a 128-bit MFMA operand fragment of either element type
-template <int NP>
-__device__ __forceinline__ f32x4 mfma_np(const u32x4& a, const u32x4& b, f32x4 c) {
-  if constexpr (NP == 3)
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-// 8 fp32 values (two float4), pre-scaled by the exact power of two s -> two fp16x8 fragments (hi, lo)
-__device__ __forceinline__ void split8_h2(const f32x4& u, const f32x4& v, float s, u32x4& hi, u32x4& lo) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    f32x2 x;
-    x[0] = (p < 2 ? u[2 * p] : v[2 * p - 4]) * s;
-    x[1] = (p < 2 ? u[2 * p + 1] : v[2 * p - 3]) * s;
-    const f16x2 h = __builtin_convertvector(x, f16x2);        // v_cvt_pk_f16_f32 (round to nearest even)
-    const f32x2 hf = __builtin_convertvector(h, f32x2);
-    f32x2 r;
-    r[0] = x[0] - hf[0];                                      // exact in fp32
-    r[1] = x[1] - hf[1];
-    hi[p] = __builtin_bit_cast(unsigned, h);
-    lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-  }
-}
-
-// exact power-of-two scale that puts `amax` into [2^14, 2^15) (fp16 max is 65504), and its inverse
-__device__ __forceinline__ void h2_scale(float amax, float& s, float& inv) {
-  int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;   // floor(log2 amax) for normal amax
-  if (!(amax > 0.f) || e > 100) e = 14;                         // empty / non-finite tracker: scale 1
-  e = e < -100 ? -100 : e;
-  s = __uint_as_float((unsigned)(14 - e + 127) << 23);
-  inv = __uint_as_float((unsigned)(e - 14 + 127) << 23);
-}
-
 template <int BM, int BN, int WGM, int WGN, int S, int NP>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_gemm_desc d) {
   constexpr int NW = WGM * WGN;           // wavefronts per workgroup

@@ -27,7 +27,10 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
   __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4));
 }
 
-template <int BM, int BN, int WGM, int WGN, int S>
+// NP = 3: bf16 planes (six products); NP = 2 (DZN_PREC_F32_H2): fp16 planes of x * 2^e written by
+// pad_rows_split2_kernel, which also SNAPSHOTS the |max| it scaled by (d.a_amax points at the snapshot, not at the
+// live tracker: the positional conv updates the tensor it reads, so the live tracker moves while tiles start).
+template <int BM, int BN, int WGM, int WGN, int S, int NP>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dzn_gemm_desc d) {
   constexpr int NW = WGM * WGN;
   constexpr int BK = 32;
@@ -36,8 +39,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
   constexpr int RB = NW * 1024;
   constexpr int ROWS = NW * 16;           // plane rows per LDS-DMA round (64-B rows)
   constexpr int AR = BM / ROWS, WR = BN / ROWS;
-  constexpr int APLANE = BM * 64, WPLANE = BN * 64, BUF = 3 * (APLANE + WPLANE);
-  constexpr int LPT = 3 * (AR + WR);
+  constexpr int APLANE = BM * 64, WPLANE = BN * 64, BUF = NP * (APLANE + WPLANE);
+  constexpr int LPT = NP * (AR + WR);
   static_assert(BM % ROWS == 0 && BN % ROWS == 0, "whole rounds");
   static_assert(MI % 2 == 0, "two row halves per wavefront tile");
   static_assert(S >= 2 && (S - 1) * LPT < 64, "vmcnt range");
@@ -57,7 +60,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
   const int z = blockIdx.y;
   const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
   const u16* __restrict__ A3 = reinterpret_cast<const u16*>(d.A) + z0 * d.a_z0 + z1 * d.a_z1;
-  const u16* __restrict__ W3 = reinterpret_cast<const u16*>(d.W3) + 3 * (z0 * d.w_z0 + z1 * d.w_z1);
+  const u16* __restrict__ W3 =
+      reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + NP * (z0 * d.w_z0 + z1 * d.w_z1);
+  float acc_scale = 1.f;
+  if constexpr (NP == 2) {
+    float unused;
+    h2_scale(*d.a_amax, unused, acc_scale);
+  }
   const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
   const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
 
@@ -76,16 +85,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
   for (int i = 0; i < WR; ++i) {
     int n = tn * BN + pr0 + ROWS * i;
     n = n < d.N ? n : d.N - 1;
-    wptr[i] = W3 + (int64_t)n * 3 * d.ldw + psw * 8;
+    wptr[i] = W3 + (int64_t)n * NP * d.ldw + psw * 8;
   }
 
   int ik = 0, irem = 0;
   int64_t ikoff = 0;
   auto issue = [&](int stage) {
     unsigned char* sA = smem + stage * BUF + wave * 1024;
-    unsigned char* sW = sA + 3 * APLANE;
+    unsigned char* sW = sA + NP * APLANE;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int i = 0; i < AR; ++i)
         __builtin_amdgcn_global_load_lds(
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
 #pragma unroll
       for (int i = 0; i < WR; ++i)
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(wptr[i] + 3 * ik + p * 32),
+            (const __attribute__((address_space(1))) void*)(wptr[i] + NP * ik + p * 32),
             (__attribute__((address_space(3))) void*)(sW + p * WPLANE + i * RB), 16, 0, 0);
     }
     ik += BK;
@@ -118,35 +127,37 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int row = wn * TN + j * 16 + lr;
-    woff[j] = 3 * APLANE + row * 64 + ((lq ^ pswz(row)) << 4);
+    woff[j] = NP * APLANE + row * 64 + ((lq ^ pswz(row)) << 4);
   }
-  auto read_w = [&](int stage, bf16x8 (&wf)[NI][3]) {
+  auto read_w = [&](int stage, u32x4 (&wf)[NI][NP]) {
     const unsigned char* base = smem + stage * BUF;
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wf[j][p] = *reinterpret_cast<const bf16x8*>(base + p * WPLANE + woff[j]);
+      for (int p = 0; p < NP; ++p) wf[j][p] = *reinterpret_cast<const u32x4*>(base + p * WPLANE + woff[j]);
   };
-  auto read_a = [&](int stage, bf16x8 (&af)[MI][3]) {
+  auto read_a = [&](int stage, u32x4 (&af)[MI][NP]) {
     const unsigned char* base = smem + stage * BUF;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(base + p * APLANE + aoff[i]);
+      for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(base + p * APLANE + aoff[i]);
   };
-  auto mma6 = [&](int i, const bf16x8 (&wf)[NI][3], const bf16x8& ah, const bf16x8& am, const bf16x8& al) {
+  // products of one 16-row block, smallest terms first (same order as gemm_split.hip)
+  auto mma = [&](int i, const u32x4 (&wf)[NI][NP], const u32x4 (&a)[NP]) {
+    if constexpr (NP == 3) {
+      constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][2], ah, acc[i][j], 0, 0, 0);
+      for (int t = 0; t < 6; ++t)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], al, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][PW[t]], a[PA[t]], acc[i][j]);
+    } else {
+      constexpr int PW[3] = {1, 0, 0}, PA[3] = {0, 1, 0};
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], am, acc[i][j], 0, 0, 0);
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], ah, acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], am, acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], ah, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][PW[t]], a[PA[t]], acc[i][j]);
+    }
   };
 
   const int nk = d.K / BK;
@@ -156,17 +167,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
   if (nk >= S) wait_vm_lgkm0<(S - 1) * LPT>();
   else wait_vm_lgkm0<0>();
   __builtin_amdgcn_s_barrier();
-  bf16x8 wfa[NI][3], wfb[NI][3], af[MI][3];
+  u32x4 wfa[NI][NP], wfb[NI][NP], af[MI][NP];
   read_w(0, wfa);
   read_a(0, af);
   int stage = 0;
-  auto step = [&](int kt, const bf16x8 (&wc)[NI][3], bf16x8 (&wn_)[NI][3]) {
+  auto step = [&](int kt, const u32x4 (&wc)[NI][NP], u32x4 (&wn_)[NI][NP]) {
     const bool more = kt + 1 < nk;
 #pragma unroll
-    for (int i = 0; i < MH; ++i) mma6(i, wc, af[i][0], af[i][1], af[i][2]);
-    bf16x8 ah[MI - MH], am[MI - MH], al[MI - MH];
+    for (int i = 0; i < MH; ++i) mma(i, wc, af[i]);
+    u32x4 a2[MI - MH][NP];
 #pragma unroll
-    for (int i = MH; i < MI; ++i) { ah[i - MH] = af[i][0]; am[i - MH] = af[i][1]; al[i - MH] = af[i][2]; }
+    for (int i = MH; i < MI; ++i)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) a2[i - MH][p] = af[i][p];
     const int nstage = stage + 1 == S ? 0 : stage + 1;
     __builtin_amdgcn_sched_barrier(0);
     if (more) {
@@ -179,21 +192,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = MH; i < MI; ++i) mma6(i, wc, ah[i - MH], am[i - MH], al[i - MH]);
+    for (int i = MH; i < MI; ++i) mma(i, wc, a2[i - MH]);
     stage = nstage;
   };
   for (int kt = 0; kt < nk; kt += 2) {
     step(kt, wfa, wfb);
     if (kt + 1 < nk) step(kt + 1, wfb, wfa);
   }
-  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz);
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, acc_scale,
+                                        NP == 2 ? d.col_scale + z0 * d.b_z0 + z1 * d.b_z1 : nullptr);
 }
 
-template <int BM, int BN, int WGM, int WGN, int S>
+template <int BM, int BN, int WGM, int WGN, int S, int NP>
 int launch_pre_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-  const size_t lds = (size_t)S * 3 * (BM + BN) * 64;
-  auto kern = gemm_split_pre_kernel<BM, BN, WGM, WGN, S>;
+  const size_t lds = (size_t)S * NP * (BM + BN) * 64;
+  auto kern = gemm_split_pre_kernel<BM, BN, WGM, WGN, S, NP>;
   static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
   if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -205,9 +219,9 @@ int launch_pre_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     char cls[64];
     static const bool by_shape = getenv("DZN_PROFILE_SHAPES") != nullptr;
     if (by_shape)
-      snprintf(cls, sizeof(cls), "gemm_f32s_pre_%dx%d M%d N%d K%d z%d", BM, BN, d.M, d.N, d.K, d.nz);
+      snprintf(cls, sizeof(cls), "gemm_f32%s_pre_%dx%d M%d N%d K%d z%d", NP == 3 ? "s" : "h", BM, BN, d.M, d.N, d.K, d.nz);
     else
-      snprintf(cls, sizeof(cls), "gemm_f32s_pre_%dx%d", BM, BN);
+      snprintf(cls, sizeof(cls), "gemm_f32%s_pre_%dx%d", NP == 3 ? "s" : "h", BM, BN);
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
     pid = prof_begin(s, cls, fl, 0.0);
   }
@@ -244,18 +258,71 @@ __global__ __launch_bounds__(256) void pad_rows_split3_kernel(const float* __res
   }
 }
 
+// two-term fp16 variant: planes of x * 2^e (e from the live |max| tracker of x); the |max| that was used is
+// snapshotted for the consuming contraction (see gemm_split_pre_kernel)
+__global__ __launch_bounds__(256) void pad_rows_split2_kernel(const float* __restrict__ x, u16* __restrict__ planes,
+                                                              int64_t plane_stride, int L, int Lp, int pad, int D,
+                                                              const float* __restrict__ amax, float* __restrict__ snapshot) {
+  const int b = blockIdx.y;
+  const float am = *amax;
+  float sc, inv;
+  h2_scale(am, sc, inv);
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) *snapshot = am;
+  const int chunks = D / 8;
+  const int64_t n = (int64_t)Lp * chunks;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / chunks), c = (int)(i - (int64_t)r * chunks);
+    const int blk = c >> 2, q = c & 3;
+    const int t = r - pad;
+    f32x4 u = (f32x4){0.f, 0.f, 0.f, 0.f}, v = u;
+    if (t >= 0 && t < L) {
+      const float* src = x + ((int64_t)b * L + t) * D + blk * 32 + 4 * q;
+      const float4 a = *reinterpret_cast<const float4*>(src);
+      const float4 e = *reinterpret_cast<const float4*>(src + 16);
+      u = (f32x4){a.x, a.y, a.z, a.w};
+      v = (f32x4){e.x, e.y, e.z, e.w};
+    }
+    u32x4 ph, pl;
+    split8_h2(u, v, sc, ph, pl);
+    u16* dst = planes + ((int64_t)b * Lp + r) * D + blk * 32 + q * 8;
+    *reinterpret_cast<u32x4*>(dst) = ph;
+    *reinterpret_cast<u32x4*>(dst + plane_stride) = pl;
+  }
+}
+
 }  // namespace
 
 // A = plane 0 of the pre-split operand (bf16), planes a_plane elements apart.  Requirements: K % 32 == 0,
 // kc % 32 == 0, ldw == K, all A offsets multiples of 8 elements.
-int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s) {
-  if ((d.K & 31) || (d.kc & 31) || !d.W3 || d.ldw != d.K || !d.a_split3 || d.a_plane <= 0) return DZN_E_INVALID;
+template <int NP>
+int launch_gemm_split_pre_np(const dzn_gemm_desc& d, hipStream_t s) {
   static const char* force = getenv("DZN_GEMM_CFG");   // tuning knob
-  if (force && !strcmp(force, "256x128")) return launch_pre_cfg<256, 128, 4, 2, 2>(d, s);
-  if (force && !strcmp(force, "128x128")) return launch_pre_cfg<128, 128, 2, 2, 2>(d, s);
-  if (force && !strcmp(force, "128x64")) return launch_pre_cfg<128, 64, 4, 1, 2>(d, s);
-  if (d.N > 64) return launch_pre_cfg<256, 128, 4, 2, 2>(d, s);   // 144 KB of LDS, 8 wavefronts
-  return launch_pre_cfg<128, 64, 4, 1, 2>(d, s);   // 72 KB of LDS: two workgroups per CU
+  if (force && !strcmp(force, "256x128")) return launch_pre_cfg<256, 128, 4, 2, 2, NP>(d, s);
+  if (force && !strcmp(force, "128x128")) return launch_pre_cfg<128, 128, 2, 2, 2, NP>(d, s);
+  if (force && !strcmp(force, "128x64")) return launch_pre_cfg<128, 64, 4, 1, 2, NP>(d, s);
+  if (d.N > 64) return launch_pre_cfg<256, 128, 4, 2, 2, NP>(d, s);   // 144 KB of LDS (NP = 3), 8 wavefronts
+  return launch_pre_cfg<128, 64, 4, 1, 2, NP>(d, s);   // 72 KB of LDS (NP = 3): two workgroups per CU
+}
+
+int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s) {
+  if ((d.K & 31) || (d.kc & 31) || d.ldw != d.K || !d.a_split3 || d.a_plane <= 0) return DZN_E_INVALID;
+  if (d.a_split3 == 2) {   // two fp16 planes
+    if (!d.W2h || !d.col_scale || !d.a_amax || d.w_z0 * 1 != d.w_z0) return DZN_E_INVALID;
+    return launch_gemm_split_pre_np<2>(d, s);
+  }
+  if (!d.W3) return DZN_E_INVALID;
+  return launch_gemm_split_pre_np<3>(d, s);
+}
+
+int launch_pad_rows_split2(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
+                           const float* amax, float* snapshot, hipStream_t st) {
+  ProfScope prof_scope_(st, "pad_rows_split2");
+  if (D % 32 || !amax || !snapshot) return DZN_E_INVALID;
+  int64_t g = cdiv64((int64_t)Lp * (D / 8), 256);
+  g = g > 4096 ? 4096 : g;
+  hipLaunchKernelGGL(pad_rows_split2_kernel, dim3((unsigned)g, B), dim3(256), 0, st, x, static_cast<u16*>(planes),
+                     plane_stride, L, Lp, pad, D, amax, snapshot);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
 extern "C" int dzn_op_split_rows(const float* x, void* planes, int64_t plane_stride, int64_t rows, int32_t D,

@@ -58,17 +58,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
       st_act(yp, idx, 0.f);
     }
   }
-  if (amax_out) {   // |max| tracker of the output tensor (scale of the consumer's fp16 split, gemm_split.hip)
-    amax = wave_max(amax);
-    if (lane == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(amax));
-  }
+  if (amax_out) track_amax(amax_out, amax);   // |max| of the output tensor: scale of the consumer's fp16 split
 }
 
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ amax_out) {
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+  track_amax(amax_out, m);
 }
 
 // (mean, rstd) of each row — the LayerNorm whose affine part is folded into the consuming contraction

@@ -155,7 +155,8 @@ def test_gemm_split_is_fp32_grade(built_lib, gpu):
     W2, cs = ops.split_weights_h2(W.to(gpu))
     W2 = W2.cpu().view(torch.float16).double()                                  # [N, K/32, 2, 32]
     rec2 = ((W2[:, :, 0] + W2[:, :, 1])[:, :, pos].reshape(N, K)) * cs.cpu().double()[:, None]
-    assert ((rec2 - W.double()).abs() <= 2.0 ** -22 * W.double().abs() + 1e-30).all()
+    # (elements more than 2^17 below their row maximum keep a subnormal lo term: absolute floor 2^-25 scaled)
+    assert ((rec2 - W.double()).abs() <= 2.0 ** -22 * W.double().abs() + 2.0 ** -25 * cs.cpu().double()[:, None]).all()
     assert torch.equal(torch.log2(cs.cpu()).round(), torch.log2(cs.cpu()))       # exact powers of two
     assert (W2[:, :, 0].abs().amax(dim=(1, 2)) < 2.0 ** 15).all() and (W2[:, :, 0].abs().amax(dim=(1, 2)) >= 2.0 ** 14).all()
 
