@@ -46,22 +46,37 @@ PEAK_HBM_GBS = 8000.0
 from diarizen_amd.synth import synth_recording  # noqa: E402
 
 
-def pmc_traffic(kernel_class: str, args):
-    """HBM bytes per launch of `kernel_class` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE on this same command, gfx950 correction applied; scripts/pmc_traffic.py).  bench.py
-    cannot run rocprofv3 on itself, so the figure is read from profiles/ and only when the workload
-    matches the one the passes were taken on."""
-    path = ROOT / "profiles" / f"r1_pmc_traffic_{args.precision}_30min_b{args.batch}.json"
+# in-situ profiler class -> kernel symbol in the rocprofv3 tables (scripts/pmc_summary.py writes profiles/*.json)
+PMC_SYMBOLS = {"conv0_ln_gelu": "conv0_kernel", "attention_relpos_f32s": "attn_split_kernel<true>",
+               "attention_relpos_f32h": "attn_split_kernel<true>", "attention_f32s": "attn_split_kernel<false>",
+               "conv3x3_c32_f32s": "conv3x3_c32_split_kernel", "layernorm": "layernorm_kernel<16"}
+
+
+def pmc_table(args):
+    """HBM bytes per launch / MfmaUtil per kernel from the committed rocprofv3 --pmc passes of this same command
+    (separate passes per counter, gfx950 FETCH_SIZE correction: scripts/pmc_traffic.py, scripts/pmc_mfma.py).
+    bench.py cannot run rocprofv3 on itself, so the table is read from profiles/ and only when the workload matches
+    the one the passes were taken on; otherwise `traffic` is null."""
+    path = ROOT / "profiles" / f"r2_pmc_{args.precision}_30min_b{args.batch}.json"
     if not path.exists() or args.minutes != 30.0 or args.model != "wavlm_large_s80_md" or args.window != 8.0:
         return None
-    table = json.loads(path.read_text())
+    return json.loads(path.read_text())
+
+
+def pmc_lookup(table, kernel_class: str, field: str):
+    if not table:
+        return None
     key = None
-    for prefix, kern in (("gemm_f32s_", "gemm_split_kernel"), ("gemm_f32_", "gemm_glds_kernel")):
-        if kernel_class.startswith(prefix):
-            bm, bn = kernel_class[len(prefix):].split("x")
-            key = next((k for k in table if k.startswith(f"{kern}<{bm}, {bn},")), None)
+    for tag, planes in (("gemm_f32h_pre_", 2), ("gemm_f32s_pre_", 3), ("gemm_f32h_", 2), ("gemm_f32s_", 3)):
+        if kernel_class.startswith(tag):
+            bm, bn = kernel_class[len(tag):].split("x")
+            sym = "gemm_split_pre_kernel" if "_pre_" in tag else "gemm_split_kernel"
+            key = next((k for k in table if k.startswith(f"{sym}<{bm}, {bn},") and k.endswith(f", {planes}>")), None)
             break
-    return table[key]["hbm_bytes_per_launch"] if key else None
+    else:
+        sym = PMC_SYMBOLS.get(kernel_class)
+        key = next((k for k in table if sym and k.startswith(sym)), None)
+    return table[key].get(field) if key else None
 
 
 def cpu_baseline(seg_cfg, sd, esd, window: int, step_s: float, budget_windows: int = 8):
@@ -85,15 +100,86 @@ def cpu_baseline(seg_cfg, sd, esd, window: int, step_s: float, budget_windows: i
                       f"passes per window (as the reference executes), fp32 torch CPU, {dt:.1f} s"}
 
 
+def shard_slice(num_samples: int, window: int, step: int, rank: int, world: int):
+    """strong scaling: rank -> (first window, one-past-last window, first sample, samples incl. the window-length halo)"""
+    from diarizen_amd.dist import shard_range
+    from diarizen_amd.inference import window_plan
+    n, last = window_plan(num_samples, window, step)
+    c0, c1 = shard_range(n + int(last), rank, world)
+    if c1 <= c0:
+        return c0, c1, 0, 0
+    return c0, c1, c0 * step, (c1 - c0 - 1) * step + window
+
+
+def run_mode(cfg, sd, esd, wave, args, window, precision, full, dev):
+    """one untimed + one timed step of the same workload in another arithmetic mode (reported beside the headline)"""
+    from diarizen_amd.configs import RESNET34
+    from diarizen_amd.engine import Engine
+    from diarizen_amd.inference import WindowRunner
+    eng = Engine(cfg, sd, RESNET34, esd, max_batch=args.batch, max_samples=window, precision=precision, device=dev)
+    r = WindowRunner(eng, args.window, 0.1, args.batch)
+    dt = 0.0
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        res = r.run(wave, with_embeddings=full)
+        _ = (res.segmentations.cpu(), res.embeddings.cpu()) if full else res.segmentations.cpu()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+    eng.close()
+    return dt
+
+
+def e2e_leg(args, dev, wave_host):
+    """BASELINE configs[2] names segmentation + embedding + AHC: ONE untimed-for-the-headline pass of the whole
+    DiariZenPipeline (device stage, then speaker counting / AHC / reconstruction / RTTM on the host) over the same
+    recording, with the seeded turn-taking weights so that the host stage sees non-degenerate decisions."""
+    import copy
+    import numpy as np
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.pipeline import DiariZenPipeline
+    from diarizen_amd.weights import emb_state_dict, turn_taking_state_dict
+    cfg = get_seg_config(args.model)
+    conf = {"model": {"path": "diarizen.models.eend.model_wavlm_conformer.Model",
+                      "args": {"wavlm_src": args.model, "wavlm_layer_num": cfg.wavlm_layer_num,
+                               "wavlm_feat_dim": cfg.embed_dim, "chunk_size": int(args.window)}},
+            "inference": {"args": {"seg_duration": args.window, "segmentation_step": 0.1, "batch_size": args.batch,
+                                   "apply_median_filtering": True}},
+            "clustering": {"args": {"method": "AgglomerativeClustering", "min_speakers": 1, "max_speakers": 20,
+                                    "ahc_criterion": "distance", "ahc_threshold": 0.1, "min_cluster_size": 13}}}
+    pipe = DiariZenPipeline(None, None, config=copy.deepcopy(conf), device=dev, precision=args.precision,
+                            seg_state=turn_taking_state_dict(cfg, 0), emb_state=emb_state_dict(0))
+    x = np.ascontiguousarray(wave_host.numpy())
+    best = None
+    for _ in range(2):                      # first pass warms allocations / tables
+        t0 = time.perf_counter()
+        seg, emb = pipe.device_stage(x)
+        t1 = time.perf_counter()
+        ann = pipe.host_stage(seg, emb, "bench")
+        t2 = time.perf_counter()
+        best = (t1 - t0, t2 - t1, ann)
+    dev_s, host_s, ann = best
+    audio_s = len(x) / 16000.0
+    active = int((seg.sum(1) > 0).sum())
+    return {"device_s": round(dev_s, 3), "host_s": round(host_s, 3), "upload_included": True,
+            "audio_seconds_per_s": round(audio_s / (dev_s + host_s), 1),
+            "speakers": len(ann.labels()), "rttm_lines": len(ann.to_rttm().splitlines()),
+            "active_window_speakers": active,
+            "note": "DiariZenPipeline device stage (host->HBM upload + segmentation + masks + embeddings + D2H) then host "
+                    "counting + AHC (centroid linkage) + constrained assignment + reconstruction + RTTM; seeded "
+                    "turn-taking weights"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default=os.environ.get("DZN_BENCH_PRECISION", "f32s"),
-                    choices=["f32s", "f32h", "f32", "bf16"],
-                    help="f32s (default) and f32 are both fp32 arithmetic held to the strict parity tolerance; "
-                         "f32 runs the contractions on the fp32 MFMA instead of the split bf16 products")
+    ap.add_argument("--precision", default=os.environ.get("DZN_BENCH_PRECISION", "f32h"),
+                    choices=["f32h", "f32s", "f32", "bf16"],
+                    help="f32h (default), f32s and f32 are fp32 arithmetic held to the same strict parity tolerance: "
+                         "f32h = 2-term fp16 split / 3 MFMA products, f32s = 3-term bf16 split / 6 products, "
+                         "f32 = the fp32 MFMA instruction")
     ap.add_argument("--minutes", type=float, default=30.0)
     ap.add_argument("--window", type=float, default=8.0)
     ap.add_argument("--batch", type=int, default=256)
@@ -101,9 +187,14 @@ def main():
     ap.add_argument("--stage", default="full", choices=["full", "seg"],
                     help="seg = segmentation-only (BASELINE configs[1]: --model wavlm_base_s80_md --window 5 "
                          "--batch 32 --stage seg)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank owns its own recording of --minutes; strong (BASELINE configs[3]): ONE "
+                         "recording of --minutes whose windows are sharded over the ranks (each rank uploads only its "
+                         "slice + one window of halo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra fp32-MFMA-mode step reported beside f32s")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra steps in the other fp32 modes")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (device + host AHC) leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,8 +218,10 @@ def main():
 
     from diarizen_amd import _lib
     from diarizen_amd.configs import RESNET34, get_seg_config
+    from diarizen_amd.dist import gather_windows
     from diarizen_amd.engine import Engine
     from diarizen_amd.inference import WindowRunner
+    from diarizen_amd.synth import synth_recording_range
     from diarizen_amd.weights import emb_state_dict, seg_state_dict   # seeded random init
 
     cfg = get_seg_config(args.model)
@@ -140,17 +233,31 @@ def main():
                  precision=args.precision, device=dev)
     runner = WindowRunner(eng, args.window, 0.1, args.batch)
     num_samples = int(args.minutes * 60 * sr)
-    wave = synth_recording(num_samples, seed=3407 + rank).to(dev)
-    n_windows = runner.num_windows(num_samples)
     audio_s = num_samples / sr
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        # ONE recording (seed 3407) for all ranks; this rank generates and uploads only the samples its windows touch
+        c0, c1, s0, ns = shard_slice(num_samples, runner.window, runner.step, rank, world)
+        wave_host = synth_recording_range(s0, ns, total=num_samples, seed=3407)
+        n_windows = runner.num_windows(num_samples)
+    else:
+        wave_host = synth_recording(num_samples, seed=3407 + rank)
+        n_windows = runner.num_windows(num_samples)
+    wave = wave_host.to(dev)
 
     full = args.stage == "full"
 
     def step():
-        res = runner.run(wave, with_embeddings=full)
+        res = runner.run(wave, with_embeddings=full) if wave.numel() else None
         if not full:
             return res.segmentations.cpu()
         if world > 1:
+            if strong:      # ranks hold different window counts: padded all-gather in window order (dist.py)
+                S, L = eng.seg.max_speakers_per_chunk, runner.num_frames
+                seg_l = res.segmentations if res is not None else torch.empty((0, L, S), device=dev, dtype=torch.uint8)
+                emb_l = res.embeddings if res is not None else torch.empty((0, S, eng.emb.embed_dim), device=dev)
+                seg_g, emb_g = gather_windows(seg_l, emb_l)
+                return (seg_g.cpu(), emb_g.cpu()) if rank == 0 else None
             segs = [torch.empty_like(res.segmentations) for _ in range(world)]
             embs = [torch.empty_like(res.embeddings) for _ in range(world)]
             dist.all_gather(segs, res.segmentations)
@@ -162,6 +269,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # the in-situ HIP-event profiler runs INSIDE the timed steps (two event records per launch on the launch stream;
+    # measured cost 1 % of the step, reported as `unprofiled_ms_per_step` from one extra step below)
     if not args.no_profile:
         _lib.profile_enable(True)
     if dist is not None:
@@ -180,12 +289,19 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    unprofiled_ms = (time.perf_counter() - t1) * 1e3
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * audio_s * args.steps / dt
+        total_audio = audio_s if strong else world * audio_s
+        value = total_audio * args.steps / dt
         roofline = None
         kernels = []
+        extra = {}
         if prof:
             tot_ms = sum(p["ms"] for p in prof)
             for p in sorted(prof, key=lambda p: -p["ms"]):
@@ -195,8 +311,10 @@ def main():
                     e["tflops"] = round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 2)
                 if p["bytes"] > 0 and p["ms"] > 0:
                     e["gbs"] = round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1)
+                    e["alg_bytes_per_launch"] = int(p["bytes"] / p["launches"])
                 kernels.append(e)
             top = max(prof, key=lambda p: p["ms"])
+            traffic = pmc_table(args)
             if top["flops"] > 0:
                 prec = ("bf16" if "bf16" in top["name"] else "f32s" if "f32s" in top["name"] else
                         "f32h" if "f32h" in top["name"] else "f32")
@@ -204,7 +322,7 @@ def main():
                 roofline = {"kernel": top["name"], "bound": "mfma", "achieved": round(ach, 2),
                             "peak": round(PEAK_TFLOPS[prec], 1), "unit": "TFLOP/s",
                             "frac": round(ach / PEAK_TFLOPS[prec], 4),
-                            "traffic": pmc_traffic(top["name"], args),
+                            "traffic": pmc_lookup(traffic, top["name"], "hbm_bytes_per_launch"),
                             "launches": top["launches"],
                             "avg_launch_ms": round(top["ms"] / top["launches"], 4),
                             "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 3)}
@@ -221,39 +339,63 @@ def main():
                 ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
                 roofline = {"kernel": top["name"], "bound": "hbm", "achieved": round(ach, 1),
                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
-                            "traffic": None, "launches": top["launches"],
+                            "traffic": pmc_lookup(traffic, top["name"], "hbm_bytes_per_launch"),
+                            "launches": top["launches"],
                             "avg_launch_ms": round(top["ms"] / top["launches"], 4)}
+            # north_star asks for two more figures: MFMA utilisation on the attention contractions and HBM GB/s on
+            # the conv frontend.  Rates are live (HIP events of this run); MfmaUtil / PMC bytes come from the
+            # committed rocprofv3 --pmc passes of the same command (profiles/, scripts/final_measure.sh).
+            for key, names in (("attention", ("attention_relpos_f32s", "attention_relpos_f32h", "attention_relpos_f32")),
+                               ("conv_frontend", ("conv0_ln_gelu", "conv01_fused"))):
+                p = next((p for p in prof if p["name"] in names), None)
+                if p is None:
+                    continue
+                e = {"kernel": p["name"], "avg_launch_ms": round(p["ms"] / p["launches"], 4)}
+                if p["flops"] > 0:
+                    e["tflops"] = round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 2)
+                if p["bytes"] > 0:
+                    e["alg_bytes_per_launch"] = int(p["bytes"] / p["launches"])
+                    e["gbs"] = round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1)
+                    e["frac_of_hbm_peak"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
+                e["pmc_hbm_bytes_per_launch"] = pmc_lookup(traffic, p["name"], "hbm_bytes_per_launch")
+                e["pmc_mfma_util_pct"] = pmc_lookup(traffic, p["name"], "mfma_util_pct")
+                extra[key] = e
+            extra["kernel_ms_per_step"] = round(tot_ms / args.steps, 2)
+            extra["non_kernel_frac"] = round(1.0 - tot_ms / args.steps / ms_per_step, 4)
         out = {
             "metric": "audio-seconds/s (RTF) for wavlm-large-s80 pipeline, 16 kHz mono",
             "value": round(value, 2), "unit": "audio-seconds/s", "rtf": round(1.0 / value, 6),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
             "config": {"workload": f"{args.model} hot path ({'segmentation + masks + ResNet34 embeddings' if full else 'segmentation only'}), "
-                                   f"{args.minutes:g} min synthetic 16 kHz mono per GPU, window "
+                                   f"{args.minutes:g} min synthetic 16 kHz mono {'sharded over the ranks' if strong else 'per GPU'}, window "
                                    f"{args.window:g} s, step {0.1 * args.window:g} s, {n_windows} windows, "
-                                   f"batch {args.batch}; host clustering excluded",
+                                   f"batch {args.batch}; host clustering excluded from `value` (see `e2e`)",
                        "windows_per_step": n_windows, "batch": args.batch,
                        "weights": "seeded random init (no checkpoints offline)"},
-            "windows_per_s": round(world * n_windows * args.steps / dt, 1),
+            "windows_per_s": round((1 if strong else world) * n_windows * args.steps / dt, 1),
+            "unprofiled_ms_per_step": round(unprofiled_ms, 2),
             "roofline": roofline,
+            "roofline_extra": extra,
             "kernels": kernels,
         }
-        if args.precision == "f32s" and world == 1 and not args.no_alt:
-            # the same workload with the contractions on the fp32 MFMA (one extra untimed-warmup + timed step)
-            eng2 = Engine(cfg, sd, RESNET34, esd, max_batch=args.batch, max_samples=window, precision="f32",
-                          device=dev)
-            r2 = WindowRunner(eng2, args.window, 0.1, args.batch)
-            for timed in (False, True):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                res = r2.run(wave, with_embeddings=full)
-                _ = (res.segmentations.cpu(), res.embeddings.cpu()) if full else res.segmentations.cpu()
-                torch.cuda.synchronize()
-                dt2 = time.perf_counter() - t1
-            out["fp32_mfma_mode"] = {"value": round(audio_s / dt2, 2), "unit": "audio-seconds/s",
-                                     "ms_per_step": round(dt2 * 1e3, 2), "steps": 1,
-                                     "note": "--precision f32: same workload, contractions on v_mfma_f32_16x16x4_f32"}
+        if world == 1 and not args.no_alt and args.precision in ("f32h", "f32s"):
+            # the same workload in the other fp32 modes (strict parity tests run in all three)
+            alt = {}
+            for prec in ("f32s", "f32h", "f32"):
+                if prec == args.precision:
+                    continue
+                dt2 = run_mode(cfg, sd, esd, wave, args, window, prec, full, dev)
+                alt[prec] = {"value": round(audio_s / dt2, 2), "unit": "audio-seconds/s",
+                             "ms_per_step": round(dt2 * 1e3, 2), "steps": 1, "dtype": DTYPE_NOTE[prec]}
+            out["other_fp32_modes"] = alt
+            out["fp32_mfma_mode"] = alt["f32"]
+        if world == 1 and full and not args.no_e2e and args.minutes <= 60:
+            del eng
+            torch.cuda.empty_cache()
+            out["e2e"] = e2e_leg(args, dev, wave_host)
         if not args.no_cpu_baseline and world == 1 and full:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, esd, window, 0.1 * args.window)
         print(json.dumps(out))

@@ -65,7 +65,34 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
         if verbose:
             print(f"linked {LIB}")
+    build_c_harness(force, verbose)
     return LIB
+
+
+C_HARNESS_SRC = ROOT.parent / "tests" / "c_abi_smoke.c"
+C_HARNESS = OBJ / "c_abi_smoke"
+
+
+def build_c_harness(force: bool = False, verbose: bool = False):
+    """tests/c_abi_smoke.c with gcc as plain C11 against include/dzn.h + libdzn_hip.so: proves the boundary is a C ABI
+    (no C++ / torch types) and gives tests/test_properties_gpu.py a Python-free driver.  Optional: skipped when the
+    source or gcc is absent."""
+    import shutil
+    gcc = shutil.which("gcc")
+    if not C_HARNESS_SRC.exists() or gcc is None:
+        return None
+    if (not force and C_HARNESS.exists() and C_HARNESS.stat().st_mtime > C_HARNESS_SRC.stat().st_mtime
+            and C_HARNESS.stat().st_mtime > _headers_mtime()):
+        return C_HARNESS
+    cmd = [gcc, "-std=c11", "-O1", "-Wall", f"-I{ROOT.parent / 'include'}", "-I/opt/rocm/include", str(C_HARNESS_SRC),
+           "-o", str(C_HARNESS), f"-L{LIBDIR}", "-ldzn_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"gcc failed for c_abi_smoke.c:\n{r.stderr[-3000:]}")
+    if verbose:
+        print(f"built {C_HARNESS}")
+    return C_HARNESS
 
 
 if __name__ == "__main__":

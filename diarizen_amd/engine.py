@@ -21,7 +21,7 @@ PRECISIONS = {"f32": DZN_PREC_F32, "fp32": DZN_PREC_F32, "bf16": DZN_PREC_BF16,
 
 
 def make_dzn_config(seg: SegConfig, emb: Optional[EmbConfig], max_batch: int, max_samples: int,
-                    precision: str = "f32s") -> DznConfig:
+                    precision: str = "f32h") -> DznConfig:
     c = DznConfig()
     c.struct_size = C.sizeof(DznConfig)
     c.precision = PRECISIONS[precision]
@@ -70,7 +70,7 @@ class Engine:
     def __init__(self, seg: SegConfig, seg_state: Mapping[str, torch.Tensor],
                  emb: Optional[EmbConfig] = None,
                  emb_state: Optional[Mapping[str, torch.Tensor]] = None, *, max_batch: int = 32,
-                 max_samples: int = 128000, precision: str = "f32s",
+                 max_samples: int = 128000, precision: str = "f32h",
                  device: Optional[torch.device] = None):
         if not torch.cuda.is_available():
             raise _lib.DznError("no HIP device: diarizen_amd has no CPU path")

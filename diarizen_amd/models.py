@@ -15,6 +15,7 @@ from __future__ import annotations
 import importlib
 import os
 from dataclasses import dataclass
+from enum import Enum
 from functools import cached_property
 from typing import Any, Dict, Mapping, Optional
 
@@ -41,15 +42,30 @@ def instantiate(path: str, args: Optional[Dict[str, Any]] = None, initialize: bo
     return cls(**(args or {}))
 
 
+class Resolution(Enum):      # PA/core/task.py Resolution
+    FRAME = 1
+    CHUNK = 2
+
+
 @dataclass
 class Specifications:
-    """Subset of PA/core/task.py Specifications read by the pipeline (PA/core/model.py:159-170)."""
+    """PA/core/task.py:80-136 `Specifications` as far as Inference / the pipelines read it (PA/core/inference.py:
+    116-163, PA/core/model.py:159-170): iterable of itself (`for s in specifications`, `next(iter(...))`), frame
+    resolution, powerset mono-label problem."""
     duration: float
     classes: tuple
     powerset_max_classes: int
     powerset: bool = True
     permutation_invariant: bool = True
     warm_up: tuple = (0.0, 0.0)
+    resolution: Resolution = Resolution.FRAME
+    min_duration: Optional[float] = None
+
+    def __len__(self) -> int:
+        return 1
+
+    def __iter__(self):
+        yield self
 
     @property
     def num_powerset_classes(self) -> int:
@@ -66,7 +82,7 @@ class WavLMConformer:
                  use_posi: bool = False, output_activate_function=False,
                  max_speakers_per_chunk: int = 4, max_speakers_per_frame: int = 2,
                  chunk_size: int = 5, num_channels: int = 8, selected_channel: int = 0,
-                 sample_rate: int = 16000, precision: str = "f32s", max_batch: int = 32):
+                 sample_rate: int = 16000, precision: str = "f32h", max_batch: int = 32):
         if use_posi or output_activate_function:
             raise NotImplementedError("use_posi / output activation are unused by the released confs")
         from dataclasses import replace
@@ -92,6 +108,8 @@ class WavLMConformer:
         self.specifications = Specifications(
             duration=chunk_size, classes=tuple(f"speaker#{i + 1}" for i in range(max_speakers_per_chunk)),
             powerset_max_classes=max_speakers_per_frame)
+        from .compat import AudioLite
+        self.audio = AudioLite(sample_rate, "downmix" if num_channels == 1 else None)    # PA/core/model.py:152-157
         self._state: Optional[Mapping[str, torch.Tensor]] = None
         self.engine: Optional[Engine] = None
         self.device = torch.device("cpu")

@@ -64,7 +64,7 @@ def run_host_stage(seg: np.ndarray, emb: np.ndarray, *, chunks: SlidingWindow, c
 class DiariZenPipeline:
     def __init__(self, diarizen_hub, embedding_model, config_parse: Optional[Dict[str, Any]] = None,
                  rttm_out_dir: Optional[str] = None, *, device: Optional[torch.device] = None,
-                 precision: str = "f32s", seg_state: Optional[Mapping[str, torch.Tensor]] = None,
+                 precision: str = "f32h", seg_state: Optional[Mapping[str, torch.Tensor]] = None,
                  emb_state: Optional[Mapping[str, torch.Tensor]] = None,
                  config: Optional[Dict[str, Any]] = None):
         """diarizen_hub: directory with config.toml / pytorch_model.bin / plda ; embedding_model: path of
@@ -154,12 +154,30 @@ class DiariZenPipeline:
                              step=self.segmentation_step * self.seg_duration)
 
     def device_stage(self, waveform: np.ndarray):
-        """host float32 [N] -> (segmentations u8 [C, L, 4], embeddings f32 [C, 4, 256]) on the host."""
+        """host float32 [N] -> (segmentations u8 [C, L, 4], embeddings f32 [C, 4, 256]) on the host.
+        With torch.distributed initialised, this rank uploads ONLY the samples its contiguous window range touches
+        (its slice + one window of halo), runs them, and the per-window results are all-gathered."""
         from . import dist as dz_dist
-        wave = torch.from_numpy(np.ascontiguousarray(waveform, dtype=np.float32)).to(self.device)
-        rng = dz_dist.my_window_range(self._runner.num_windows(wave.numel()))
-        res = self._runner.run(wave, with_embeddings=True, window_range=rng)
-        seg, emb = dz_dist.gather_windows(res.segmentations, res.embeddings)
+        r = self._runner
+        C = r.num_windows(len(waveform))
+        rng = dz_dist.my_window_range(C)
+        x = np.ascontiguousarray(waveform, dtype=np.float32)
+        if rng is not None:
+            c0, c1 = rng
+            lo, n = c0 * r.step, ((c1 - c0 - 1) * r.step + r.window if c1 > c0 else 0)
+            sl = np.zeros(n, dtype=np.float32)                     # zero-extended like the last window (inference.py:293-299)
+            have = x[lo:lo + n]
+            sl[:len(have)] = have
+            x = sl
+        if len(x):
+            wave = torch.from_numpy(x).to(self.device)
+            res = r.run(wave, with_embeddings=True)
+            seg_l, emb_l = res.segmentations, res.embeddings
+        else:                                                      # more ranks than windows
+            S = self.engine.seg.max_speakers_per_chunk
+            seg_l = torch.empty((0, r.num_frames, S), device=self.device, dtype=torch.uint8)
+            emb_l = torch.empty((0, S, self.engine.emb.embed_dim), device=self.device, dtype=torch.float32)
+        seg, emb = dz_dist.gather_windows(seg_l, emb_l)
         torch.cuda.synchronize(self.device)
         return seg.cpu().numpy(), emb.cpu().numpy()
 
@@ -172,7 +190,7 @@ class DiariZenPipeline:
     # ------------------------------------------------------------------ __call__
     def __call__(self, in_wav, sess_name: Optional[str] = None) -> Annotation:
         import time
-        if isinstance(in_wav, dict):                       # ProtocolFile-like
+        if isinstance(in_wav, Mapping):                    # pyannote ProtocolFile (a Mapping, not a dict)
             in_wav = in_wav["audio"]
         assert isinstance(in_wav, (str, os.PathLike, BytesIO, bytes)), \
             f"input must be either a str, BytesIO or a ProtocolFile; there was {type(in_wav)}"

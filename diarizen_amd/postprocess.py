@@ -22,7 +22,7 @@ from .core import Annotation, Segment, SlidingWindow, SlidingWindowFeature
 def receptive_field(sample_rate: int = 16000) -> SlidingWindow:
     """Model._receptive_field (PA/core/model.py:180-195) for the 7-conv WavLM extractor
     (k = 10,3,3,3,3,2,2 ; s = 5,2,2,2,2,2,2): size 400 samples, step 320, centre of frame 0 at
-    sample 79.5 -> start = (79.5 - 199.5)/sr = -0.0075 s."""
+    sample 79 -> start = (79 - 199.5)/sr = -0.00753125 s."""
     k = [10, 3, 3, 3, 3, 2, 2]
     s = [5, 2, 2, 2, 2, 2, 2]
 

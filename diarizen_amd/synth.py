@@ -28,3 +28,24 @@ def synth_recording(num_samples: int, seed: int = 3407) -> torch.Tensor:
                  + 0.3 * torch.randn(num_samples, generator=g))
         x += 0.08 * active[s] * voice
     return x.clamp_(-1.0, 1.0)
+
+
+BLOCK_S = 60   # seconds per independently seeded block of synth_recording_range
+
+
+def synth_recording_range(start: int, num: int, total: int, seed: int = 3407) -> torch.Tensor:
+    """samples [start, start + num) of a `total`-sample recording built from independently seeded 60 s blocks
+    (block b = synth_recording(60 s, seed + 1000 b)), zero beyond `total`: any rank can materialise just the slice
+    its windows touch (strong scaling over one long recording, BASELINE configs[3]) and all ranks agree on the data."""
+    out = torch.zeros(max(num, 0))
+    if num <= 0:
+        return out
+    bl = BLOCK_S * 16000
+    end = min(start + num, total)
+    for b in range(start // bl, (max(end, start + 1) - 1) // bl + 1):
+        lo, hi = max(start, b * bl), min(end, (b + 1) * bl)
+        if hi <= lo:
+            continue
+        blk = synth_recording(min(bl, total - b * bl), seed=seed + 1000 * b)
+        out[lo - start:hi - start] = blk[lo - b * bl:hi - b * bl]
+    return out

@@ -39,7 +39,7 @@ class _SW:
         return 0.5 * (s + (s + self.duration))
 
 
-RECEPTIVE_FIELD = (-0.0075, 0.025, 0.02)          # Model._receptive_field: start, duration, step (PA/core/model.py:180-195)
+RECEPTIVE_FIELD = (-0.00753125, 0.025, 0.02)          # Model._receptive_field: start, duration, step (PA/core/model.py:180-195)
 
 
 def aggregate(scores, chunks: _SW, frames: _SW, hamming=False, missing=np.nan, skip_average=False,

@@ -122,3 +122,50 @@ def test_degenerate_waveforms_match_oracle(engine, gpu):
     emb = engine.embed(wave.to(gpu), masks)
     torch.cuda.synchronize()
     assert torch.isfinite(emb).all()
+
+
+def test_c_abi_without_python(built_lib, gpu, tmp_path):
+    """The drop-in boundary is a C ABI: tests/c_abi_smoke.c (gcc -std=c11, built by diarizen_amd/build.py) creates a
+    handle, loads every tensor, finalizes, runs dzn_segment_forward on ITS OWN hipMalloc'ed buffers and stream and
+    checks the log-probs against the oracle's — no Python, torch or C++ on its side.  Python only writes the blob."""
+    import struct
+    import subprocess
+    import ctypes as C
+    from diarizen_amd import build as b
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import make_dzn_config
+    from diarizen_amd.weights import turn_taking_state_dict
+    from oracle import seg_model
+    from oracle.gen_golden import tt_windows
+    exe = b.build_c_harness()
+    if exe is None:
+        pytest.skip("gcc not available")
+    cfg = get_seg_config("tiny_ln")
+    sd = turn_taking_state_dict(cfg, 0)
+    B, N = 3, 12000
+    wave = tt_windows([16000, 80000, 200000], N)
+    ref = seg_model.seg_forward(sd, cfg, wave).numpy()
+    L = ref.shape[1]
+    zc = make_dzn_config(cfg, None, B, N, "f32h")
+    blob = tmp_path / "blob.bin"
+    with open(blob, "wb") as f:
+        f.write(b"DZNBLOB1")
+        f.write(bytes(zc))
+        items = [(k, v) for k, v in sd.items()]
+        f.write(struct.pack("<i", len(items)))
+        for k, v in items:
+            t = v.detach().cpu().contiguous()
+            if t.dtype == torch.int64:
+                dt = 2
+            else:
+                t, dt = t.float(), 0
+            kb = k.encode()
+            f.write(struct.pack("<i", len(kb)) + kb + struct.pack("<ii", dt, t.dim()))
+            f.write(struct.pack(f"<{t.dim()}q", *t.shape))
+            f.write(t.numpy().tobytes())
+        f.write(struct.pack("<ii", B, N) + wave.numpy().astype(np.float32).tobytes())
+        f.write(struct.pack("<ii", L, cfg.n_classes) + ref.astype(np.float32).tobytes() + struct.pack("<f", 1e-3))
+    r = subprocess.run([str(exe), str(blob)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "argmax flips=0" in r.stdout
