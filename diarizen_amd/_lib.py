@@ -138,6 +138,8 @@ def load() -> C.CDLL:
     sig("dzn_segment_forward", i32, [vp, vp, i32, i32, vp, vp, vp])
     sig("dzn_embed_forward", i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp])
     sig("dzn_prepare_masks", i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp])
+    sig("dzn_speaker_count", i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp])
+    sig("dzn_cluster_activations", i32, [vp, vp, i32, i32, i32, vp, i32, i32, vp, vp])
     sig("dzn_debug_fetch", i32, [vp, C.c_char_p, vp, i64, C.POINTER(i64)])
     sig("dzn_num_ignored", i32, [vp])
     sig("dzn_workspace_bytes", i64, [vp])
@@ -165,7 +167,7 @@ def load() -> C.CDLL:
 
 EXPORTED = [
     "dzn_create", "dzn_load_tensor", "dzn_finalize_weights", "dzn_num_frames",
-    "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_debug_fetch", "dzn_num_ignored",
+    "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_speaker_count", "dzn_cluster_activations", "dzn_debug_fetch", "dzn_num_ignored",
     "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid",
     "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention",
     "dzn_profile_enable", "dzn_profile_collect", "dzn_op_relpos_bucket",

@@ -69,7 +69,91 @@ __global__ __launch_bounds__(256) void prepare_masks_kernel(const uint8_t* __res
   }
 }
 
+// ---- host post-processing moved to the device -------------------------------------------
+// Inference.aggregate (PA/core/inference.py:574-666) for the two uses of the pipeline — speaker counting
+// (PA/pipelines/utils/diarization.py:147-155) and reconstruct / to_diarization (PA/pipelines/speaker_diarization.py:
+// 400-425, diarization.py:213-239) — is an overlap-add of small integers: window c adds its L frames at
+// start_frame[c] (host-computed with the reference's float64 closest_frame, so no float semantics live here).
+// Integer atomics: order independent, bit-reproducible.
+__global__ __launch_bounds__(256) void count_accum_kernel(const uint8_t* __restrict__ seg, int64_t CL, int L, int S,
+                                                          const int32_t* __restrict__ start, int T,
+                                                          int32_t* __restrict__ sum, int32_t* __restrict__ cnt) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < CL; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i / L), l = (int)(i - (int64_t)c * L);
+    const int t = start[c] + l;
+    if (t < 0 || t >= T) continue;
+    int tot = 0;
+    for (int s = 0; s < S; ++s) tot += seg[i * S + s];
+    if (tot) atomicAdd(sum + t, tot);
+    atomicAdd(cnt + t, 1);
+  }
+}
+
+// count[t] = uint8(rint(sum / max(cnt, 1e-12))) in float32 like the reference's float32 accumulators; frames no
+// window covers are `missing = 0`
+__global__ __launch_bounds__(256) void count_finalize_kernel(const int32_t* __restrict__ sum, const int32_t* __restrict__ cnt,
+                                                             int T, uint8_t* __restrict__ count) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float avg = cnt[t] ? __fdiv_rn((float)sum[t], fmaxf((float)cnt[t], 1e-12f)) : 0.f;
+  count[t] = (uint8_t)rintf(avg);
+}
+
+// act[t, k] += max_s { seg[c, l, s] : hard[c, s] == k }   (skip_average=True; clusters absent from a window are NaN in
+// the reference = contribute nothing)
+__global__ __launch_bounds__(256) void cluster_accum_kernel(const uint8_t* __restrict__ seg, const int8_t* __restrict__ hard,
+                                                            int64_t CL, int L, int S, const int32_t* __restrict__ start,
+                                                            int T, int K, int32_t* __restrict__ act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < CL; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i / L), l = (int)(i - (int64_t)c * L);
+    const int t = start[c] + l;
+    if (t < 0 || t >= T) continue;
+    unsigned mask = 0;
+    for (int s = 0; s < S; ++s) {
+      const int k = hard[c * S + s];
+      if (k >= 0 && k < K && seg[i * S + s]) mask |= 1u << k;
+    }
+    while (mask) {
+      const int k = __ffs(mask) - 1;
+      mask &= mask - 1;
+      atomicAdd(act + (int64_t)t * K + k, 1);
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int dzn_speaker_count(const uint8_t* d_seg, int32_t C, int32_t L, int32_t S, const int32_t* d_start_frame,
+                                 int32_t T, int32_t* d_work, uint8_t* d_count, void* stream) {
+  if (!d_seg || !d_start_frame || !d_work || !d_count || C < 0 || L < 1 || S < 1 || T < 1) return DZN_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(d_work, 0, sizeof(int32_t) * 2 * (size_t)T, st) != hipSuccess) return DZN_E_HIP;
+  const int64_t CL = (int64_t)C * L;
+  if (CL > 0) {
+    int64_t g = cdiv64(CL, 256);
+    g = g > 8192 ? 8192 : g;
+    hipLaunchKernelGGL(count_accum_kernel, dim3((unsigned)g), dim3(256), 0, st, d_seg, CL, L, S, d_start_frame, T,
+                       d_work, d_work + T);
+  }
+  hipLaunchKernelGGL(count_finalize_kernel, dim3((T + 255) / 256), dim3(256), 0, st, d_work, d_work + T, T, d_count);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+extern "C" int dzn_cluster_activations(const uint8_t* d_seg, const int8_t* d_hard, int32_t C, int32_t L, int32_t S,
+                                       const int32_t* d_start_frame, int32_t T, int32_t K, int32_t* d_act, void* stream) {
+  if (!d_seg || !d_hard || !d_start_frame || !d_act || C < 0 || L < 1 || S < 1 || T < 1 || K < 1 || K > 32)
+    return DZN_E_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(d_act, 0, sizeof(int32_t) * (size_t)T * K, st) != hipSuccess) return DZN_E_HIP;
+  const int64_t CL = (int64_t)C * L;
+  if (CL > 0) {
+    int64_t g = cdiv64(CL, 256);
+    g = g > 8192 ? 8192 : g;
+    hipLaunchKernelGGL(cluster_accum_kernel, dim3((unsigned)g), dim3(256), 0, st, d_seg, d_hard, CL, L, S, d_start_frame,
+                       T, K, d_act);
+  }
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
 
 int launch_prepare_masks(const uint8_t* ml, int B, int L, int S, int median, int exclude_overlap,
                          int min_num_frames, uint8_t* filtered, float* masks, hipStream_t st) {

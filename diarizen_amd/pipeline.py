@@ -26,7 +26,7 @@ from .core import Annotation, SlidingWindow
 from .engine import Engine
 from .inference import WindowRunner
 from .models import SpeakerEmbedding, WavLMConformer, instantiate
-from .postprocess import binarize, receptive_field, reconstruct, speaker_count
+from .postprocess import DevicePost, binarize, receptive_field, reconstruct, speaker_count
 
 try:
     import tomllib as _toml  # py311+
@@ -44,20 +44,24 @@ def _load_checkpoint(path: str) -> Dict[str, torch.Tensor]:
 
 
 def run_host_stage(seg: np.ndarray, emb: np.ndarray, *, chunks: SlidingWindow, clustering, min_speakers: int,
-                   max_speakers: int, sample_rate: int = 16000, sess_name: Optional[str] = None) -> Annotation:
+                   max_speakers: int, sample_rate: int = 16000, sess_name: Optional[str] = None,
+                   device=None) -> Annotation:
     """The host half of `DiariZenPipeline.__call__` (diarizen/pipelines/inference.py:137-185): speaker
     counting -> clustering -> inactive speakers to -2 -> reconstruction -> Binarize.  Needs no device, so
     it is checked on the CPU against the oracle's loop-for-loop restatement (tests/test_host.py)."""
     frames = receptive_field(sample_rate)
     segf = seg.astype(np.float32)
-    count = speaker_count(segf, chunks, frames)
+    # device=...: the two overlap-add aggregations run on the HIP device (postprocess.DevicePost); None = numpy
+    post = DevicePost(seg, chunks, frames, device) if device is not None else None
+    count = post.speaker_count() if post is not None else speaker_count(segf, chunks, frames)
     hard, _, _ = clustering(embeddings=emb.astype(np.float64) if emb.dtype != np.float32 else emb,
                             segmentations=segf, min_clusters=min_speakers, max_clusters=max_speakers)
     count.data = np.minimum(count.data, max_speakers).astype(np.int8)
     inactive = np.sum(segf, axis=1) == 0
     hard = np.array(hard, copy=True)
     hard[inactive] = -2
-    discrete, _ = reconstruct(segf, chunks, hard, count)
+    res = post.reconstruct(hard, count) if post is not None else None
+    discrete, _ = res if res is not None else reconstruct(segf, chunks, hard, count)
     return binarize(discrete, onset=0.5, offset=0.5, uri=sess_name)
 
 
@@ -124,6 +128,7 @@ class DiariZenPipeline:
         if rttm_out_dir is not None:
             os.makedirs(rttm_out_dir, exist_ok=True)
         self.rttm_out_dir = rttm_out_dir
+        self.device_postprocess = True      # speaker counting / reconstruction aggregations on the device (row f2)
         self.timings: Dict[str, float] = {}
 
     # ------------------------------------------------------------------ construction
@@ -185,7 +190,8 @@ class DiariZenPipeline:
         """counting -> clustering -> reconstruction -> Annotation (inference.py:137-185)."""
         return run_host_stage(seg, emb, chunks=self.chunks_window(), clustering=self.clustering,
                               min_speakers=self.min_speakers, max_speakers=self.max_speakers,
-                              sample_rate=self.segmentation_model.sample_rate, sess_name=sess_name)
+                              sample_rate=self.segmentation_model.sample_rate, sess_name=sess_name,
+                              device=self.device if self.device_postprocess else None)
 
     # ------------------------------------------------------------------ __call__
     def __call__(self, in_wav, sess_name: Optional[str] = None) -> Annotation:

@@ -81,20 +81,7 @@ def to_diarization(clustered: np.ndarray, chunks: SlidingWindow, count: SlidingW
                    ) -> Tuple[SlidingWindowFeature, SlidingWindowFeature]:
     act = aggregate(clustered, chunks, count.sliding_window, hamming=False, missing=0.0,
                     skip_average=True)
-    K = act.data.shape[1]
-    max_per_frame = int(np.max(count.data)) if count.data.size else 0
-    if K < max_per_frame:
-        act.data = np.pad(act.data, ((0, 0), (0, max_per_frame - K)))
-    n = min(len(act.data), len(count.data))      # identical grids: extent & extent keeps all frames
-    a = act.data[:n]
-    c = count.data[:n].reshape(-1).astype(np.int64)
-    order = np.argsort(-a, axis=-1)               # same call as the reference (ties: numpy's order)
-    sel = (np.arange(a.shape[1])[None, :] < c[:, None]).astype(a.dtype)
-    binary = np.zeros_like(a)
-    np.put_along_axis(binary, order, sel, axis=-1)
-    sw = SlidingWindow(start=act.sliding_window.start, duration=act.sliding_window.duration,
-                       step=act.sliding_window.step)
-    return SlidingWindowFeature(binary, sw), SlidingWindowFeature(a, sw)
+    return _select_top_count(act, count)
 
 
 def reconstruct(segmentations: np.ndarray, chunks: SlidingWindow, hard_clusters: np.ndarray,
@@ -113,6 +100,87 @@ def reconstruct(segmentations: np.ndarray, chunks: SlidingWindow, hard_clusters:
         vals = np.where(sel[:, None, :], seg, -np.inf).max(axis=2)  # max over local speakers -> [C, L]
         clustered[has, :, k] = vals[has]
     return to_diarization(clustered, chunks, count)
+
+
+# ----------------------------------------------------------------------------- device versions (row f2)
+def _frame_grid(C: int, L: int, chunks: SlidingWindow, frames: SlidingWindow):
+    """(frame grid of aggregate(), start frame of every window, number of output frames) — the reference's float64
+    closest_frame arithmetic (PA/core/inference.py:577-581, 611-620, 645) stays on the host."""
+    grid = SlidingWindow(start=chunks.start, duration=frames.duration, step=frames.step)
+    starts = np.array([grid.closest_frame(chunks.start + c * chunks.step + 0.5 * grid.duration) for c in range(C)],
+                      dtype=np.int32)
+    T = grid.closest_frame(chunks.start + chunks.duration + (C - 1) * chunks.step + 0.5 * grid.duration) + 1
+    return grid, starts, int(T)
+
+
+class DevicePost:
+    """speaker_count / reconstruct with their overlap-add aggregations on the HIP device (dzn_speaker_count,
+    dzn_cluster_activations: integer atomics over the u8 decisions).  The decisions are uploaded once (3.6 MB per
+    30 min); the top-`count` selection per frame keeps the reference's numpy call on the downloaded activations."""
+
+    def __init__(self, segmentations: np.ndarray, chunks: SlidingWindow, frames: SlidingWindow, device):
+        import ctypes as C_
+        import torch
+        from . import _lib
+        self._C, self.torch, self.lib, self.check = C_, torch, _lib.load(), _lib.check
+        self.device = torch.device(device)
+        seg = np.ascontiguousarray(segmentations)
+        if seg.dtype != np.uint8:
+            if not np.array_equal(seg, seg.astype(np.uint8)):
+                raise ValueError("DevicePost needs hard {0,1} decisions")
+            seg = seg.astype(np.uint8)
+        self.C, self.L, self.S = seg.shape
+        self.chunks = chunks
+        self.grid, starts, self.T = _frame_grid(self.C, self.L, chunks, frames)
+        with torch.cuda.device(self.device):
+            self.seg = torch.from_numpy(seg).to(self.device)
+            self.starts = torch.from_numpy(starts).to(self.device)
+
+    def _p(self, t):
+        return self._C.c_void_p(t.data_ptr())
+
+    def speaker_count(self) -> SlidingWindowFeature:
+        torch = self.torch
+        with torch.cuda.device(self.device):
+            work = torch.empty(2 * self.T, device=self.device, dtype=torch.int32)
+            out = torch.empty(self.T, device=self.device, dtype=torch.uint8)
+            st = self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            self.check(self.lib.dzn_speaker_count(self._p(self.seg), self.C, self.L, self.S, self._p(self.starts), self.T,
+                                                  self._p(work), self._p(out), st), None, "dzn_speaker_count")
+            return SlidingWindowFeature(out.cpu().numpy().reshape(-1, 1), self.grid)
+
+    def reconstruct(self, hard_clusters: np.ndarray, count: SlidingWindowFeature):
+        torch = self.torch
+        K = int(np.max(hard_clusters)) + 1 if hard_clusters.size else 0
+        if K < 1 or K > 32:
+            return None                                     # caller falls back to the numpy path
+        with torch.cuda.device(self.device):
+            hard = torch.from_numpy(np.ascontiguousarray(hard_clusters, dtype=np.int8)).to(self.device)
+            act = torch.empty((self.T, K), device=self.device, dtype=torch.int32)
+            st = self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            self.check(self.lib.dzn_cluster_activations(self._p(self.seg), self._p(hard), self.C, self.L, self.S,
+                                                        self._p(self.starts), self.T, K, self._p(act), st), None,
+                       "dzn_cluster_activations")
+            a = act.cpu().numpy().astype(np.float32)
+        return _select_top_count(SlidingWindowFeature(a, count.sliding_window), count)
+
+
+def _select_top_count(act: SlidingWindowFeature, count: SlidingWindowFeature):
+    """tail of to_diarization (PA/pipelines/utils/diarization.py:222-239) on aggregated activations"""
+    K = act.data.shape[1]
+    max_per_frame = int(np.max(count.data)) if count.data.size else 0
+    if K < max_per_frame:
+        act.data = np.pad(act.data, ((0, 0), (0, max_per_frame - K)))
+    n = min(len(act.data), len(count.data))      # identical grids: extent & extent keeps all frames
+    a = act.data[:n]
+    c = count.data[:n].reshape(-1).astype(np.int64)
+    order = np.argsort(-a, axis=-1)               # same call as the reference (ties: numpy's order)
+    sel = (np.arange(a.shape[1])[None, :] < c[:, None]).astype(a.dtype)
+    binary = np.zeros_like(a)
+    np.put_along_axis(binary, order, sel, axis=-1)
+    sw = SlidingWindow(start=act.sliding_window.start, duration=act.sliding_window.duration,
+                       step=act.sliding_window.step)
+    return SlidingWindowFeature(binary, sw), SlidingWindowFeature(a, sw)
 
 
 def binarize(diar: SlidingWindowFeature, onset: float = 0.5, offset: Optional[float] = None,

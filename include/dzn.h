@@ -174,6 +174,23 @@ int dzn_prepare_masks(dzn_handle* h, const uint8_t* d_multilabel, int32_t B, int
                       int32_t median_size, int32_t exclude_overlap, int32_t min_num_frames,
                       uint8_t* d_filtered, float* d_masks, void* hip_stream);
 
+/*
+ * Host post-processing on the device (stateless, no handle): the two overlap-add aggregations of
+ * the pipeline over the per-window decisions that are already in HBM.
+ *   dzn_speaker_count       <- SpeakerDiarizationMixin.speaker_count + Inference.aggregate(hamming=False,
+ *                              skip_average=False, missing=0)   PA/pipelines/utils/diarization.py:147-155,
+ *                              PA/core/inference.py:574-666:  count[t] = uint8(rint(sum_c sum_s seg / #windows))
+ *   dzn_cluster_activations <- SpeakerDiarization.reconstruct + the aggregate(skip_average=True) of to_diarization
+ *                              PA/pipelines/speaker_diarization.py:400-425, diarization.py:213-220:
+ *                              act[t,k] = sum_c max_s{seg[c,t-start_c,s] : hard[c,s]==k}   (hard < 0 = inactive)
+ * d_seg u8 [C,L,S]; d_start_frame int32 [C] = closest_frame(c*step + duration_frame/2) computed by the caller with
+ * the reference's float64 arithmetic; T = number of output frames.  d_work int32 [2T] scratch; d_act int32 [T,K], K<=32.
+ */
+int dzn_speaker_count(const uint8_t* d_seg, int32_t C, int32_t L, int32_t S, const int32_t* d_start_frame, int32_t T,
+                      int32_t* d_work, uint8_t* d_count, void* hip_stream);
+int dzn_cluster_activations(const uint8_t* d_seg, const int8_t* d_hard, int32_t C, int32_t L, int32_t S,
+                            const int32_t* d_start_frame, int32_t T, int32_t K, int32_t* d_act, void* hip_stream);
+
 /* Copy a named intermediate activation of the LAST forward to host (debug / parity
  * tests).  *n_elems receives the element count; host_out may be NULL to query. */
 int dzn_debug_fetch(dzn_handle* h, const char* name, float* host_out, int64_t cap,

@@ -169,3 +169,37 @@ def test_c_abi_without_python(built_lib, gpu, tmp_path):
     print(r.stdout, r.stderr)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "argmax flips=0" in r.stdout
+
+
+def test_device_postprocess_equals_numpy(built_lib, gpu):
+    """row f2: speaker counting and cluster activations aggregated on the device (integer atomics over the u8
+    decisions) are bit-identical to the numpy restatement of Inference.aggregate / reconstruct — on the e2e golden
+    and on a seeded 20-minute case with unassigned speakers, empty clusters and a cluster count above the speakers."""
+    import os
+    from diarizen_amd.core import SlidingWindow
+    from diarizen_amd.postprocess import DevicePost, receptive_field, reconstruct, speaker_count
+    frames = receptive_field(16000)
+    cases = []
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_EN2002a_30s.npz"))
+    cases.append((g["seg"], g["hard_clusters"].copy(), 8.0))
+    r = np.random.default_rng(5)
+    C, L = 1500, 399
+    seg = (r.random((C, L, 4)) < 0.3).astype(np.uint8)
+    seg[r.random((C, 4)) < 0.3] = 0                                  # inactive speakers
+    hard = r.integers(-2, 9, size=(C, 4)).astype(np.int8)            # -2 / -1 never contribute; cluster 7 may be empty
+    hard[hard == 7] = 3
+    cases.append((seg, hard, 8.0))
+    for seg, hard, dur in cases:
+        chunks = SlidingWindow(start=0.0, duration=dur, step=0.1 * dur)
+        hard = np.array(hard, copy=True)
+        hard[seg.sum(1) == 0] = -2
+        segf = seg.astype(np.float32)
+        c_np = speaker_count(segf, chunks, frames)
+        post = DevicePost(seg, chunks, frames, gpu)
+        c_dev = post.speaker_count()
+        assert c_dev.data.dtype == np.uint8 and np.array_equal(c_dev.data, c_np.data)
+        c_np.data = np.minimum(c_np.data, 20).astype(np.int8)
+        b_np, a_np = reconstruct(segf, chunks, hard, c_np)
+        b_dev, a_dev = post.reconstruct(hard, c_np)
+        assert np.array_equal(a_dev.data, a_np.data.astype(np.float32))
+        assert np.array_equal(b_dev.data, b_np.data)
