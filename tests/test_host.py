@@ -560,3 +560,22 @@ def test_duck_typed_facade_attribute_reads():
     assert m.eval() is m and m.num_frames(128000) == 399
     with pytest.raises(RuntimeError):
         m.to("cpu")                                        # no CPU path, loudly
+
+
+# ---------------------------------------------------------------- DER scorer (configs[4] acceptance metric)
+def test_der_known_answers():
+    from diarizen_amd.der import der, der_rttm
+    ref = [(0.0, 10.0, "A"), (5.0, 15.0, "B")]
+    assert der(ref, ref)["der"] == 0.0
+    assert der(ref, [(0.0, 10.0, "x"), (5.0, 15.0, "y")])["der"] == 0.0               # labels are mapped
+    d = der(ref, [(0.0, 10.0, "x")])                                                     # B missed entirely
+    assert abs(d["miss"] - 10.0) < 1e-12 and abs(d["der"] - 0.5) < 1e-12 and d["false_alarm"] == 0
+    d = der(ref, [(0.0, 10.0, "x"), (5.0, 15.0, "y"), (20.0, 22.0, "z")])                # 2 s of false alarm
+    assert abs(d["false_alarm"] - 2.0) < 1e-12 and abs(d["der"] - 0.1) < 1e-12
+    d = der([(0.0, 10.0, "A"), (10.0, 20.0, "B")], [(0.0, 12.0, "x"), (12.0, 20.0, "y")])   # 2 s confused
+    assert abs(d["confusion"] - 2.0) < 1e-12 and abs(d["der"] - 0.1) < 1e-12 and d["mapping"] == {"A": "x", "B": "y"}
+    d = der([(0.0, 10.0, "A"), (0.0, 10.0, "B")], [(0.0, 10.0, "x")])                       # overlap scored: one of two found
+    assert abs(d["der"] - 0.5) < 1e-12
+    rttm = open(os.path.join(GOLD, "e2e_EN2002a_30s.rttm")).read()
+    assert der_rttm(rttm, rttm, "EN2002a")["der"] == 0.0
+    assert der_rttm(rttm, open(os.path.join(GOLD, "e2e_EN2002a_30s_vbx.rttm")).read())["der"] > 0.0
