@@ -2,8 +2,8 @@
 and the `Audio` helper of PA/core/io.py for what the hot path needs: WAV in, first channel kept —
 "force to use the SDM data", inference.py:128 — resampled to 16 kHz when the file is at another
 rate, as `Audio.downmix_and_resample` does with `torchaudio.functional.resample`, PA/core/io.py:214-218).
-torchaudio is not available in this image: RIFF/WAVE PCM8/16/32 and float32 are decoded with the
-standard library + numpy, and the resampler restates torchaudio's default algorithm
+torchaudio is not available in this image: RIFF/WAVE (PCM 8/16/24/32, float 32/64, WAVE_FORMAT_EXTENSIBLE) is parsed
+directly with numpy, and the resampler restates torchaudio's default algorithm
 (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99; torchaudio==2.1.1 functional/functional.py
 `_get_sinc_resample_kernel` / `_apply_sinc_resample_kernel`).  Parity of the resampler is UNPINNED
 (no torchaudio here, no fixture in the reference); tests pin its properties instead.
@@ -11,42 +11,29 @@ standard library + numpy, and the resampler restates torchaudio's default algori
 from __future__ import annotations
 
 import io
-import wave
 from typing import BinaryIO, Tuple, Union
 
 import numpy as np
 
 
+_PCM_GUID_TAIL = bytes.fromhex("000000001000800000aa00389b71")   # KSDATAFORMAT_SUBTYPE_*: tag + this tail
+
+
 def load_wav(src: Union[str, bytes, BinaryIO, io.BytesIO]) -> Tuple[np.ndarray, int]:
-    """-> (float32 [channels, samples] in [-1, 1), sample_rate)  (torchaudio.load semantics)."""
+    """-> (float32 [channels, samples] in [-1, 1), sample_rate)  (torchaudio.load semantics).
+    RIFF/WAVE is parsed directly: PCM 8 / 16 / 24 / 32 bit, IEEE float 32 / 64, and WAVE_FORMAT_EXTENSIBLE
+    (tag 0xFFFE: the real format is the first two bytes of the SubFormat GUID) — everything `torchaudio.load`
+    reads from a .wav; the standard `wave` module refuses 24-bit extensible and float files."""
     if isinstance(src, (bytes, bytearray)):
-        src = io.BytesIO(src)
-    try:
-        with wave.open(src, "rb") as w:
-            nch, width, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
-            raw = w.readframes(n)
-        if width == 2:
-            x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-        elif width == 4:
-            x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
-        elif width == 1:
-            x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
-        else:
-            raise ValueError(f"unsupported PCM width {width}")
-    except wave.Error:
-        x, sr, nch = _load_float_wav(src)
-    return x.reshape(-1, nch).T.copy(), sr
-
-
-def _load_float_wav(src):
-    """IEEE-float WAVE (format tag 3), which the `wave` module refuses."""
-    if hasattr(src, "seek"):
-        src.seek(0)
+        data = bytes(src)
+    elif hasattr(src, "read"):
+        if hasattr(src, "seek"):
+            src.seek(0)
         data = src.read()
     else:
         with open(src, "rb") as f:
             data = f.read()
-    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+    if data[:4] not in (b"RIFF", b"RF64") or data[8:12] != b"WAVE":
         raise ValueError("not a RIFF/WAVE file")
     pos, fmt, body = 12, None, None
     while pos + 8 <= len(data):
@@ -54,17 +41,48 @@ def _load_float_wav(src):
         if cid == b"fmt ":
             fmt = data[pos + 8:pos + 8 + size]
         elif cid == b"data":
-            body = data[pos + 8:pos + 8 + size]
+            body = data[pos + 8:] if size in (0, 0xFFFFFFFF) else data[pos + 8:pos + 8 + size]   # streamed files
+            break
         pos += 8 + size + (size & 1)
-    if fmt is None or body is None:
+    if fmt is None or body is None or len(fmt) < 16:
         raise ValueError("malformed WAVE file")
     tag = int.from_bytes(fmt[0:2], "little")
     nch = int.from_bytes(fmt[2:4], "little")
     sr = int.from_bytes(fmt[4:8], "little")
+    block = int.from_bytes(fmt[12:14], "little")
     bits = int.from_bytes(fmt[14:16], "little")
-    if tag != 3 or bits != 32:
-        raise ValueError(f"unsupported WAVE format tag {tag} / {bits} bit")
-    return np.frombuffer(body, dtype="<f4").astype(np.float32), sr, nch
+    if tag == 0xFFFE:                                        # WAVE_FORMAT_EXTENSIBLE
+        if len(fmt) < 40 or fmt[26:40] != _PCM_GUID_TAIL:
+            raise ValueError("unsupported WAVE_FORMAT_EXTENSIBLE sub-format")
+        tag = int.from_bytes(fmt[24:26], "little")
+    if nch < 1 or sr < 1:
+        raise ValueError("malformed WAVE fmt chunk")
+    width = block // nch if block else (bits + 7) // 8      # container bytes per sample
+    body = body[:len(body) - len(body) % (width * nch)]
+    if tag == 1:                                             # integer PCM
+        if width == 1:
+            x = (np.frombuffer(body, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        elif width == 2:
+            x = np.frombuffer(body, dtype="<i2").astype(np.float32) / 32768.0
+        elif width == 3:
+            b3 = np.frombuffer(body, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b3[:, 0] | (b3[:, 1] << 8) | (b3[:, 2] << 16)
+            v = np.where(v & 0x800000, v - 0x1000000, v)
+            x = v.astype(np.float32) / 8388608.0
+        elif width == 4:
+            x = np.frombuffer(body, dtype="<i4").astype(np.float32) / 2147483648.0
+        else:
+            raise ValueError(f"unsupported PCM width {width}")
+    elif tag == 3:                                           # IEEE float
+        if width == 4:
+            x = np.frombuffer(body, dtype="<f4").astype(np.float32)
+        elif width == 8:
+            x = np.frombuffer(body, dtype="<f8").astype(np.float32)
+        else:
+            raise ValueError(f"unsupported float width {width}")
+    else:
+        raise ValueError(f"unsupported WAVE format tag {tag} ({bits} bit)")
+    return x.reshape(-1, nch).T.copy(), sr
 
 
 def resample(x: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,

@@ -36,7 +36,7 @@ def _hip_ready() -> bool:
         return False
 
 
-def centroid_linkage(emb: np.ndarray, backend: str = "auto") -> np.ndarray:
+def centroid_linkage(emb: np.ndarray, backend: str = "auto", device: int = -1) -> np.ndarray:
     """linkage(emb, method="centroid", metric="euclidean") (PA/pipelines/clustering.py:407-416, :656).
     backend "scipy": the reference's own call.  "hip": csrc/linkage.hip — the same greedy algorithm with
     the float64 distance matrix resident in HBM; produces the identical dendrogram (checked bit for bit
@@ -45,10 +45,25 @@ def centroid_linkage(emb: np.ndarray, backend: str = "auto") -> np.ndarray:
     if backend not in ("auto", "scipy", "hip"):
         raise ValueError(f"unknown linkage backend {backend!r}")
     use_hip = backend == "hip" or (backend == "auto" and len(emb) >= HIP_LINKAGE_MIN and _hip_ready())
+    if use_hip and backend == "auto" and _has_duplicate_rows(emb):
+        # exact distance ties: scipy's neighbour-heap order and the device's lowest-index argmin may merge tied
+        # pairs in a different order -> keep the reference's own call whenever ties are certain
+        use_hip = False
     if not use_hip:
         return linkage(emb, method="centroid", metric="euclidean")
     from . import ops
-    return ops.linkage_centroid(emb)
+    from ._lib import DznError
+    try:
+        return ops.linkage_centroid(emb, device=device)
+    except (DznError, MemoryError):
+        if backend == "hip":
+            raise
+        return linkage(emb, method="centroid", metric="euclidean")     # e.g. the n x n matrix does not fit
+
+
+def _has_duplicate_rows(emb: np.ndarray) -> bool:
+    v = np.ascontiguousarray(emb).view(np.dtype((np.void, emb.dtype.itemsize * emb.shape[1]))).ravel()
+    return len(np.unique(v)) < len(v)
 
 
 # --------------------------------------------------------------------------- shared pieces
@@ -124,7 +139,7 @@ class AgglomerativeClustering:
         if self.metric == "cosine" and self.method in ("centroid", "median", "ward"):
             with np.errstate(divide="ignore", invalid="ignore"):
                 emb /= np.linalg.norm(emb, axis=-1, keepdims=True)      # in place, like the reference
-            dendro = (centroid_linkage(emb, self.linkage_backend) if self.method == "centroid"
+            dendro = (centroid_linkage(emb, self.linkage_backend, getattr(self, 'device', -1)) if self.method == "centroid"
                       else linkage(emb, method=self.method, metric="euclidean"))
         else:
             dendro = linkage(emb, method=self.method, metric=self.metric)
@@ -264,7 +279,7 @@ class VBxClustering:
             return (np.zeros((C, S), dtype=np.int8), np.ones((C, S, 1)),
                     np.mean(train, axis=0, keepdims=True))
         normed = train / np.linalg.norm(train, axis=1, keepdims=True)
-        dendro = centroid_linkage(normed, self.linkage_backend)
+        dendro = centroid_linkage(normed, self.linkage_backend, getattr(self, 'device', -1))
         ahc = fcluster(dendro, self.ahc_threshold, criterion=self.ahc_criterion) - 1
         _, ahc = np.unique(ahc, return_inverse=True)
         if self._plda is None:

@@ -37,7 +37,12 @@ EMBEDDING_REPO = "pyannote/wespeaker-voxceleb-resnet34-LM"
 
 
 def _load_checkpoint(path: str) -> Dict[str, torch.Tensor]:
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    """plain state_dict (DiariZen hub `pytorch_model.bin`) or Lightning checkpoint (WeSpeaker).  Tensors-only
+    unpickling first; the permissive loader only for checkpoints that carry other python objects (Lightning)."""
+    try:
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(ckpt, dict) and "state_dict" in ckpt and isinstance(ckpt["state_dict"], dict):
         ckpt = ckpt["state_dict"]          # Lightning checkpoint (PA/core/model.py:459-473)
     return ckpt
@@ -125,6 +130,7 @@ class DiariZenPipeline:
                                             ahc_threshold=clu["ahc_threshold"], Fa=clu["Fa"], Fb=clu["Fb"])
         else:
             raise ValueError(f"Unsupported clustering method: {clu['method']}")
+        self.clustering.device = self.device.index if self.device.index is not None else 0   # device linkage (row f1)
         if rttm_out_dir is not None:
             os.makedirs(rttm_out_dir, exist_ok=True)
         self.rttm_out_dir = rttm_out_dir

@@ -579,3 +579,34 @@ def test_der_known_answers():
     rttm = open(os.path.join(GOLD, "e2e_EN2002a_30s.rttm")).read()
     assert der_rttm(rttm, rttm, "EN2002a")["der"] == 0.0
     assert der_rttm(rttm, open(os.path.join(GOLD, "e2e_EN2002a_30s_vbx.rttm")).read())["der"] > 0.0
+
+
+def test_wav_loader_24bit_extensible_float64(tmp_path):
+    """inputs torchaudio.load accepts — 24-bit PCM, WAVE_FORMAT_EXTENSIBLE (SubFormat GUID), float64"""
+    import struct
+    from diarizen_amd.audio import load_wav
+    g = np.random.default_rng(0)
+    x = np.clip(g.normal(size=(2, 1000)) * 0.3, -0.99, 0.99)
+
+    def riff(fmt, body):
+        chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(body)) + body
+        return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+    q = np.round(x.T * 8388607).astype(np.int32)                                 # interleaved 24-bit
+    b24 = b"".join(int(v).to_bytes(3, "little", signed=True) for v in q.reshape(-1))
+    fmt_pcm24 = struct.pack("<HHIIHH", 1, 2, 44100, 44100 * 6, 6, 24)
+    y, sr = load_wav(riff(fmt_pcm24, b24))
+    assert sr == 44100 and y.shape == (2, 1000) and np.abs(y - q.T / 8388608.0).max() < 1e-7
+    guid = struct.pack("<H", 1) + bytes.fromhex("000000001000800000aa00389b71")
+    fmt_ext = struct.pack("<HHIIHH", 0xFFFE, 2, 16000, 16000 * 6, 6, 24) + struct.pack("<HHI", 22, 24, 3) + guid
+    y2, sr2 = load_wav(io.BytesIO(riff(fmt_ext, b24)))
+    assert sr2 == 16000 and np.array_equal(y2, y)
+    f64 = x.T.astype("<f8").tobytes()
+    fmt_f64 = struct.pack("<HHIIHH", 3, 2, 8000, 8000 * 16, 16, 64)
+    y3, _ = load_wav(riff(fmt_f64, f64))
+    assert np.abs(y3 - x).max() < 1e-7
+    p = tmp_path / "x.wav"
+    p.write_bytes(riff(fmt_pcm24, b24))
+    assert np.array_equal(load_wav(str(p))[0], y)
+    with pytest.raises(ValueError):
+        load_wav(riff(struct.pack("<HHIIHH", 2, 1, 8000, 8000, 1, 4), b"\x00" * 16))   # ADPCM: refused loudly
