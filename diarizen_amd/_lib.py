@@ -91,6 +91,7 @@ class DznGemmDesc(C.Structure):
         ("a_split3", C.c_int32), ("a_plane", C.c_int64),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
         ("W2h", C.c_void_p), ("col_scale", C.c_void_p), ("a_amax", C.c_void_p), ("c_amax", C.c_void_p),
+        ("amax_unit", C.c_int32),
     ]
 
 

@@ -44,12 +44,15 @@ __device__ __forceinline__ float wave_max(float v) {
 // the atomic max is order independent (deterministic).  The tracker is read first (device-scope load: the value
 // only grows within a forward, so a stale read can only cost a redundant atomic) — without that check millions of
 // same-address atomics serialise (measured: 7 ms for a LayerNorm over 3.3 M rows).
-__device__ __forceinline__ void track_amax(float* tracker, float wave_partial) {
-  const float m = wave_max(wave_partial);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) {
+__device__ __forceinline__ void track_amax_lane(float* tracker, float m) {
+  if (m > 0.f) {
     const unsigned cur = __hip_atomic_load(reinterpret_cast<unsigned int*>(tracker), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (__float_as_uint(m) > cur) atomicMax(reinterpret_cast<unsigned int*>(tracker), __float_as_uint(m));
   }
+}
+__device__ __forceinline__ void track_amax(float* tracker, float wave_partial) {
+  const float m = wave_max(wave_partial);
+  if ((threadIdx.x & 63) == 0) track_amax_lane(tracker, m);
 }
 
 // ---- activations (match torch CPU fp32 semantics) ----
@@ -109,7 +112,7 @@ int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const f
                      hipStream_t s);
 int launch_layernorm_t(const void* x, int x_bf16, int64_t ldx, void* y, int y_bf16, int64_t ldy,
                        const float* g, const float* b, const float* post, int64_t rows, int C, int Cpad,
-                       float eps, int gelu, hipStream_t s, float* amax = nullptr);
+                       float eps, int gelu, hipStream_t s, float* amax = nullptr, int64_t amax_unit = 0);
 int launch_cast_bf16(const float* x, void* y, int64_t n, hipStream_t s);
 int launch_row_stats(const float* x, int64_t ldx, int64_t rows, int C, float eps, float* stats, hipStream_t s);
 int launch_gate_stats(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* Wg,

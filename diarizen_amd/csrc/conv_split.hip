@@ -192,9 +192,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
         out_amax = fmaxf(fmaxf(out_amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
     }
+    if (a.amax) {     // per-image |max| tracker of `out` (the scale unit of the consumer's fp16 split is the window)
+      track_amax(a.amax + b, out_amax);
+      out_amax = 0.f;
+    }
     __syncthreads();  // the strip is free for the next tile's staging
   }
-  if (a.amax) track_amax(a.amax, out_amax);
 }
 
 }  // namespace

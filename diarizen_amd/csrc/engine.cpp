@@ -154,8 +154,9 @@ struct dzn_handle {
         *gate = nullptr, *mid = nullptr;
   float *hz = nullptr, *ht = nullptr, *hmid = nullptr, *hv = nullptr;
   float* rstat = nullptr;   // [max_batch * maxL][2] (mean, rstd) of the LayerNorm folded into the next contraction
-  // |max| trackers of activation tensors (DZN_PREC_F32_H2): written by the producer's epilogue / LayerNorm,
-  // read by the consuming contraction to scale its fp16 split (gemm_split.hip).  Zeroed at every forward.
+  // |max| trackers of activation tensors (DZN_PREC_F32_H2), ONE PER WINDOW of the batch (slot * max_batch + b): written
+  // by the producer's epilogue / LayerNorm, read by the consuming contraction to scale its fp16 split
+  // (gemm_split.hip).  Per window, so a window's result is independent of the batch it runs in.  Zeroed per forward.
   enum { AM_CONVA, AM_CONVB, AM_X, AM_XPAD, AM_Y, AM_MID, AM_QKV, AM_HZ, AM_HMID, AM_IMG0, AM_COUNT = AM_IMG0 + 12 };
   float conv0_bound = 0.f;  // sqrt(C0) max|gamma| + max|beta| >= |GELU(LN(conv0))|: static |max| of conv0's output
   float* amax = nullptr;
@@ -640,7 +641,7 @@ void finalize_seg(H* h) {
   h->hmid = dalloc<float>(h, ML * std::max(Fh, 3 * A));
   h->hv = dalloc<float>(h, ML * A);
   h->rstat = dalloc<float>(h, ML * 2);
-  h->amax = dalloc<float>(h, dzn_handle::AM_COUNT);
+  h->amax = dalloc<float>(h, (int64_t)dzn_handle::AM_COUNT * c.max_batch);
 }
 
 // ------------------------------------------------------------------ embedding: finalize
@@ -879,8 +880,9 @@ dzn_gemm_desc gd(H* h, const float* A, const Lin& l, float* C, int64_t M, int64_
 
 // LayerNorm with typed input / output (fp32, or bf16 in the bf16 engine mode)
 void ln_t(const float* x, bool x16, int64_t ldx, float* y, bool y16, int64_t ldy, const LNp& p, int64_t rows,
-          int Cpad, int gelu, hipStream_t st, const float* post = nullptr, float* amax = nullptr) {
-  chk(launch_layernorm_t(x, x16, ldx, y, y16, ldy, p.g, p.b, post, rows, p.C, Cpad, 1e-5f, gelu, st, amax),
+          int Cpad, int gelu, hipStream_t st, const float* post = nullptr, float* amax = nullptr,
+          int64_t amax_unit = 0) {
+  chk(launch_layernorm_t(x, x16, ldx, y, y16, ldy, p.g, p.b, post, rows, p.C, Cpad, 1e-5f, gelu, st, amax, amax_unit),
       "layernorm");
 }
 
@@ -934,20 +936,24 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   auto gemm = [&](dzn_gemm_desc& d, bool a16, bool c16, const char* what) {
     d.a_bf16 = a16;
     d.c_bf16 = c16;
+    // |max| trackers are per window: rows of a [B*L, .] tensor belong to window m / L; z-batched launches
+    // (conv stack: z = window) use the z index
+    if (d.nz == 1 || (d.a_rowoff && d.a_rowoff == h->pos_rowoff)) d.amax_unit = L;
     chk(launch_gemm(d, st), what);
   };
   // DZN_PREC_F32_H2: |max| trackers (see dzn_handle::amax).  am(slot) is NULL in the other modes, which makes
   // every contraction take its bf16 three-term / fp32 kernel.
   const bool h2 = c.precision == DZN_PREC_F32_H2;
+  const int64_t MB = c.max_batch;
   if (h2) {
-    HIPCHK(hipMemsetAsync(h->amax, 0, dzn_handle::AM_IMG0 * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(h->amax, 0, dzn_handle::AM_IMG0 * MB * sizeof(float), st));
     if (lnx && h->conv0_bound > 0.f) {   // conv0 (LN + GELU) writes bufA: static bound instead of a tracker
       uint32_t bits;
       memcpy(&bits, &h->conv0_bound, 4);
-      HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->amax + dzn_handle::AM_CONVA), (int)bits, 1, st));
+      HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->amax + dzn_handle::AM_CONVA * MB), (int)bits, B, st));
     }
   }
-  auto am = [&](int slot) -> float* { return h2 ? h->amax + slot : nullptr; };
+  auto am = [&](int slot) -> float* { return h2 ? h->amax + slot * MB : nullptr; };
   auto conv_slot = [&](const float* buf) { return buf == h->bufA ? dzn_handle::AM_CONVA : dzn_handle::AM_CONVB; };
 
   // ---- conv feature extractor ----
@@ -986,7 +992,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     gemm(d, lp, lp && !lnx, "conv gemm");
     if (lnx)  // channel LayerNorm + GELU (+ dummy_weight after the last conv, components.py:208)
       ln_t(dst, false, h->Cp[i], nxt, lp, h->Cp[i], h->conv_ln[i], (int64_t)B * T[i], h->Cp[i], 1, st,
-           i == last ? h->dummy_w : nullptr, am(conv_slot(nxt)));
+           i == last ? h->dummy_w : nullptr, am(conv_slot(nxt)), T[i]);
     std::swap(cur, nxt);
   }
   if (!lnx || c.n_conv == 1)
@@ -1069,7 +1075,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     d.c_amax = am(dzn_handle::AM_X);
     gemm(d, pc16, false, "pos conv");
   }
-  if (!c.layer_norm_first) ln_t(h->x, false, D, h->x, false, D, h->enc_ln, ML, D, 0, st, nullptr, am(dzn_handle::AM_X));
+  if (!c.layer_norm_first) ln_t(h->x, false, D, h->x, false, D, h->enc_ln, ML, D, 0, st, nullptr, am(dzn_handle::AM_X), L);
   chk(launch_ws_accum(h->x, h->ws, h->wsum_w[0], 1, ML * D, st), "ws_accum");
   tap(h, "rep0", h->x, ML, D, D, st);
 
@@ -1088,7 +1094,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
                               st),
             "gate_stats");
       } else if (c.layer_norm_first) {
-        ln_t(h->x, false, D, h->y, lp, D, Ly.ln1, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y));
+        ln_t(h->x, false, D, h->y, lp, D, Ly.ln1, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y), L);
         yin = h->y;
         y16 = lp;
       } else if (lp) {
@@ -1124,7 +1130,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
           chk(launch_row_stats(h->x, D, ML, D, 1e-5f, h->rstat, st), "row_stats");
           fin = h->x;
         } else {
-          ln_t(h->x, false, D, h->y, lp, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y));
+          ln_t(h->x, false, D, h->y, lp, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y), L);
         }
         dzn_gemm_desc f1 = gd(h, fin, Ly.f1, h->mid, ML, D, Ly.Fp);
         if (fold) folded(f1, Ly.f1);
@@ -1144,7 +1150,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
         chk(launch_ws_accum(h->x, h->ws, wl, 0, ML * D, st), "ws_accum");
       }
     } else {
-      ln_t(h->x, false, D, h->x, false, D, Ly.ln1, ML, D, 0, st, nullptr, am(dzn_handle::AM_X));
+      ln_t(h->x, false, D, h->x, false, D, Ly.ln1, ML, D, 0, st, nullptr, am(dzn_handle::AM_X), L);
       if (Ly.ffn) {
         const float* fin = h->x;
         if (lp) {
@@ -1162,7 +1168,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
         f2.c_amax = am(dzn_handle::AM_X);
         gemm(f2, lp, false, "ffn2");
       }
-      ln_t(h->x, false, D, h->x, false, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_X));
+      ln_t(h->x, false, D, h->x, false, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_X), L);
       chk(launch_ws_accum(h->x, h->ws, wl, 0, ML * D, st), "ws_accum");
     }
     if (h->debug) {
@@ -1181,7 +1187,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     }
     dzn_gemm_desc d = gd(h, pin, h->proj, h->hz, ML, D, A);
     gemm(d, lp, false, "proj");   // (ws has no tracker: bf16 split)
-    ln_t(h->hz, false, A, h->hz, false, A, h->lnorm, ML, A, 0, st, nullptr, am(dzn_handle::AM_HZ));
+    ln_t(h->hz, false, A, h->hz, false, A, h->lnorm, ML, A, 0, st, nullptr, am(dzn_handle::AM_HZ), L);
   }
   tap(h, "head_in", h->hz, ML, A, A, st);
   for (int i = 0; i < c.conf_layers; ++i) {
@@ -1252,7 +1258,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       gemm(p2, lp, false, "conf pw2");
     }
     half_ffn(Cl.ffn2_ln, Cl.ffn2_w1, Cl.ffn2_w2);
-    ln_t(h->hz, false, A, h->hz, false, A, Cl.out_ln, ML, A, 0, st, nullptr, am(dzn_handle::AM_HZ));
+    ln_t(h->hz, false, A, h->hz, false, A, Cl.out_ln, ML, A, 0, st, nullptr, am(dzn_handle::AM_HZ), L);
     if (h->debug) {
       const std::string nm = "conf" + std::to_string(i);
       tap(h, nm.c_str(), h->hz, ML, A, A, st);
@@ -1297,12 +1303,13 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
   // DZN_PREC_F32_H2: one |max| tracker per image buffer (sbuf[s][k] -> slot AM_IMG0 + 3 s + k), running over the
   // forward; the stem's image has no writer with a tracker, but its only consumer is the dedicated bf16 stage-1 kernel
   const bool h2 = c.precision == DZN_PREC_F32_H2;
-  if (h2) HIPCHK(hipMemsetAsync(h->amax + dzn_handle::AM_IMG0, 0, 12 * sizeof(float), st));
+  const int64_t MB = c.max_batch;
+  if (h2) HIPCHK(hipMemsetAsync(h->amax + dzn_handle::AM_IMG0 * MB, 0, 12 * MB * sizeof(float), st));
   auto img_am = [&](const float* buf) -> float* {
     if (!h2 || !buf) return nullptr;
     for (int s2 = 0; s2 < 4; ++s2)
       for (int k = 0; k < 3; ++k)
-        if (buf == h->sbuf[s2][k]) return h->amax + dzn_handle::AM_IMG0 + 3 * s2 + k;
+        if (buf == h->sbuf[s2][k]) return h->amax + (dzn_handle::AM_IMG0 + 3 * s2 + k) * MB;
     return nullptr;
   };
   for (int s = 0; s < 4; ++s) {

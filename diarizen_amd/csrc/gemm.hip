@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dzn_gemm_desc d) {
     __syncthreads();
   }
 
-  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz);
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const dzn_gemm_desc d) {
     mma(a1, b1);
     __builtin_amdgcn_sched_barrier(0);
   }
-  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz);
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool LOWP>

@@ -9,18 +9,22 @@ namespace {
 
 template <int BM, int BN, int TM, int TN, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
-                                              int wm, int wn, int lr, int lq, int64_t cz, int64_t bz,
-                                              float acc_scale = 1.f, const float* col_scale = nullptr) {
+                                              int wm, int wn, int lr, int lq, int64_t cz, int64_t bz, int z0 = 0,
+                                              const float* row_inv = nullptr, const float* col_scale = nullptr) {
   // ---- epilogue: lane (lr, lq) of block (i, j) holds row m = ..+lr, columns n0..n0+3 ----
   const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
   const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0;
-  float amax = 0.f;   // running |max| of what this lane stores (d.c_amax: the scale of the fp16 split of the consumer)
+  // running |max| of what this lane stores, per unit (d.c_amax[unit]: the scale of the consumer's fp16 split);
+  // unit = m / amax_unit (rows of one window) or the z batch index
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = tm * BM + wm * TM + i * 16 + lr;
     if (m >= d.M) continue;
     const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
     // LayerNorm folded into the weights: finish it with the row statistics (dzn_ops.h)
+    const float acc_scale = row_inv ? row_inv[i] : 1.f;
+    float amax_row = 0.f;
     float ln_mu = 0.f, ln_rs = 1.f;
     if (d.ln_stats) {
       const float2 st = *reinterpret_cast<const float2*>(d.ln_stats + 2 * (int64_t)m);
@@ -57,7 +61,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         *reinterpret_cast<float4*>(d.C + crow + n0) = make_float4(v[0], v[1], v[2], v[3]);
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        amax_row = fmaxf(fmaxf(amax_row, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         if (d.WS) {
           float4* w = reinterpret_cast<float4*>(d.WS + (int64_t)m * d.ldws + n0);
           float4 a = d.ws_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *w;
@@ -77,7 +81,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
           if (d.R) x += d.R[crow + n];
           if (d.post_relu) x = fmaxf(x, 0.f);
           d.C[crow + n] = x;
-          amax = fmaxf(amax, fabsf(x));
+          amax_row = fmaxf(amax_row, fabsf(x));
           if (d.WS) {
             float* w = d.WS + (int64_t)m * d.ldws + n;
             *w = d.ws_init ? d.ws_w * x : (*w + d.ws_w * x);
@@ -85,8 +89,18 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
         }
       }
     }
+    if (d.c_amax) {
+      if (d.amax_unit > 0) {
+        // the row lives in lanes lr, lr + 16, lr + 32, lr + 48 (all of them took this branch: m depends on lr only)
+        float r = fmaxf(amax_row, __shfl_xor(amax_row, 16, 64));
+        r = fmaxf(r, __shfl_xor(r, 32, 64));
+        if (lq == 0) track_amax_lane(d.c_amax + m / d.amax_unit, r);
+      } else {
+        amax = fmaxf(amax, amax_row);
+      }
+    }
   }
-  if (d.c_amax) track_amax(d.c_amax, amax);
+  if (d.c_amax && d.amax_unit <= 0) track_amax(d.c_amax + z0, amax);
 }
 
 }  // namespace

@@ -64,8 +64,8 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 //     rows is multiplied, then [wait tile kt+1, barrier, refill the stage of tile kt], then the
 //     fragments of tile kt+1 are read into the second register set while the second half of
 //     tile kt is multiplied — the matrix pipe has work queued across the barrier.
-template <int BM, int BN, int WGM, int WGN, int S, int NP>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_gemm_desc d) {
+template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1>
+__global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const dzn_gemm_desc d) {
   constexpr int NW = WGM * WGN;           // wavefronts per workgroup
   constexpr int BK = 32;
   constexpr int TM = BM / WGM, TN = BN / WGN;
@@ -99,8 +99,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
   const float* __restrict__ A = d.A + z0 * d.a_z0 + z1 * d.a_z1;
   const u16* __restrict__ W3 =
       reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + NP * (z0 * d.w_z0 + z1 * d.w_z1);
-  float a_scale = 1.f, acc_scale = 1.f;
-  if constexpr (NP == 2) h2_scale(*d.a_amax, a_scale, acc_scale);
+  // NP = 2: exact power-of-two scale of every A row from the |max| tracker of the UNIT (window / image) the row
+  // belongs to — unit = m / amax_unit, or the z batch index when amax_unit == 0 — so that a window's result does
+  // not depend on what else is in the batch
+  float a_scale[MI], row_inv[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a_scale[i] = row_inv[i] = 1.f;
+  if constexpr (NP == 2) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      int m = tm * BM + wm * TM + i * 16 + (lane & 15);
+      m = m < d.M ? m : d.M - 1;
+      h2_scale(d.a_amax[d.amax_unit > 0 ? m / d.amax_unit : z0], a_scale[i], row_inv[i]);
+    }
+  }
   const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
   const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
 
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][PW[t]], af[PA[t]], acc[i][j]);
     }
   };
-  auto split = [&](const f32x4 (&a)[2], u32x4 (&af)[NP]) {
+  auto split = [&](const f32x4 (&a)[2], u32x4 (&af)[NP], float sc) {
     if constexpr (NP == 3) {
       bf16x8 h_, m_, l_;
       split8(a[0], a[1], h_, m_, l_);
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
       af[1] = __builtin_bit_cast(u32x4, m_);
       af[2] = __builtin_bit_cast(u32x4, l_);
     } else {
-      split8_h2(a[0], a[1], a_scale, af[0], af[1]);
+      split8_h2(a[0], a[1], sc, af[0], af[1]);
     }
   };
 
@@ -242,12 +254,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
 #pragma unroll
     for (int i = 0; i < MH; ++i) {
       u32x4 af[NP];
-      split(ar[i], af);
+      split(ar[i], af, a_scale[i]);
       mma(i, wc, af);
     }
     u32x4 af2[MI - MH][NP];
 #pragma unroll
-    for (int i = MH; i < MI; ++i) split(ar[i], af2[i - MH]);
+    for (int i = MH; i < MI; ++i) split(ar[i], af2[i - MH], a_scale[i]);
     const int nstage = stage + 1 == S ? 0 : stage + 1;
     __builtin_amdgcn_sched_barrier(0);  // keep the second half of the MFMAs BEHIND the barrier block
     if (more) {
@@ -268,14 +280,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_kernel(const dzn_ge
     step(kt, wfa, wfb);
     if (kt + 1 < nk) step(kt + 1, wfb, wfa);
   }
-  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, acc_scale, NP == 2 ? d.col_scale : nullptr);
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, NP == 2 ? d.col_scale : nullptr);
 }
 
-template <int BM, int BN, int WGM, int WGN, int S, int NP>
+template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1>
 int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
   const size_t lds = (size_t)S * (BM * 128 + NP * BN * 64);
-  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, NP>;
+  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, NP, OCC>;
   static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
   if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -62,10 +62,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
   const u16* __restrict__ A3 = reinterpret_cast<const u16*>(d.A) + z0 * d.a_z0 + z1 * d.a_z1;
   const u16* __restrict__ W3 =
       reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + NP * (z0 * d.w_z0 + z1 * d.w_z1);
-  float acc_scale = 1.f;
+  float row_inv[MI];     // NP = 2: inverse of the per-unit scale the producer applied (pad_rows_split2_kernel)
+#pragma unroll
+  for (int i = 0; i < MI; ++i) row_inv[i] = 1.f;
   if constexpr (NP == 2) {
-    float unused;
-    h2_scale(*d.a_amax, unused, acc_scale);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      int m = tm * BM + wm * TM + i * 16 + (lane & 15);
+      m = m < d.M ? m : d.M - 1;
+      float unused;
+      h2_scale(d.a_amax[d.amax_unit > 0 ? m / d.amax_unit : z0], unused, row_inv[i]);
+    }
   }
   const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
   const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
     step(kt, wfa, wfb);
     if (kt + 1 < nk) step(kt + 1, wfb, wfa);
   }
-  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, acc_scale,
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv,
                                         NP == 2 ? d.col_scale + z0 * d.b_z0 + z1 * d.b_z1 : nullptr);
 }
 
@@ -264,10 +271,10 @@ __global__ __launch_bounds__(256) void pad_rows_split2_kernel(const float* __res
                                                               int64_t plane_stride, int L, int Lp, int pad, int D,
                                                               const float* __restrict__ amax, float* __restrict__ snapshot) {
   const int b = blockIdx.y;
-  const float am = *amax;
+  const float am = amax[b];              // per-window tracker
   float sc, inv;
   h2_scale(am, sc, inv);
-  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) *snapshot = am;
+  if (blockIdx.x == 0 && threadIdx.x == 0) snapshot[b] = am;
   const int chunks = D / 8;
   const int64_t n = (int64_t)Lp * chunks;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {

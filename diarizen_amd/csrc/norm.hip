@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
                                                         const float* __restrict__ beta,
                                                         const float* __restrict__ post, int64_t rows,
                                                         int C, int Cpad, float eps, int gelu,
-                                                        float* __restrict__ amax_out) {
+                                                        float* __restrict__ amax_out, int64_t amax_unit) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= rows) return;
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
       st_act(yp, idx, 0.f);
     }
   }
-  if (amax_out) track_amax(amax_out, amax);   // |max| of the output tensor: scale of the consumer's fp16 split
+  // |max| of the output rows of this unit (window): scale of the consumer's fp16 split
+  if (amax_out) track_amax(amax_out + (amax_unit > 0 ? row / amax_unit : 0), amax);
 }
 
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ amax_out) {
@@ -142,12 +143,12 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(const float* __restric
 template <typename TI, typename TO>
 int launch_ln_typed(const TI* x, int64_t ldx, TO* y, int64_t ldy, const float* g, const float* b,
                     const float* post, int64_t rows, int C, int Cpad, float eps, int gelu, hipStream_t s,
-                    float* amax) {
+                    float* amax, int64_t amax_unit) {
   const unsigned grid = (unsigned)cdiv64(rows, 4);
   const int need = (Cpad > C ? Cpad : C);
 #define DZN_LN(MAXI)                                                                               \
   hipLaunchKernelGGL((layernorm_kernel<MAXI, TI, TO>), dim3(grid), dim3(256), 0, s, x, ldx, y, ldy, g, \
-                     b, post, rows, C, Cpad, eps, gelu, amax)
+                     b, post, rows, C, Cpad, eps, gelu, amax, amax_unit)
   if (need <= 256) DZN_LN(4);
   else if (need <= 512) DZN_LN(8);
   else if (need <= 1024) DZN_LN(16);
@@ -160,7 +161,7 @@ int launch_ln_typed(const TI* x, int64_t ldx, TO* y, int64_t ldy, const float* g
 
 int launch_layernorm_t(const void* x, int x_bf16, int64_t ldx, void* y, int y_bf16, int64_t ldy,
                        const float* g, const float* b, const float* post, int64_t rows, int C, int Cpad,
-                       float eps, int gelu, hipStream_t s, float* amax) {
+                       float eps, int gelu, hipStream_t s, float* amax, int64_t amax_unit) {
   ProfScope prof_scope_(s, "layernorm", 0.0, (double)rows * C * 8.0);
   if (rows <= 0) return DZN_OK;
   if (C <= 0 || C > 2048 || Cpad > 2048) return DZN_E_INVALID;
@@ -168,10 +169,10 @@ int launch_layernorm_t(const void* x, int x_bf16, int64_t ldx, void* y, int y_bf
   const u16* xh = static_cast<const u16*>(x);
   float* yf = static_cast<float*>(y);
   u16* yh = static_cast<u16*>(y);
-  if (!x_bf16 && !y_bf16) return launch_ln_typed(xf, ldx, yf, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax);
-  if (!x_bf16 && y_bf16) return launch_ln_typed(xf, ldx, yh, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax);
-  if (x_bf16 && !y_bf16) return launch_ln_typed(xh, ldx, yf, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax);
-  return launch_ln_typed(xh, ldx, yh, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax);
+  if (!x_bf16 && !y_bf16) return launch_ln_typed(xf, ldx, yf, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax, amax_unit);
+  if (!x_bf16 && y_bf16) return launch_ln_typed(xf, ldx, yh, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax, amax_unit);
+  if (x_bf16 && !y_bf16) return launch_ln_typed(xh, ldx, yf, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax, amax_unit);
+  return launch_ln_typed(xh, ldx, yh, ldy, g, b, post, rows, C, Cpad, eps, gelu, s, amax, amax_unit);
 }
 
 int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* g,

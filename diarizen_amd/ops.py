@@ -25,7 +25,7 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
          ws_init=False, a_rowoff=None, c_rowoff=None, lda=None, kc=0, ldk=0, ldw=None, ldc=None,
          ldws=0, act=0, alpha=1.0, post_relu=False, nz=1, zdiv=1, zs=None, precision=0,
          W16=None, W3=None, a_planes=None, ln_stats=None, ln_colsum=None, W2h=None, col_scale=None,
-         a_amax=None, c_amax=None):
+         a_amax=None, c_amax=None, amax_unit=None):
     """C = epilogue(A @ W^T); see dzn_gemm_desc.  A: [M, K] (or raw buffer with lda / rowoff),
     W: [N, K] fp32 (and optionally W16 bf16)."""
     lib = _lib.load()
@@ -72,9 +72,11 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
     d.ln_stats, d.ln_colsum = _p(ln_stats), _p(ln_colsum)
     if precision == _lib.DZN_PREC_F32_H2 and W2h is None and K % 32 == 0 and ldw == K and W.is_contiguous():
         W2h, col_scale = split_weights_h2(W.reshape(-1, K))
-        if a_amax is None:
-            a_amax = amax(A)
+        if a_amax is None:      # one |max| for the whole tensor, replicated for every z scale unit
+            a_amax = amax(A).repeat(max(1, nz // max(zdiv, 1)))
     d.W2h, d.col_scale, d.a_amax, d.c_amax = _p(W2h), _p(col_scale), _p(a_amax), _p(c_amax)
+    # one scale unit for the whole tensor unless told otherwise (engines use one unit per window)
+    d.amax_unit = int(amax_unit) if amax_unit is not None else (max(M, 1) if nz == 1 else 0)
     check(lib.dzn_op_gemm(C.byref(d), _stream()), what="dzn_op_gemm")
     return C_out
 

@@ -87,12 +87,15 @@ typedef struct dzn_gemm_desc {
   const float* ln_colsum;
   /* DZN_PREC_F32_H2 ("f32h"): two-term fp16 split, three products (csrc/gemm_split.hip, NP = 2).
    * W2h = planes from dzn_op_split_weights_h2 ([rows][K/32][2][32] fp16 of w * 2^e_row), col_scale[n] = 2^-e_row,
-   * a_amax = device scalar >= max |A| (tracked by the producer of A through c_amax, or dzn_op_amax).  Any of them
+   * a_amax = device array of per-unit bounds >= max |A| (tracked by the producer of A through c_amax, or dzn_op_amax).  Any of them
    * NULL -> the bf16 three-term kernel (W3).  c_amax (any mode): atomically max'ed with |C| as stored. */
   const void* W2h;
   const float* col_scale;
   const float* a_amax;
   float* c_amax;
+  /* a_amax / c_amax are ARRAYS with one |max| per scale unit, so that a window's result does not depend on the rest
+   * of the batch: unit of row m = m / amax_unit when amax_unit > 0 (rows of one window), else the z0 batch index. */
+  int32_t amax_unit;
 } dzn_gemm_desc;
 
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);

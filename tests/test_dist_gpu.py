@@ -16,7 +16,12 @@ def _run(nproc, backend, port):
     env = dict(os.environ, DZN_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER]
-    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    log = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    os.makedirs(log, exist_ok=True)
+    with open(os.path.join(log, f"dist_{backend}_{nproc}.log"), "w") as f:
+        f.write(r.stdout[-6000:] + "\n---- stderr ----\n" + r.stderr[-12000:])
+    return r
 
 
 def test_window_shard_gather_rccl_world1(built_lib, gpu):

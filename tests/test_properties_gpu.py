@@ -17,7 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["f32s", "f32"])
+@pytest.fixture(scope="module", params=["f32h", "f32s", "f32"])
 def engine(built_lib, gpu, request):
     from diarizen_amd.configs import RESNET34, get_seg_config
     from diarizen_amd.engine import Engine
@@ -185,7 +185,8 @@ def test_device_postprocess_equals_numpy(built_lib, gpu):
     r = np.random.default_rng(5)
     C, L = 1500, 399
     seg = (r.random((C, L, 4)) < 0.3).astype(np.uint8)
-    seg[r.random((C, 4)) < 0.3] = 0                                  # inactive speakers
+    seg = seg * (r.random((C, 1, 4)) >= 0.3)                         # inactive speakers
+    seg = np.ascontiguousarray(seg.astype(np.uint8))
     hard = r.integers(-2, 9, size=(C, 4)).astype(np.int8)            # -2 / -1 never contribute; cluster 7 may be empty
     hard[hard == 7] = 3
     cases.append((seg, hard, 8.0))
