@@ -16,7 +16,13 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
   const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0;
   // running |max| of what this lane stores, per unit (d.c_amax[unit]: the scale of the consumer's fp16 split);
   // unit = m / amax_unit (rows of one window) or the z batch index
-  float amax = 0.f;
+  float amax = 0.f, amax_hi = 0.f;
+  // a wavefront's TM consecutive rows span at most two units when amax_unit >= TM: two running maxima (rows below /
+  // at or above the first unit boundary inside the wave tile) and one tracker update each, instead of one per row
+  const int wrow0 = tm * BM + wm * TM;
+  const bool two_unit = d.c_amax && d.amax_unit >= TM;
+  const int unit0 = two_unit ? (wrow0 < d.M ? wrow0 : d.M - 1) / d.amax_unit : 0;
+  const int boundary = two_unit ? (unit0 + 1) * d.amax_unit : 0;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = tm * BM + wm * TM + i * 16 + lr;
@@ -90,7 +96,10 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
       }
     }
     if (d.c_amax) {
-      if (d.amax_unit > 0) {
+      if (two_unit) {
+        if (m < boundary) amax = fmaxf(amax, amax_row);
+        else amax_hi = fmaxf(amax_hi, amax_row);
+      } else if (d.amax_unit > 0) {
         // the row lives in lanes lr, lr + 16, lr + 32, lr + 48 (all of them took this branch: m depends on lr only)
         float r = fmaxf(amax_row, __shfl_xor(amax_row, 16, 64));
         r = fmaxf(r, __shfl_xor(r, 32, 64));
@@ -100,7 +109,12 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
       }
     }
   }
-  if (d.c_amax && d.amax_unit <= 0) track_amax(d.c_amax + z0, amax);
+  if (two_unit) {
+    track_amax(d.c_amax + unit0, amax);
+    if (wrow0 + TM > boundary && boundary < d.M) track_amax(d.c_amax + unit0 + 1, amax_hi);   // wave-uniform
+  } else if (d.c_amax && d.amax_unit <= 0) {
+    track_amax(d.c_amax + z0, amax);
+  }
 }
 
 }  // namespace

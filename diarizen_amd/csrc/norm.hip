@@ -19,47 +19,56 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
                                                         const float* __restrict__ beta,
                                                         const float* __restrict__ post, int64_t rows,
                                                         int C, int Cpad, float eps, int gelu,
-                                                        float* __restrict__ amax_out, int64_t amax_unit) {
+                                                        float* __restrict__ amax_out, int64_t amax_unit, int rows_per_wave) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-  if (row >= rows) return;
+  // every wavefront owns a contiguous run of rows (rows_per_wave = 1 without a tracker): the |max| tracker of a
+  // unit (window) is then touched once per run instead of once per row
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
   float amax = 0.f;
-  const TI* xp = x + row * ldx;
-  float v[MAXI];
-  float sum = 0.f;
+  int64_t unit = amax_out && amax_unit > 0 && r0 < rows ? r0 / amax_unit : 0;
+  for (int64_t row = r0; row < r0 + rows_per_wave && row < rows; ++row) {
+    const TI* xp = x + row * ldx;
+    float v[MAXI];
+    float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i) {
-    const int idx = lane + 64 * i;
-    v[i] = idx < C ? ld_act(xp, idx) : 0.f;
-    sum += v[i];
-  }
-  const float mean = wave_sum(sum) / (float)C;
-  float sq = 0.f;
+    for (int i = 0; i < MAXI; ++i) {
+      const int idx = lane + 64 * i;
+      v[i] = idx < C ? ld_act(xp, idx) : 0.f;
+      sum += v[i];
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i) {
-    const int idx = lane + 64 * i;
-    const float dv = idx < C ? v[i] - mean : 0.f;
-    sq += dv * dv;
-  }
-  const float var = wave_sum(sq) / (float)C;
-  const float rstd = 1.0f / sqrtf(var + eps);
-  TO* yp = y + row * ldy;
+    for (int i = 0; i < MAXI; ++i) {
+      const int idx = lane + 64 * i;
+      const float dv = idx < C ? v[i] - mean : 0.f;
+      sq += dv * dv;
+    }
+    const float var = wave_sum(sq) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (amax_out && amax_unit > 0 && row / amax_unit != unit) {   // wave-uniform: flush the finished unit
+      track_amax(amax_out + unit, amax);
+      amax = 0.f;
+      unit = row / amax_unit;
+    }
+    TO* yp = y + row * ldy;
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i) {
-    const int idx = lane + 64 * i;
-    if (idx < C) {
-      float o = (v[i] - mean) * rstd;
-      if (gamma) o = o * gamma[idx] + beta[idx];
-      if (gelu) o = gelu_erf(o);
-      if (post) o *= post[idx];
-      st_act(yp, idx, o);
-      amax = fmaxf(amax, fabsf(o));
-    } else if (idx < Cpad) {
-      st_act(yp, idx, 0.f);
+    for (int i = 0; i < MAXI; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < C) {
+        float o = (v[i] - mean) * rstd;
+        if (gamma) o = o * gamma[idx] + beta[idx];
+        if (gelu) o = gelu_erf(o);
+        if (post) o *= post[idx];
+        st_act(yp, idx, o);
+        amax = fmaxf(amax, fabsf(o));
+      } else if (idx < Cpad) {
+        st_act(yp, idx, 0.f);
+      }
     }
   }
   // |max| of the output rows of this unit (window): scale of the consumer's fp16 split
-  if (amax_out) track_amax(amax_out + (amax_unit > 0 ? row / amax_unit : 0), amax);
+  if (amax_out && r0 < rows) track_amax(amax_out + unit, amax);
 }
 
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ amax_out) {
@@ -144,11 +153,18 @@ template <typename TI, typename TO>
 int launch_ln_typed(const TI* x, int64_t ldx, TO* y, int64_t ldy, const float* g, const float* b,
                     const float* post, int64_t rows, int C, int Cpad, float eps, int gelu, hipStream_t s,
                     float* amax, int64_t amax_unit) {
-  const unsigned grid = (unsigned)cdiv64(rows, 4);
+  // with a tracker: contiguous runs of rows per wavefront, >= 8 waves per SIMD worth of wavefronts in flight
+  int rpw = 1;
+  if (amax) {
+    const int64_t waves = 256 * 4 * 8;
+    rpw = (int)(rows / waves);
+    rpw = rpw < 1 ? 1 : (rpw > 64 ? 64 : rpw);
+  }
+  const unsigned grid = (unsigned)cdiv64(cdiv64(rows, rpw), 4);
   const int need = (Cpad > C ? Cpad : C);
 #define DZN_LN(MAXI)                                                                               \
   hipLaunchKernelGGL((layernorm_kernel<MAXI, TI, TO>), dim3(grid), dim3(256), 0, s, x, ldx, y, ldy, g, \
-                     b, post, rows, C, Cpad, eps, gelu, amax, amax_unit)
+                     b, post, rows, C, Cpad, eps, gelu, amax, amax_unit, rpw)
   if (need <= 256) DZN_LN(4);
   else if (need <= 512) DZN_LN(8);
   else if (need <= 1024) DZN_LN(16);
