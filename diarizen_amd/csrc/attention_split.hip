@@ -21,16 +21,22 @@ namespace {
 constexpr int ATT_PLANE = 64 * 128;  // one bf16 plane of a 64 x 64 tile
 constexpr int ATT_OCC = 3;           // wavefronts per SIMD the register budget is held to (LDS allows 3 workgroups/CU)
 
-template <bool BIAS>
+// NP = 3: bf16 three-term split, six products.  NP = 2 (DZN_PREC_F32_H2): fp16 two-term split, three products:
+//   q, k, v are scaled by the exact power of two s from the window's |max| tracker of the qkv tensor (amax[b]);
+//   the scores come out of the MFMA times s^2 and are multiplied back (exactly) before bias / softmax;
+//   the probabilities are produced as p' = 2^14 p (one exp2 with +14 in the exponent, p' <= 2^14 fits fp16) and the
+//   final normalisation divides by s * sum p', so neither scale costs an instruction in the inner loops.
+template <bool BIAS, int NP>
 __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                          const float* __restrict__ gate,
                                                          const float* __restrict__ table,
                                                          const int32_t* __restrict__ head_idx, int B, int L,
-                                                         int h, int Htot, int ldqkv, int ldo, float scale) {
+                                                         int h, int Htot, int ldqkv, int ldo, float scale,
+                                                         const float* __restrict__ amax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sK = smem;                    // 3 planes [64 keys][64 d]
-  unsigned char* sV = smem + 3 * ATT_PLANE;    // 3 planes [64 d][64 keys in MFMA order]
-  float* sT = reinterpret_cast<float*>(smem + 6 * ATT_PLANE);  // [2L-1] bias table of this head
+  unsigned char* sK = smem;                     // NP planes [64 keys][64 d]
+  unsigned char* sV = smem + NP * ATT_PLANE;    // NP planes [64 d][64 keys in MFMA order]
+  float* sT = reinterpret_cast<float*>(smem + 2 * NP * ATT_PLANE);  // [2L-1] bias table of this head
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
@@ -49,11 +55,15 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
   // scores are kept in the log2 domain (q and the bias gate carry a factor log2 e), so the softmax
   // exponentials are bare v_exp_f32: exp(s - m) == exp2(s log2e - m log2e)
   constexpr float LOG2E = 1.4426950408889634f;
+  float op_scale = 1.f, op_inv = 1.f;           // NP = 2: power-of-two scale of q / k / v and its inverse
+  if constexpr (NP == 2) h2_scale(amax[blockIdx.z], op_scale, op_inv);
   const float qs = scale * LOG2E;
+  const float s_inv = op_inv * op_inv;          // scores leave the MFMA scaled by op_scale^2
+  constexpr float PSHIFT = NP == 2 ? 14.0f : 0.0f;   // p' = 2^PSHIFT p
   // ---- Q fragments (B operand of S^T = K Q^T): lane (query lr, group lq) holds d = 32 half + 8 lq .. +7 ----
   const int q_row = qt * 64 + wave * 16 + lr;
   const bool q_ok = q_row < L;
-  bf16x8 qh[2], qm[2], ql[2];
+  u32x4 qf[2][NP];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     f32x4 u = (f32x4){0.f, 0.f, 0.f, 0.f}, v = u;
@@ -64,7 +74,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
       u = (f32x4){a.x * qs, a.y * qs, a.z * qs, a.w * qs};
       v = (f32x4){c.x * qs, c.y * qs, c.z * qs, c.w * qs};
     }
-    split8(u, v, qh[half], qm[half], ql[half]);
+    split_np(u, v, op_scale, qf[half]);
   }
   float g = 0.f;
   if constexpr (BIAS) {
@@ -124,22 +134,20 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int item = tid + 256 * i;
-      bf16x8 ph, pm, pl;
+      u32x4 pf[NP];
       {
         const int key = item >> 3, slot = item & 7;
         const int off = key * 128 + ((slot ^ ((key >> 1) & 7)) << 4);
-        split8(rk[i][0], rk[i][1], ph, pm, pl);
-        *reinterpret_cast<bf16x8*>(sK + off) = ph;
-        *reinterpret_cast<bf16x8*>(sK + ATT_PLANE + off) = pm;
-        *reinterpret_cast<bf16x8*>(sK + 2 * ATT_PLANE + off) = pl;
+        split_np(rk[i][0], rk[i][1], op_scale, pf);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(sK + p * ATT_PLANE + off) = pf[p];
       }
       {
         const int d = item & 63, grp = item >> 6;
         const int off = d * 128 + ((grp ^ ((d >> 1) & 7)) << 4);
-        split8(rv[i][0], rv[i][1], ph, pm, pl);
-        *reinterpret_cast<bf16x8*>(sV + off) = ph;
-        *reinterpret_cast<bf16x8*>(sV + ATT_PLANE + off) = pm;
-        *reinterpret_cast<bf16x8*>(sV + 2 * ATT_PLANE + off) = pl;
+        split_np(rv[i][0], rv[i][1], op_scale, pf);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(sV + p * ATT_PLANE + off) = pf[p];
       }
     }
     __syncthreads();
@@ -150,28 +158,24 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
     for (int kb = 0; kb < 4; ++kb) s[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      bf16x8 kh[4], km[4], kl[4];
+      u32x4 kf[4][NP];
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         const int key = kb * 16 + lr;
         const int off = key * 128 + (((half * 4 + lq) ^ ((key >> 1) & 7)) << 4);
-        kh[kb] = *reinterpret_cast<const bf16x8*>(sK + off);
-        km[kb] = *reinterpret_cast<const bf16x8*>(sK + ATT_PLANE + off);
-        kl[kb] = *reinterpret_cast<const bf16x8*>(sK + 2 * ATT_PLANE + off);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) kf[kb][p] = *reinterpret_cast<const u32x4*>(sK + p * ATT_PLANE + off);
       }
-      // product-major order: 4 independent accumulators between dependent MFMAs
+      // product-major order (smallest terms first): 4 independent accumulators between dependent MFMAs
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[kb], qh[half], s[kb], 0, 0, 0);
+      for (int t = 0; t < SplitTerms<NP>::N; ++t)
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kb], ql[half], s[kb], 0, 0, 0);
+        for (int kb = 0; kb < 4; ++kb)
+          s[kb] = mfma_np<NP>(kf[kb][SplitTerms<NP>::A[t]], qf[half][SplitTerms<NP>::B[t]], s[kb]);
+    }
+    if constexpr (NP == 2) {
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km[kb], qm[half], s[kb], 0, 0, 0);
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km[kb], qh[half], s[kb], 0, 0, 0);
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kb], qm[half], s[kb], 0, 0, 0);
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kb], qh[half], s[kb], 0, 0, 0);
+      for (int kb = 0; kb < 4; ++kb) s[kb] = s[kb] * s_inv;     // exact: s_inv is a power of two
     }
 
     // ---- bias, mask (last tile only), online softmax; lane owns query q_row, keys kb*16 + lq*4 + rg ----
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const float p = __builtin_amdgcn_exp2f(s[kb][rg] - m_new);
+        const float p = __builtin_amdgcn_exp2f(s[kb][rg] - m_new + PSHIFT);
         s[kb][rg] = p;
         psum += p;
       }
@@ -228,29 +232,21 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
     // ---- O += P V : P fragment of MFMA mm = {s[2mm], s[2mm+1]} (the order V was staged in) ----
 #pragma unroll
     for (int mm = 0; mm < 2; ++mm) {
-      bf16x8 ph, pm, pl;
-      split8(s[2 * mm], s[2 * mm + 1], ph, pm, pl);
-      bf16x8 vh[4], vm[4], vl[4];
+      u32x4 pf[NP];
+      split_np(s[2 * mm], s[2 * mm + 1], 1.0f, pf);
+      u32x4 vf[4][NP];
 #pragma unroll
       for (int dblk = 0; dblk < 4; ++dblk) {
         const int d = dblk * 16 + lr;
         const int off = d * 128 + (((mm * 4 + lq) ^ ((d >> 1) & 7)) << 4);
-        vh[dblk] = *reinterpret_cast<const bf16x8*>(sV + off);
-        vm[dblk] = *reinterpret_cast<const bf16x8*>(sV + ATT_PLANE + off);
-        vl[dblk] = *reinterpret_cast<const bf16x8*>(sV + 2 * ATT_PLANE + off);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) vf[dblk][p] = *reinterpret_cast<const u32x4*>(sV + p * ATT_PLANE + off);
       }
 #pragma unroll
-      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[dblk], O[dblk], 0, 0, 0);
+      for (int t = 0; t < SplitTerms<NP>::N; ++t)
 #pragma unroll
-      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[dblk], O[dblk], 0, 0, 0);
-#pragma unroll
-      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, vm[dblk], O[dblk], 0, 0, 0);
-#pragma unroll
-      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, vh[dblk], O[dblk], 0, 0, 0);
-#pragma unroll
-      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vm[dblk], O[dblk], 0, 0, 0);
-#pragma unroll
-      for (int dblk = 0; dblk < 4; ++dblk) O[dblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[dblk], O[dblk], 0, 0, 0);
+        for (int dblk = 0; dblk < 4; ++dblk)
+          O[dblk] = mfma_np<NP>(pf[SplitTerms<NP>::B[t]], vf[dblk][SplitTerms<NP>::A[t]], O[dblk]);
     }
   }
 
@@ -262,7 +258,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
     const float lt = __shfl(l_tot, lq * 4 + rg, 64);
     const int q = qt * 64 + wave * 16 + lq * 4 + rg;
     if (q < L) {
-      const float inv = 1.0f / lt;
+      const float inv = op_inv / lt;      // NP = 2: lt = 2^14 sum p and O carries 2^14 op_scale
       float* op = out + (rowbase + q) * ldo + j * 64 + lr;
 #pragma unroll
       for (int dblk = 0; dblk < 4; ++dblk) op[dblk * 16] = O[dblk][rg] * inv;
@@ -274,28 +270,39 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
 
 int launch_attention_split(const float* qkv, float* out, const float* gate, const float* table,
                            const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
-                           float scale, hipStream_t s) {
+                           float scale, hipStream_t s, const float* amax) {
   if (h <= 0 || B <= 0 || L <= 0) return DZN_OK;
   if ((ldqkv & 3) || (reinterpret_cast<uintptr_t>(qkv) & 15)) return DZN_E_INVALID;
   const bool bias = gate && table && head_idx;
-  const size_t lds = 6 * ATT_PLANE + (bias ? (2 * L - 1) : 0) * sizeof(float);
+  const int np = amax ? 2 : 3;
+  const size_t lds = 2 * np * ATT_PLANE + (bias ? (2 * L - 1) : 0) * sizeof(float);
   if (lds > 160 * 1024) return DZN_E_INVALID;
   static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
   if (first_use_on_device(attr_mask)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* ks[4] = {reinterpret_cast<const void*>(attn_split_kernel<true, 3>), reinterpret_cast<const void*>(attn_split_kernel<false, 3>),
+                         reinterpret_cast<const void*>(attn_split_kernel<true, 2>), reinterpret_cast<const void*>(attn_split_kernel<false, 2>)};
+    for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   dim3 grid((L + 63) / 64, h, B);
-  const int pid = prof_begin(s, bias ? "attention_relpos_f32s" : "attention_f32s",
+  const int pid = prof_begin(s, bias ? (amax ? "attention_relpos_f32h" : "attention_relpos_f32s") : (amax ? "attention_f32h" : "attention_f32s"),
                              4.0 * B * h * (double)L * L * 64.0, 0.0);
-  if (bias)
-    hipLaunchKernelGGL(attn_split_kernel<true>, grid, dim3(256), lds, s, qkv, out, gate, table, head_idx, B, L, h,
-                       Htot, ldqkv, ldo, scale);
-  else
-    hipLaunchKernelGGL(attn_split_kernel<false>, grid, dim3(256), lds, s, qkv, out, gate, table, head_idx, B, L, h,
-                       Htot, ldqkv, ldo, scale);
+#define DZN_ATT(BV, NPV)                                                                                            \
+  hipLaunchKernelGGL((attn_split_kernel<BV, NPV>), grid, dim3(256), lds, s, qkv, out, gate, table, head_idx, B, L, h, \
+                     Htot, ldqkv, ldo, scale, amax)
+  if (bias && amax) DZN_ATT(true, 2);
+  else if (bias) DZN_ATT(true, 3);
+  else if (amax) DZN_ATT(false, 2);
+  else DZN_ATT(false, 3);
+#undef DZN_ATT
   prof_end(pid, s);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+// kernel-level entry point of the fp16 two-term variant (tests): amax = f32 [B], per-window |max| of qkv
+extern "C" int dzn_op_attention_h2(const float* qkv, float* out, const float* gate, const float* table,
+                                   const int32_t* head_idx, int32_t B, int32_t L, int32_t h, int32_t Htot, int32_t ldqkv,
+                                   int32_t ldo, float scale, const float* amax, void* stream) {
+  if (!qkv || !out || !amax) return DZN_E_INVALID;
+  return launch_attention_split(qkv, out, gate, table, head_idx, B, L, h, Htot, ldqkv, ldo, scale,
+                                reinterpret_cast<hipStream_t>(stream), amax);
 }

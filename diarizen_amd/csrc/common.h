@@ -128,7 +128,8 @@ int launch_attention_t(const float* qkv, void* out, int out_bf16, const float* g
                        float scale, hipStream_t s);
 int launch_attention_split(const float* qkv, float* out, const float* gate, const float* table,
                            const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
-                           float scale, hipStream_t s);  // attention_split.hip (DZN_PREC_F32_SPLIT)
+                           float scale, hipStream_t s, const float* amax = nullptr);  // attention_split.hip
+                           // (amax = per-window |max| of qkv -> fp16 two-term variant, else bf16 three-term)
 int launch_attention(const float* qkv, float* out, const float* gate, const float* table,
                      const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
                      float scale, int precision, hipStream_t s);
@@ -156,13 +157,14 @@ int launch_frame_prep(const float* wave, int B, int N, int T, int flen, int fshi
 int launch_power(const float* spec, int64_t rows, int nb, float* pw, hipStream_t st);
 int launch_log_cmn(float* mel, int B, int T, int NB, float eps, hipStream_t st);
 int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* w, const float* bias,
-                     void* img, int out_bf16, hipStream_t st);
+                     void* img, int out_bf16, hipStream_t st, float* amax = nullptr);
 int launch_stats_pool(const void* img, int in_bf16, int B, int H, int W, int C, const float* masks, int S,
                       int L, float* stats, hipStream_t st);
 
 // conv_split.hip: 3x3 stride-1 conv 32 -> 32 over zero-bordered NHWC images (DZN_PREC_F32_SPLIT)
 int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias, const float* R, float* out, int B,
-                             int Hs, int Ws, int relu, int post_relu, hipStream_t s, float* amax = nullptr);
+                             int Hs, int Ws, int relu, int post_relu, hipStream_t s, float* amax = nullptr,
+                             const void* W2h = nullptr, const float* col_scale = nullptr, const float* amax_in = nullptr);
 
 // post.hip
 int launch_prepare_masks(const uint8_t* ml, int B, int L, int S, int median, int exclude_overlap,

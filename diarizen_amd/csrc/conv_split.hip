@@ -29,19 +29,25 @@ namespace {
 
 constexpr int CS_TP = 128;               // output pixels per tile
 constexpr int CS_SEG = CS_TP + 2;        // pixels per input segment
-constexpr int CS_PLANE = 3 * CS_SEG * 64;  // bytes per bf16 plane of the strip
+constexpr int CS_PLANE = 3 * CS_SEG * 64;  // bytes per 16-bit plane of the strip
 
+// NP = 3: bf16 three-term split (six products per block).  NP = 2 (DZN_PREC_F32_H2): fp16 two-term split (three
+// products): the strip is scaled by the exact power of two from the input image's |max| tracker (amax_in[b]) when it
+// is split, the weights come pre-scaled per output channel (col_scale), the epilogue multiplies both back.
 struct ConvArgs {
   const float* in;
-  const u16* W3;       // [32 oc][9 taps][3 planes][32] bf16, k order of gemm_split.hip
+  const u16* W3;       // [32 oc][9 taps][NP planes][32] 16-bit, k order of gemm_split.hip
   const float* bias;   // [32]
   const float* R;      // residual image (same geometry) or nullptr
   float* out;
   int B, Hs, Ws;       // interior size; images are [Hs+2][Ws+2][32]
   int relu, post_relu;
-  float* amax;         // |max| tracker of `out` (DZN_PREC_F32_H2 consumers) or nullptr
+  float* amax;         // |max| tracker of `out` per image (DZN_PREC_F32_H2 consumers) or nullptr
+  const float* amax_in;    // NP = 2: per-image |max| of `in`
+  const float* col_scale;  // NP = 2: [32] inverse weight scales
 };
 
+template <int NP>
 __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -56,15 +62,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
   const int last_pix = (a.Hs + 2) * P - 1;
 
   // this wavefront's weight fragments: A operand rows = output channels nb*16 + lr, k = 8 lq .. 8 lq + 7
-  bf16x8 wf[9][3];
+  u32x4 wf[9][NP];
   {
-    const u16* wp = a.W3 + (int64_t)(nb * 16 + lr) * (9 * 96) + lq * 8;
+    const u16* wp = a.W3 + (int64_t)(nb * 16 + lr) * (9 * NP * 32) + lq * 8;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wf[t][p] = *reinterpret_cast<const bf16x8*>(wp + t * 96 + p * 32);
+      for (int p = 0; p < NP; ++p) wf[t][p] = *reinterpret_cast<const u32x4*>(wp + t * NP * 32 + p * 32);
   }
   const float4 b4 = *reinterpret_cast<const float4*>(a.bias + nb * 16 + lq * 4);
+  float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  if constexpr (NP == 2) cs4 = *reinterpret_cast<const float4*>(a.col_scale + nb * 16 + lq * 4);
   float out_amax = 0.f;
 
   // staging registers: 7 items per thread (3 segments x 130 pixels x 4 chunks of 8 channels = 1560 items);
@@ -89,20 +97,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
       v4[i] = *reinterpret_cast<const float4*>(src + 16);   // channels 16+4c .. 16+4c+3
     }
   };
-  auto split_store = [&]() {
+  auto split_store = [&](float in_scale) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int item = tid + 256 * i;
       const int seg = item / (CS_SEG * 4);
       const int r = item - seg * (CS_SEG * 4);
       const int px = r >> 2, c = r & 3;
-      bf16x8 ph, pm, pl;
-      split8((f32x4){u4[i].x, u4[i].y, u4[i].z, u4[i].w}, (f32x4){v4[i].x, v4[i].y, v4[i].z, v4[i].w}, ph, pm, pl);
+      u32x4 pf[NP];
+      split_np<NP>((f32x4){u4[i].x, u4[i].y, u4[i].z, u4[i].w}, (f32x4){v4[i].x, v4[i].y, v4[i].z, v4[i].w}, in_scale, pf);
       if (item < NITEM) {
         const int off = (seg * CS_SEG + px) * 64 + ((c ^ ((px >> 1) & 3)) << 4);
-        *reinterpret_cast<bf16x8*>(smem + off) = ph;
-        *reinterpret_cast<bf16x8*>(smem + CS_PLANE + off) = pm;
-        *reinterpret_cast<bf16x8*>(smem + 2 * CS_PLANE + off) = pl;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(smem + p * CS_PLANE + off) = pf[p];
       }
     }
   };
@@ -124,7 +131,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
     const int tile = tile_of(j);
     const int b = tile / tiles_img;
     const int q0 = P + (tile - b * tiles_img) * CS_TP;    // first output pixel (flat, padded coords)
-    split_store();      // every input pixel of the strip is split exactly once
+    float in_scale = 1.f, in_inv = 1.f;
+    if constexpr (NP == 2) h2_scale(a.amax_in[b], in_scale, in_inv);
+    split_store(in_scale);      // every input pixel of the strip is split exactly once
     __syncthreads();
     if (j + 1 < nmine) fetch(tile_of(j + 1));   // in flight during the MFMA phase
 
@@ -140,28 +149,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
         const int t = dh * 3 + dw;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          bf16x8 xh[2], xm[2], xl[2];
+          u32x4 xf[2][NP];
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             const int px = mh * 64 + (2 * g + m) * 16 + lr + dw;
             const int off = (dh * CS_SEG + px) * 64 + ((lq ^ ((px >> 1) & 3)) << 4);
-            xh[m] = *reinterpret_cast<const bf16x8*>(smem + off);
-            xm[m] = *reinterpret_cast<const bf16x8*>(smem + CS_PLANE + off);
-            xl[m] = *reinterpret_cast<const bf16x8*>(smem + 2 * CS_PLANE + off);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) xf[m][p] = *reinterpret_cast<const u32x4*>(smem + p * CS_PLANE + off);
           }
           // product-major, smallest terms first
 #pragma unroll
-          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][2], xh[m], acc[2 * g + m], 0, 0, 0);
+          for (int tt = 0; tt < SplitTerms<NP>::N; ++tt)
 #pragma unroll
-          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0], xl[m], acc[2 * g + m], 0, 0, 0);
-#pragma unroll
-          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][1], xm[m], acc[2 * g + m], 0, 0, 0);
-#pragma unroll
-          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][1], xh[m], acc[2 * g + m], 0, 0, 0);
-#pragma unroll
-          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0], xm[m], acc[2 * g + m], 0, 0, 0);
-#pragma unroll
-          for (int m = 0; m < 2; ++m) acc[2 * g + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0], xh[m], acc[2 * g + m], 0, 0, 0);
+            for (int m = 0; m < 2; ++m)
+              acc[2 * g + m] = mfma_np<NP>(wf[t][SplitTerms<NP>::A[tt]], xf[m][SplitTerms<NP>::B[tt]], acc[2 * g + m]);
         }
       }
 
@@ -175,6 +176,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
       if (q < P + npix && col >= 1 && col <= a.Ws) {
         const int64_t o = (int64_t)q * 32 + nb * 16 + lq * 4;
         f32x4 v = acc[mb];
+        if constexpr (NP == 2) {   // undo the exact power-of-two operand scales
+          v[0] *= in_inv * cs4.x; v[1] *= in_inv * cs4.y; v[2] *= in_inv * cs4.z; v[3] *= in_inv * cs4.w;
+        }
         v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
         if (a.relu) {
 #pragma unroll
@@ -202,23 +206,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
 
 }  // namespace
 
-// in / out / R: zero-bordered fp32 NHWC images [B][Hs+2][Ws+2][32] (image bases, not interior pointers)
+// in / out / R: zero-bordered fp32 NHWC images [B][Hs+2][Ws+2][32] (image bases, not interior pointers).
+// W2h / col_scale / amax_in all given -> fp16 two-term variant, else the bf16 three-term one (W3).
 int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias, const float* R, float* out, int B,
-                             int Hs, int Ws, int relu, int post_relu, hipStream_t s, float* amax) {
+                             int Hs, int Ws, int relu, int post_relu, hipStream_t s, float* amax, const void* W2h,
+                             const float* col_scale, const float* amax_in) {
   if (B <= 0 || Hs <= 0 || Ws <= 0) return DZN_OK;
   if (!in || !W3 || !bias || !out) return DZN_E_INVALID;
+  const bool h2 = W2h && col_scale && amax_in;
   static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
-  const size_t lds = 3 * CS_PLANE;
+  const size_t lds = (h2 ? 2 : 3) * CS_PLANE;
   if (first_use_on_device(attr_mask)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_split_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_split_kernel<3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_split_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  ConvArgs a{in, static_cast<const u16*>(W3), bias, R, out, B, Hs, Ws, relu, post_relu, amax};
-  const int64_t ntiles = (int64_t)((Hs * (Ws + 2) + CS_TP - 1) / CS_TP) * B;
-  (void)ntiles;
+  ConvArgs a{in, static_cast<const u16*>(h2 ? W2h : W3), bias, R, out, B, Hs, Ws, relu, post_relu, amax, amax_in, col_scale};
   const int grid = 512;   // persistent: 2 workgroups per CU; XCD-major work distribution inside the kernel
-  const int pid = prof_begin(s, "conv3x3_c32_f32s", 2.0 * B * Hs * (double)Ws * 32.0 * 288.0, 0.0);
-  hipLaunchKernelGGL(conv3x3_c32_split_kernel, dim3(grid), dim3(256), lds, s, a);
+  const int pid = prof_begin(s, h2 ? "conv3x3_c32_f32h" : "conv3x3_c32_f32s", 2.0 * B * Hs * (double)Ws * 32.0 * 288.0, 0.0);
+  if (h2) hipLaunchKernelGGL(conv3x3_c32_split_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(conv3x3_c32_split_kernel<3>, dim3(grid), dim3(256), lds, s, a);
   prof_end(pid, s);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
@@ -226,5 +234,14 @@ int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias,
 extern "C" int dzn_op_conv3x3_c32(const float* in, const void* W3, const float* bias, const float* R, float* out,
                                   int32_t B, int32_t Hs, int32_t Ws, int32_t relu, int32_t post_relu, void* stream) {
   return launch_conv3x3_c32_split(in, W3, bias, R, out, B, Hs, Ws, relu, post_relu,
-                                  reinterpret_cast<hipStream_t>(stream), nullptr);
+                                  reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, nullptr, nullptr);
+}
+
+// fp16 two-term variant (tests): W2h / col_scale from dzn_op_split_weights_h2 of W [32][288], amax_in f32 [B]
+extern "C" int dzn_op_conv3x3_c32_h2(const float* in, const void* W3, const void* W2h, const float* col_scale,
+                                     const float* amax_in, const float* bias, const float* R, float* out, int32_t B,
+                                     int32_t Hs, int32_t Ws, int32_t relu, int32_t post_relu, void* stream) {
+  if (!W2h || !col_scale || !amax_in) return DZN_E_INVALID;
+  return launch_conv3x3_c32_split(in, W3, bias, R, out, B, Hs, Ws, relu, post_relu,
+                                  reinterpret_cast<hipStream_t>(stream), nullptr, W2h, col_scale, amax_in);
 }

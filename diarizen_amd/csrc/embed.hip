@@ -98,11 +98,13 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                                                         int NB, int C,
                                                         const float* __restrict__ w,  // [C, 9] folded
                                                         const float* __restrict__ bias,
-                                                        TO* __restrict__ img) {
+                                                        TO* __restrict__ img, float* __restrict__ amax) {
   const int cq = C / 4;
   const int64_t total = (int64_t)B * NB * T * cq;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * 256) {
+  // wave-uniform trip count (the tracker update below is a wave-level reduction); the last sweep is predicated
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < total; i0 += (int64_t)gridDim.x * 256) {
+    const bool ok = i0 + threadIdx.x < total;
+    const int64_t i = ok ? i0 + threadIdx.x : total - 1;
     const int q = (int)(i % cq);
     int64_t p = i / cq;
     const int wv = (int)(p % T);
@@ -128,8 +130,16 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       o[c] = fmaxf(a + bias[ch], 0.f);
     }
     TO* op = img + (((int64_t)b * (NB + 2) + h + 1) * (T + 2) + wv + 1) * C + q * 4;
+    if (ok) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) st_act(op, c, o[c]);
+      for (int c = 0; c < 4; ++c) st_act(op, c, o[c]);
+    }
+    if (amax) {   // per-image |max| tracker (DZN_PREC_F32_H2: scale of the stage-1 convolutions' fp16 split)
+      const float m = ok ? fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])) : 0.f;     // post-ReLU: non-negative
+      const int b0 = __builtin_amdgcn_readfirstlane(b);
+      if (__all(b == b0)) track_amax(amax + b0, m);
+      else track_amax_lane(amax + b, m);
+    }
   }
 }
 
@@ -205,15 +215,15 @@ int launch_log_cmn(float* mel, int B, int T, int NB, float eps, hipStream_t st) 
 }
 
 int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* w, const float* bias,
-                     void* img, int out_bf16, hipStream_t st) {
+                     void* img, int out_bf16, hipStream_t st, float* amax) {
   ProfScope prof_scope_(st, "stem_conv");
   const dim3 grid(grid_for((int64_t)B * NB * T * (C / 4)));
   if (out_bf16)
     hipLaunchKernelGGL(stem_conv_kernel<u16>, grid, dim3(256), 0, st, fb, B, T, NB, C, w, bias,
-                       static_cast<u16*>(img));
+                       static_cast<u16*>(img), amax);
   else
     hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, st, fb, B, T, NB, C, w, bias,
-                       static_cast<float*>(img));
+                       static_cast<float*>(img), amax);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 

@@ -1111,7 +1111,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       gemm(d, y16, false, "qkv");
       if (prec_is_split(c.precision))
         chk(launch_attention_split(h->qkv, h->ao, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd, hd,
-                                   0.125f, st),
+                                   0.125f, st, am(dzn_handle::AM_QKV)),
             "attention");
       else
         chk(launch_attention_t(h->qkv, h->ao, lp, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd,
@@ -1227,7 +1227,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       gemm(q, lp, false, "conf qkv");
       if (prec_is_split(c.precision))
         chk(launch_attention_split(h->hmid, h->hv, nullptr, nullptr, nullptr, B, L, c.conf_heads, 0, 3 * A, A,
-                                   0.125f, st),
+                                   0.125f, st, am(dzn_handle::AM_HMID)),
             "conf attention");
       else
         chk(launch_attention_t(h->hmid, h->hv, lp, nullptr, nullptr, nullptr, B, L, c.conf_heads, 0, 3 * A, A,
@@ -1297,11 +1297,10 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
   }
   tap(h, "fbank", h->fb, MT, NB, NB, st);
   // ---- ResNet34 trunk ----
-  chk(launch_stem_conv(h->fb, B, T, NB, h->sC[0], h->stem_w, h->stem_b, h->sbuf[0][0], lp, st), "stem");
   const float* prev = nullptr;  // output image of the previous stage
   int cur = 0;
   // DZN_PREC_F32_H2: one |max| tracker per image buffer (sbuf[s][k] -> slot AM_IMG0 + 3 s + k), running over the
-  // forward; the stem's image has no writer with a tracker, but its only consumer is the dedicated bf16 stage-1 kernel
+  // forward (stem kernel, stage-1 kernel and the contraction epilogues all track what they write)
   const bool h2 = c.precision == DZN_PREC_F32_H2;
   const int64_t MB = c.max_batch;
   if (h2) HIPCHK(hipMemsetAsync(h->amax + dzn_handle::AM_IMG0 * MB, 0, 12 * MB * sizeof(float), st));
@@ -1312,6 +1311,8 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
         if (buf == h->sbuf[s2][k]) return h->amax + (dzn_handle::AM_IMG0 + 3 * s2 + k) * MB;
     return nullptr;
   };
+  chk(launch_stem_conv(h->fb, B, T, NB, h->sC[0], h->stem_w, h->stem_b, h->sbuf[0][0], lp, st, img_am(h->sbuf[0][0])),
+      "stem");
   for (int s = 0; s < 4; ++s) {
     const int Hs = h->sH[s], Ws = h->sW[s], Cc = h->sC[s];
     const int64_t img = h->simg[s];
@@ -1323,7 +1324,7 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
           (act == DZN_ACT_NONE || act == DZN_ACT_RELU)) {
         // first ResNet stage: dedicated kernel, every input pixel split once instead of once per tap
         chk(launch_conv3x3_c32_split(in, rc.l.W3, rc.l.b, R, out, B, Hs, Ws, act == DZN_ACT_RELU, post_relu, st,
-                                     img_am(out)),
+                                     img_am(out), rc.l.W2h, rc.l.wsc, img_am(in)),
             "resnet conv3x3 c32");
         return;
       }

@@ -100,3 +100,31 @@ __device__ __forceinline__ void h2_scale(float amax, float& s, float& inv) {
   inv = __uint_as_float((unsigned)(e - 14 + 127) << 23);
 }
 
+
+// the products that are summed, smallest first, as (term of operand A, term of operand B) with 0 = hi:
+//   NP = 3: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi        NP = 2: lo*hi, hi*lo, hi*hi
+template <int NP> struct SplitTerms;
+template <> struct SplitTerms<3> {
+  static constexpr int N = 6;
+  static constexpr int A[6] = {2, 0, 1, 1, 0, 0};
+  static constexpr int B[6] = {0, 2, 1, 0, 1, 0};
+};
+template <> struct SplitTerms<2> {
+  static constexpr int N = 3;
+  static constexpr int A[3] = {1, 0, 0};
+  static constexpr int B[3] = {0, 1, 0};
+};
+
+// 8 fp32 values -> NP fragments (hi, [mid,] lo); `scale` (exact power of two) applies to NP = 2 only
+template <int NP>
+__device__ __forceinline__ void split_np(const f32x4& u, const f32x4& v, float scale, u32x4 (&f)[NP]) {
+  if constexpr (NP == 3) {
+    bf16x8 h_, m_, l_;
+    split8(u, v, h_, m_, l_);
+    f[0] = __builtin_bit_cast(u32x4, h_);
+    f[1] = __builtin_bit_cast(u32x4, m_);
+    f[2] = __builtin_bit_cast(u32x4, l_);
+  } else {
+    split8_h2(u, v, scale, f[0], f[1]);
+  }
+}

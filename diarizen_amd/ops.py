@@ -125,7 +125,7 @@ def split_rows(x):
     return out
 
 
-def conv3x3_c32(img, W3, bias, R=None, relu=False, post_relu=False, out=None):
+def conv3x3_c32(img, W3, bias, R=None, relu=False, post_relu=False, out=None, h2_weights=None):
     """3x3 stride-1 conv 32 -> 32 on zero-bordered NHWC fp32 images [B, H+2, W+2, 32] (csrc/conv_split.hip);
     W3 = split_weights(W[32, 288]) with k = (dh*3 + dw)*32 + ci.  Returns a new zero-bordered image."""
     lib = _lib.load()
@@ -133,6 +133,12 @@ def conv3x3_c32(img, W3, bias, R=None, relu=False, post_relu=False, out=None):
     B, Hp, Wp, _ = img.shape
     if out is None:
         out = torch.zeros_like(img)
+    if h2_weights is not None:      # fp16 two-term variant: (W2h, col_scale) + per-image |max| of the input
+        W2h, cs = h2_weights
+        am = img.reshape(B, -1).abs().amax(dim=1).float().contiguous()
+        check(lib.dzn_op_conv3x3_c32_h2(_p(img), _p(W3), _p(W2h), _p(cs), _p(am), _p(bias), _p(R), _p(out), B, Hp - 2,
+                                        Wp - 2, int(relu), int(post_relu), _stream()), what="dzn_op_conv3x3_c32_h2")
+        return out
     check(lib.dzn_op_conv3x3_c32(_p(img), _p(W3), _p(bias), _p(R), _p(out), B, Hp - 2, Wp - 2, int(relu),
                                  int(post_relu), _stream()), what="dzn_op_conv3x3_c32")
     return out
@@ -199,6 +205,11 @@ def attention(qkv, B, L, h, *, gate=None, table=None, head_idx=None, Htot=0, sca
               precision=0):
     lib = _lib.load()
     out = torch.empty((B * L, h * 64), device=qkv.device, dtype=torch.float32)
+    if precision == _lib.DZN_PREC_F32_H2:      # fp16 two-term variant: per-window |max| of qkv
+        am = qkv.reshape(B, -1).abs().amax(dim=1).float().contiguous()
+        check(lib.dzn_op_attention_h2(_p(qkv), _p(out), _p(gate), _p(table), _p(head_idx), B, L, h, Htot,
+                                      qkv.stride(0), out.stride(0), scale, _p(am), _stream()), what="dzn_op_attention_h2")
+        return out
     check(lib.dzn_op_attention(_p(qkv), _p(out), _p(gate), _p(table), _p(head_idx), B, L, h,
                                Htot, qkv.stride(0), out.stride(0), scale, precision, _stream()),
           what="dzn_op_attention")

@@ -123,6 +123,12 @@ int dzn_op_split_rows(const float* x, void* planes, int64_t plane_stride, int64_
 int dzn_op_conv3x3_c32(const float* in, const void* W3, const float* bias, const float* R, float* out,
                        int32_t B, int32_t Hs, int32_t Ws, int32_t relu, int32_t post_relu, void* stream);
 
+/* the same convolution in the fp16 two-term arithmetic (DZN_PREC_F32_H2): W2h / col_scale = dzn_op_split_weights_h2 of
+ * W [32][288], amax_in = f32 [B] per-image |max| of `in` */
+int dzn_op_conv3x3_c32_h2(const float* in, const void* W3, const void* W2h, const float* col_scale, const float* amax_in,
+                          const float* bias, const float* R, float* out, int32_t B, int32_t Hs, int32_t Ws,
+                          int32_t relu, int32_t post_relu, void* stream);
+
 /* y[r,:] = LayerNorm(x[r,:C]) * gamma + beta (eps), optional fused erf-GELU; row strides
  * ldx / ldy; columns [C, Cpad) of y are written as zero.  torch F.layer_norm. */
 int dzn_op_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
@@ -153,6 +159,11 @@ int dzn_op_gate(const float* y, int64_t ldy, const float* Wg, const float* bg, c
 int dzn_op_gate_stats(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* Wg,
                       const float* bg, const float* cst, float* gate, float* stats, int64_t rows, int32_t Htot,
                       float eps, void* stream);
+
+/* the same attention in the fp16 two-term arithmetic (DZN_PREC_F32_H2): amax = f32 [B], |max| of each window's qkv */
+int dzn_op_attention_h2(const float* qkv, float* out, const float* gate, const float* table, const int32_t* head_idx,
+                        int32_t B, int32_t L, int32_t h, int32_t Htot, int32_t ldqkv, int32_t ldo, float scale,
+                        const float* amax, void* stream);
 
 int dzn_op_attention(const float* qkv, float* out, const float* gate, const float* table,
                      const int32_t* head_idx, int32_t B, int32_t L, int32_t h,

@@ -387,6 +387,7 @@ def test_conv3x3_c32_split(built_lib, gpu, H, W, B):
         return o.contiguous()
     wp = w.permute(0, 2, 3, 1).reshape(32, 288).contiguous()           # k = (dh*3 + dw)*32 + ci
     W3 = ops.split_weights(wp.to(gpu))
+    h2w = ops.split_weights_h2(wp.to(gpu))
     conv = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1)
     cases = [(False, False, None, conv),
              (True, False, None, torch.relu(conv)),
@@ -398,6 +399,11 @@ def test_conv3x3_c32_split(built_lib, gpu, H, W, B):
         assert _rel_err(got, ref) < 1e-5
         assert out[:, 0].abs().max() == 0 and out[:, -1].abs().max() == 0
         assert out[:, :, 0].abs().max() == 0 and out[:, :, -1].abs().max() == 0
+        # fp16 two-term variant of the same kernel (per-image power-of-two scales): same tolerance
+        out2 = ops.conv3x3_c32(padded(x).to(gpu), W3, bias.to(gpu), R=None if R is None else padded(R).to(gpu),
+                               relu=relu, post_relu=post, h2_weights=h2w).cpu()
+        assert _rel_err(out2[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double(), ref) < 1e-5
+        assert out2[:, 0].abs().max() == 0 and out2[:, :, 0].abs().max() == 0
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 64, 256), (1000, 200, 1024), (257, 1024, 96)])
