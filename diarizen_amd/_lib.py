@@ -156,7 +156,7 @@ def load() -> C.CDLL:
     sig("dzn_op_split_weights_h2", i32, [vp, i64, i32, i64, vp, vp, vp])
     sig("dzn_op_amax", i32, [vp, i64, vp, vp])
     sig("dzn_op_split_rows", i32, [vp, vp, i64, i64, i32, vp])
-    sig("dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp])
+    sig("dzn_op_conv3x3_c32", i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp])
     sig("dzn_op_conv3x3_c32_h2", i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp])
     sig("dzn_op_layernorm", i32, [vp, i64, vp, i64, vp, vp, i64, i32, i32, f32, i32, vp])
     sig("dzn_op_gate", i32, [vp, i64, vp, vp, vp, vp, i64, i32, vp])
