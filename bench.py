@@ -258,6 +258,9 @@ def main():
                 emb_l = res.embeddings if res is not None else torch.empty((0, S, eng.emb.embed_dim), device=dev)
                 seg_g, emb_g = gather_windows(seg_l, emb_l)
                 return (seg_g.cpu(), emb_g.cpu()) if rank == 0 else None
+            if dist.get_backend() != "nccl":       # single-GPU rehearsal of the N > 1 path (gloo: host staging)
+                seg_g, emb_g = gather_windows(res.segmentations, res.embeddings)
+                return (seg_g.cpu(), emb_g.cpu()) if rank == 0 else None
             segs = [torch.empty_like(res.segmentations) for _ in range(world)]
             embs = [torch.empty_like(res.embeddings) for _ in range(world)]
             dist.all_gather(segs, res.segmentations)

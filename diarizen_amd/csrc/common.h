@@ -56,9 +56,26 @@ __device__ __forceinline__ void track_amax(float* tracker, float wave_partial) {
 }
 
 // ---- activations (match torch CPU fp32 semantics) ----
+// erf to 1.5e-7 ABSOLUTE (Abramowitz & Stegun 7.1.26) in ~16 branch-free VALU ops: 1 / (1 + p|x|) on v_rcp_f32, a
+// 5-term Horner polynomial, exp(-x^2) on v_exp_f32.  libm's erff costs ~40 issue slots per element once both of its
+// branches are live in a wavefront, which made the GELU sites VALU-bound (conv0: 3.3 G elements per batch, measured
+// 2.7 TB/s of a 13 GB write stream; the FFN / LayerNorm+GELU epilogues likewise).  The error is below one fp32 ulp of
+// 1 + erf, i.e. |gelu_fast - gelu| <= 0.5 |x| 1.5e-7: inside the round-off of the contractions around it
+// (tests/test_ops_gpu.py::test_gelu_accuracy, and every model-level parity test runs through it).
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  const float y = fmaf(-p * t, e, 1.0f);
+  return copysignf(y, x);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
   // torch.nn.functional.gelu(approximate='none'): 0.5 * x * (1 + erf(x / sqrt(2)))
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }

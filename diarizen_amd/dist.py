@@ -52,6 +52,12 @@ def gather_windows(seg: torch.Tensor, emb: Optional[torch.Tensor]):
     if d is None or d.get_world_size() == 1:
         return seg, emb
     g = d.get_world_size()
+    if d.get_backend() == "gloo" and seg.is_cuda:
+        # gloo has no device all_gather: stage through the host (debug / single-GPU rehearsal of the N > 1 path;
+        # production runs use the "nccl" backend = RCCL over xGMI, device to device)
+        dev = seg.device
+        s2, e2 = gather_windows(seg.cpu(), emb.cpu() if emb is not None else None)
+        return s2.to(dev), (e2.to(dev) if e2 is not None else None)
     n = torch.tensor([seg.shape[0]], device=seg.device, dtype=torch.int64)
     counts = [torch.zeros_like(n) for _ in range(g)]
     d.all_gather(counts, n)
