@@ -154,7 +154,7 @@ int launch_attention(const float* qkv, float* out, const float* gate, const floa
 // frontend.hip
 int launch_conv0(const float* wave, int B, int N, const float* stats, const float* w,
                  const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
-                 int layer_norm, float eps, void* out, int out_bf16, hipStream_t st);
+                 int layer_norm, float eps, void* out, int out_bf16, hipStream_t st, const float* lnq = nullptr);
 int launch_groupnorm_gelu(const float* x, void* y, int y_bf16, int B, int T, int C, int Cp, int64_t ld,
                           const float* gamma, const float* beta, float eps, float* stats, hipStream_t st);
 int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int Lp, int pad, int D,
@@ -162,6 +162,11 @@ int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int 
 int launch_ws_accum(const float* x, float* ws, float w, int init, int64_t n, hipStream_t st);
 int launch_col_scale(void* x, int x_bf16, int64_t rows, int C, int64_t ld, const float* scale,
                      hipStream_t st);
+// frontend_fused.hip (DZN_PREC_F32_H2): conv0 + LN + GELU + conv1 in one kernel
+int launch_split_weights_h2_natural(const float* W, int64_t rows, int K, void* W2, float* col_scale, hipStream_t s);
+int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, const float* w0, const float* gamma0,
+                        const float* beta0, const float* lnq, int C0, int T0, int T1, const void* W2h,
+                        const float* col_scale, int N1p, float act_bound, float eps, float* out, hipStream_t st);
 // conformer.hip
 int launch_glu_dwconv(const float* u, int64_t ldu, const float* w, const float* bias, void* out,
                       int out_bf16, int64_t ldo, int B, int L, int A, int ks, hipStream_t st);

@@ -126,6 +126,9 @@ struct dzn_handle {
   int D = 0, H = 0, A = 0, Fh = 0;
   // ---- segmentation: weights ----
   float* conv0_w = nullptr;
+  float* conv0_lnq = nullptr;
+  u16* conv1_W2n = nullptr;     // conv1's fp16 planes in natural k order + row scales: the fused conv0 -> conv1 kernel
+  float* conv1_wscn = nullptr;   // [10 + 100]: mean and covariance over channels of conv0's taps (frontend.hip)
   LNp conv_ln[DZN_MAX_CONV];
   Lin conv[DZN_MAX_CONV];
   float* dummy_w = nullptr;
@@ -378,6 +381,21 @@ void finalize_seg(H* h) {
     expect_numel(w, (int64_t)h->C[0] * c.conv_k[0], pre + ".conv.weight");
     h->conv0_w = upload(h, w.v);
     h->conv_ln[0] = ln_from_sd(h, pre + ".layer_norm", h->C[0]);
+    if (c.extractor_layer_norm && c.conv_k[0] <= 10 && !getenv("DZN_CONV0_WAVE_STATS")) {
+      // LayerNorm statistics of conv0's frames as a quadratic form of the input samples (frontend.hip)
+      const int C0 = h->C[0], k0 = c.conv_k[0];
+      std::vector<double> wb(10, 0.0), Q(100, 0.0);
+      for (int ch = 0; ch < C0; ++ch)
+        for (int i = 0; i < k0; ++i) wb[i] += w.v[(size_t)ch * k0 + i] / C0;
+      for (int ch = 0; ch < C0; ++ch)
+        for (int i = 0; i < k0; ++i)
+          for (int j = 0; j < k0; ++j)
+            Q[i * 10 + j] += (w.v[(size_t)ch * k0 + i] - wb[i]) * (w.v[(size_t)ch * k0 + j] - wb[j]) / C0;
+      std::vector<float> lq(110);
+      for (int i = 0; i < 10; ++i) lq[i] = (float)wb[i];
+      for (int i = 0; i < 100; ++i) lq[10 + i] = (float)Q[i];
+      h->conv0_lnq = upload(h, lq);
+    }
     if (c.extractor_layer_norm) {   // |LN(x)_c| <= sqrt(C - 1), |GELU(t)| <= |t|
       float mg = 0.f, mb = 0.f;
       for (float v : need(h, pre + ".layer_norm.weight").v) mg = std::max(mg, std::fabs(v));
@@ -398,6 +416,15 @@ void finalize_seg(H* h) {
     h->conv[i] = make_lin(h, wp, nullptr, co, k * cip, h->Cp[i], k * cip);
     h->conv[i].Kt = k * ci;
     if (c.extractor_layer_norm) h->conv_ln[i] = ln_from_sd(h, pre + ".layer_norm", co);
+    if (i == 1 && c.precision == DZN_PREC_F32_H2 && c.extractor_layer_norm && h->conv0_lnq && c.conv_k[0] == 10 &&
+        c.conv_s[0] == 5 && k == 3 && c.conv_s[1] == 2 && h->C[0] % 64 == 0 && h->Cp[0] == h->C[0] &&
+        h->Cp[1] == 160 && !getenv("DZN_NO_CONV01_FUSION")) {
+      h->conv1_W2n = dalloc<u16>(h, (int64_t)2 * h->Cp[1] * k * cip, false);
+      h->conv1_wscn = dalloc<float>(h, h->Cp[1], false);
+      if (launch_split_weights_h2_natural(h->conv[1].W, h->Cp[1], k * cip, h->conv1_W2n, h->conv1_wscn, nullptr) != DZN_OK)
+        throw EngineError(DZN_E_HIP, "split_weights_h2_natural launch failed");
+      HIPCHK(hipDeviceSynchronize());
+    }
   }
   const int last = c.n_conv - 1;
   {
@@ -962,9 +989,13 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     chk(launch_wave_stats(wave, B, N, 1e-5f, h->stats, st), "wave_stats");
     stats = h->stats;
   }
-  if (lnx) {
+  // DZN_PREC_F32_H2: conv0 + LN + GELU + conv1 in one kernel (frontend_fused.hip): conv0's 52 MB / window never
+  // reach HBM.  (debug taps need the intermediate -> unfused)
+  const bool fuse01 = c.precision == DZN_PREC_F32_H2 && lnx && h->conv1_W2n && !h->debug && c.n_conv > 1 && T[1] > 0;
+  if (lnx && fuse01) {
+  } else if (lnx) {
     chk(launch_conv0(wave, B, N, stats, h->conv0_w, h->conv_ln[0].g, h->conv_ln[0].b, h->C[0], h->Cp[0],
-                     c.conv_k[0], c.conv_s[0], T[0], 1, 1e-5f, h->bufA, lp, st),
+                     c.conv_k[0], c.conv_s[0], T[0], 1, 1e-5f, h->bufA, lp, st, h->conv0_lnq),
         "conv0");
   } else {
     float* raw = lp ? h->craw : h->bufA;
@@ -989,7 +1020,12 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     if (!lnx) d.act = DZN_ACT_GELU;
     if (i > 1 || lnx) d.a_amax = am(conv_slot(cur));   // (group-norm conv0 has neither tracker nor bound: bf16 split)
     if (!lnx) d.c_amax = am(conv_slot(nxt));
-    gemm(d, lp, lp && !lnx, "conv gemm");
+    if (i == 1 && fuse01)
+      chk(launch_conv01_fused(wave, B, N, stats, h->conv0_w, h->conv_ln[0].g, h->conv_ln[0].b, h->conv0_lnq, h->C[0],
+                              T[0], T[1], h->conv1_W2n, h->conv1_wscn, h->Cp[1], h->conv0_bound, 1e-5f, dst, st),
+          "conv01 fused");
+    else
+      gemm(d, lp, lp && !lnx, "conv gemm");
     if (lnx)  // channel LayerNorm + GELU (+ dummy_weight after the last conv, components.py:208)
       ln_t(dst, false, h->Cp[i], nxt, lp, h->Cp[i], h->conv_ln[i], (int64_t)B * T[i], h->Cp[i], 1, st,
            i == last ? h->dummy_w : nullptr, am(conv_slot(nxt)), T[i]);

@@ -24,8 +24,10 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, int C0, int Cp,
                                                     int k, int s, int T0, float eps,
-                                                    TO* __restrict__ out) {
+                                                    TO* __restrict__ out,
+                                                    const float* __restrict__ lnq /* [10 + 100] or null */) {
   __shared__ float sx[FR_PER_BLOCK * 8 + 32];
+  __shared__ float2 sst[FR_PER_BLOCK];   // per-frame (mean, rstd) of the channel LayerNorm
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * FR_PER_BLOCK;
   const int tid = threadIdx.x, lane = tid & 63, wave_id = tid >> 6;
@@ -51,6 +53,26 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
     br[j] = (LN && c < C0) ? beta[c] : 0.f;
   }
   __syncthreads();
+  // LayerNorm statistics of a frame WITHOUT touching its C0 outputs: y_c = w_c . x (x = the frame's k samples), so
+  //   mean_c y = wbar . x   and   var_c y = x^T Q x   with wbar = mean_c w_c, Q = cov_c(w_c) (k x k, PSD, built in
+  // double at weight-load time).  One thread per frame here; the frame loop below has no cross-lane reductions left.
+  const bool qstats = LN && lnq != nullptr;
+  if (qstats && tid < nfr) {
+    float xv[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) xv[t] = t < k ? sx[tid * s + t] : 0.f;
+    float mu = 0.f, var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      mu = fmaf(lnq[i], xv[i], mu);
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) q = fmaf(lnq[10 + i * 10 + j], xv[j], q);
+      var = fmaf(q, xv[i], var);
+    }
+    sst[tid] = make_float2(mu, 1.0f / sqrtf(fmaxf(var, 0.f) + eps));
+  }
+  if (qstats) __syncthreads();
 
   for (int f = wave_id; f < nfr; f += 4) {
     float xv[10];
@@ -68,7 +90,11 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
     }
     TO* op = out + ((int64_t)b * T0 + f0 + f) * Cp;
     float mu = 0.f, rs = 1.f;
-    if constexpr (LN) {
+    if (qstats) {
+      const float2 st2 = sst[f];
+      mu = st2.x;
+      rs = st2.y;
+    } else if constexpr (LN) {
       mu = wave_sum(sum) / (float)C0;
       float sq = 0.f;
 #pragma unroll
@@ -209,17 +235,17 @@ inline unsigned grid_for(int64_t n, int per = 256, int cap = 4096) {
 template <typename TO>
 int conv0_dispatch(const float* wave, int B, int N, const float* stats, const float* w,
                    const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
-                   int layer_norm, float eps, TO* out, hipStream_t st) {
+                   int layer_norm, float eps, TO* out, hipStream_t st, const float* lnq) {
   dim3 grid((T0 + FR_PER_BLOCK - 1) / FR_PER_BLOCK, B);
   const int width = max(C0, Cp);   // a lane owns 4 consecutive channels per 256-channel group
 #define DZN_C0(CPLV)                                                                                  \
   do {                                                                                                \
     if (layer_norm)                                                                                   \
       hipLaunchKernelGGL((conv0_kernel<CPLV, true, TO>), grid, dim3(256), 0, st, wave, N, stats, w,   \
-                         gamma, beta, C0, Cp, k, s, T0, eps, out);                                    \
+                         gamma, beta, C0, Cp, k, s, T0, eps, out, lnq);                               \
     else                                                                                              \
       hipLaunchKernelGGL((conv0_kernel<CPLV, false, TO>), grid, dim3(256), 0, st, wave, N, stats, w,  \
-                         gamma, beta, C0, Cp, k, s, T0, eps, out);                                    \
+                         gamma, beta, C0, Cp, k, s, T0, eps, out, lnq);                               \
   } while (0)
   if (width <= 256) DZN_C0(4);
   else DZN_C0(8);
@@ -231,7 +257,7 @@ int conv0_dispatch(const float* wave, int B, int N, const float* stats, const fl
 
 int launch_conv0(const float* wave, int B, int N, const float* stats, const float* w,
                  const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
-                 int layer_norm, float eps, void* out, int out_bf16, hipStream_t st) {
+                 int layer_norm, float eps, void* out, int out_bf16, hipStream_t st, const float* lnq) {
   if (k > 10 || C0 > 512 || s > 8) return DZN_E_INVALID;
   // algorithmic HBM bytes: read the waveform once, write the [T0, C0] activations once
   const double esz = out_bf16 ? 2.0 : 4.0;
@@ -240,10 +266,10 @@ int launch_conv0(const float* wave, int B, int N, const float* stats, const floa
   int rc;
   if (out_bf16)
     rc = conv0_dispatch(wave, B, N, stats, w, gamma, beta, C0, Cp, k, s, T0, layer_norm, eps,
-                        static_cast<u16*>(out), st);
+                        static_cast<u16*>(out), st, lnq);
   else
     rc = conv0_dispatch(wave, B, N, stats, w, gamma, beta, C0, Cp, k, s, T0, layer_norm, eps,
-                        static_cast<float*>(out), st);
+                        static_cast<float*>(out), st, lnq);
   prof_end(pid, st);
   return rc;
 }

@@ -1,0 +1,231 @@
+// frontend_fused.hip — conv0 -> conv1 of the WavLM feature extractor in ONE kernel (DZN_PREC_F32_H2):
+//
+//     waveform --[window LN]--> conv0 (k 10, s 5) --> LayerNorm over C0 --> erf-GELU  ==(LDS)==>  conv1 (k 3, s 2)
+//     W2V/model.py:113, W2V/components.py:119-122, :63-70, :182-209
+//
+// Unfused, conv0's [T0 = 25 599, 512] fp32 activations are written to HBM (52.4 MB per 8 s window, 13.2 GB per
+// batch of 256) and read straight back as the A operand of conv1's contraction.  Here a workgroup owns 128 conv1
+// output frames of one window: it recomputes the 257 conv0 frames they touch, 64 channels at a time, as TWO fp16 planes
+// (the two-term split of gemm_split.hip, scaled by the exact power of two of conv0's static bound) in LDS, and feeds
+// conv1's MFMAs from there.  Only the waveform (0.5 MB / window) is read and conv1's raw output ([T1, Cp1] fp32,
+// 8.2 MB / window) is written.
+//
+//   * LayerNorm statistics of a conv0 frame come from its 10 input samples: mean_c y = wbar . x, var_c y = x^T Q x
+//     (wbar / Q = mean / covariance over channels of the taps, built in double at load) -> no pass over the 512
+//     outputs, so a 64-channel slab can be normalised on its own.
+//   * K order of conv1 is (tap j, channel c) -> k = j * C0 + c, natural order inside every 32-block (the planes are
+//     written by lanes that own one channel each); the fp16 weight planes W2h [Cp1][K/32][2][32] are split in that
+//     order by split_weights_h2_natural_kernel.  A fragments: frame 2 t + j, 16-byte slot (kb * 4 + lq) ^ ((frame >> 1)
+//     & 7): the 16 lanes of a fragment read 8 distinct slots (rows two frames apart would all hit the same banks).
+//   * phases per 64-channel slab: [VALU] 4 wavefronts x 65 frames x 64 lanes = conv0 + LN + GELU + split -> LDS;
+//     [MFMA] 2 x 2 wavefronts, 64 x 80 outputs each, 6 k-steps (3 taps x 2 blocks), W fragments straight from L2 into
+//     registers (the slab's W would not fit LDS next to the planes).  Two workgroups per CU (74 KB of LDS each), so one
+//     multiplies while the other computes activations.
+#include "common.h"
+#include "split.h"
+
+namespace {
+
+constexpr int FF_BM = 128;                 // conv1 output frames per workgroup
+constexpr int FF_FR = 2 * FF_BM + 1;       // conv0 frames they read (k 3, s 2)
+constexpr int FF_ROW = 128;                // bytes per frame per plane: 64 channels fp16
+constexpr int FF_PLANE = (FF_FR + 3) * FF_ROW;
+
+struct FusedArgs {
+  const float* wave;      // [B, N]
+  const float* wstats;    // [B, 2] waveform (mean, rstd) or null
+  const float* w0;        // [C0, k0]
+  const float* gamma0;    // [C0]
+  const float* beta0;     // [C0]
+  const float* lnq;       // [10 + 100]
+  const u16* W2h;         // conv1 fp16 planes, natural k order: [N1p][K/32][2][32], K = 3 * C0
+  const float* col_scale; // [N1p]
+  float* out;             // [B, T1, N1p] raw conv1 output
+  int N, T0, T1, C0, N1p;
+  float eps, a_scale, a_inv;   // power-of-two scale of the conv0 activations (from their static bound) and inverse
+};
+
+__global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* pl0 = smem;                                   // hi plane  [FF_FR][64 ch] fp16, slots swizzled
+  unsigned char* pl1 = smem + FF_PLANE;                        // lo plane
+  float* sx = reinterpret_cast<float*>(smem + 2 * FF_PLANE);   // normalised samples of the strip
+  float2* sst = reinterpret_cast<float2*>(sx + (5 * (FF_FR - 1) + 10 + 6));   // (mean, rstd) per conv0 frame
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.y;
+  const int t1_0 = blockIdx.x * FF_BM;                 // first conv1 frame of the tile
+  const int f0 = 2 * t1_0;                             // first conv0 frame
+  const int nfr = min(FF_FR, a.T0 - f0);               // conv0 frames that exist
+  const int nsamp = 5 * (nfr - 1) + 10;
+  const float wmean = a.wstats ? a.wstats[2 * b] : 0.f;
+  const float wrstd = a.wstats ? a.wstats[2 * b + 1] : 1.f;
+  const float* wp = a.wave + (int64_t)b * a.N + (int64_t)f0 * 5;
+  for (int i = tid; i < nsamp; i += 256) sx[i] = (wp[i] - wmean) * wrstd;
+  __syncthreads();
+  for (int f = tid; f < nfr; f += 256) {     // LayerNorm statistics from the 10 samples of the frame (see header)
+    float xv[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) xv[t] = sx[f * 5 + t];
+    float mu = 0.f, var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      mu = fmaf(a.lnq[i], xv[i], mu);
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) q = fmaf(a.lnq[10 + i * 10 + j], xv[j], q);
+      var = fmaf(q, xv[i], var);
+    }
+    sst[f] = make_float2(mu, 1.0f / sqrtf(fmaxf(var, 0.f) + a.eps));
+  }
+
+  // MFMA roles: 2 x 2 wavefronts over the 128 x 160 tile
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int MI = 4, NI = 5;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int KB = 3 * a.C0 / 32;            // 32-blocks of conv1's K
+  const int nslab = a.C0 / 64;
+
+  for (int slab = 0; slab < nslab; ++slab) {
+    __syncthreads();   // statistics written (first slab) / previous slab's planes fully consumed
+    // ---- VALU phase: conv0 + LayerNorm + GELU + two-term split of channel (slab * 64 + lane), frames wave, wave + 4, ..
+    {
+      const int ch = slab * 64 + lane;
+      float w0[10];
+#pragma unroll
+      for (int t = 0; t < 10; ++t) w0[t] = a.w0[ch * 10 + t];
+      const float g0 = a.gamma0[ch], b0 = a.beta0[ch];
+      const int cslot = lane >> 3, cbyte = (lane & 7) * 2;
+      for (int f = wave; f < FF_FR; f += 4) {
+        float o = 0.f;
+        if (f < nfr) {
+          float acc0 = 0.f;
+#pragma unroll
+          for (int t = 0; t < 10; ++t) acc0 = fmaf(sx[f * 5 + t], w0[t], acc0);
+          const float2 st = sst[f];
+          o = gelu_erf((acc0 - st.x) * st.y * g0 + b0);
+        }
+        const float xs = o * a.a_scale;
+        const _Float16 hi = (_Float16)xs;
+        const _Float16 lo = (_Float16)(xs - (float)hi);
+        const int off = f * FF_ROW + ((cslot ^ ((f >> 1) & 7)) << 4) + cbyte;
+        *reinterpret_cast<_Float16*>(pl0 + off) = hi;
+        *reinterpret_cast<_Float16*>(pl1 + off) = lo;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA phase: 3 taps x 2 blocks of 32 channels ----
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int kblk = j * (a.C0 / 32) + slab * 2 + kb;
+        u32x4 wf[NI][2];
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) {
+          const int n = wn * 80 + jn * 16 + lr;
+          const u16* wpn = a.W2h + ((int64_t)n * KB + kblk) * 64 + lq * 8;
+          wf[jn][0] = *reinterpret_cast<const u32x4*>(wpn);
+          wf[jn][1] = *reinterpret_cast<const u32x4*>(wpn + 32);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int f = 2 * (wm * 64 + i * 16 + lr) + j;
+          const int off = f * FF_ROW + (((kb * 4 + lq) ^ ((f >> 1) & 7)) << 4);
+          u32x4 af[2];
+          af[0] = *reinterpret_cast<const u32x4*>(pl0 + off);
+          af[1] = *reinterpret_cast<const u32x4*>(pl1 + off);
+#pragma unroll
+          for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+            for (int jn = 0; jn < NI; ++jn)
+              acc[i][jn] = mfma_np<2>(wf[jn][SplitTerms<2>::A[tt]], af[SplitTerms<2>::B[tt]], acc[i][jn]);
+        }
+      }
+  }
+
+  // ---- epilogue: lane (lr, lq) of block (i, jn) holds frame t1_0 + wm*64 + i*16 + lr, channels n0 .. n0 + 3 ----
+  float* ob = a.out + (int64_t)b * a.T1 * a.N1p;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int t1 = t1_0 + wm * 64 + i * 16 + lr;
+    if (t1 >= a.T1) continue;
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) {
+      const int n0 = wn * 80 + jn * 16 + lq * 4;
+      const float4 c4 = *reinterpret_cast<const float4*>(a.col_scale + n0);
+      const f32x4 v = acc[i][jn];
+      *reinterpret_cast<float4*>(ob + (int64_t)t1 * a.N1p + n0) =
+          make_float4(v[0] * a.a_inv * c4.x, v[1] * a.a_inv * c4.y, v[2] * a.a_inv * c4.z, v[3] * a.a_inv * c4.w);
+    }
+  }
+}
+
+// W [rows][K] fp32 -> fp16 planes [rows][K/32][2][32] in NATURAL k order (the fused kernel writes its A planes channel
+// by channel), w * 2^e_row with max |row| in [2^14, 2^15); col_scale[row] = 2^-e_row
+__global__ __launch_bounds__(256) void split_weights_h2_natural_kernel(const float* __restrict__ W, int64_t rows, int K,
+                                                                       u16* __restrict__ W2, float* __restrict__ col_scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float m = 0.f;
+  for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(W[r * K + k]));
+  m = wave_max(m);
+  float sc, inv;
+  h2_scale(m, sc, inv);
+  if (lane == 0) col_scale[r] = inv;
+  for (int k = lane; k < K; k += 64) {
+    const float x = W[r * K + k] * sc;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    u16* o = W2 + r * 2 * K + (int64_t)(k >> 5) * 64 + (k & 31);
+    o[0] = __builtin_bit_cast(u16, h);
+    o[32] = __builtin_bit_cast(u16, l);
+  }
+}
+
+}  // namespace
+
+int launch_split_weights_h2_natural(const float* W, int64_t rows, int K, void* W2, float* col_scale, hipStream_t s) {
+  if (rows <= 0) return DZN_OK;
+  if (K <= 0 || (K & 31)) return DZN_E_INVALID;
+  hipLaunchKernelGGL(split_weights_h2_natural_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, W, rows, K,
+                     static_cast<u16*>(W2), col_scale);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+// conv0 (k 10, s 5, C0 % 64 == 0) + LN + GELU + conv1 (k 3, s 2, 160 padded outputs): out = raw conv1 [B, T1, 160]
+int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, const float* w0, const float* gamma0,
+                        const float* beta0, const float* lnq, int C0, int T0, int T1, const void* W2h,
+                        const float* col_scale, int N1p, float act_bound, float eps, float* out, hipStream_t st) {
+  if (B <= 0 || T1 <= 0) return DZN_OK;
+  if ((C0 & 63) || N1p != 160 || !lnq || !W2h || !col_scale || !(act_bound > 0.f)) return DZN_E_INVALID;
+  FusedArgs a{};
+  a.wave = wave; a.wstats = wstats; a.w0 = w0; a.gamma0 = gamma0; a.beta0 = beta0; a.lnq = lnq;
+  a.W2h = static_cast<const u16*>(W2h); a.col_scale = col_scale; a.out = out;
+  a.N = N; a.T0 = T0; a.T1 = T1; a.C0 = C0; a.N1p = N1p; a.eps = eps;
+  {   // exact power-of-two scale that puts the bound into [2^14, 2^15)
+    int e;
+    (void)frexpf(act_bound, &e);          // act_bound = m * 2^e, m in [0.5, 1)
+    a.a_scale = ldexpf(1.0f, 15 - e);
+    a.a_inv = ldexpf(1.0f, e - 15);
+  }
+  const size_t lds = 2 * FF_PLANE + sizeof(float) * (5 * (FF_FR - 1) + 10 + 6) + sizeof(float2) * FF_FR;
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(attr_mask))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  dim3 grid((T1 + FF_BM - 1) / FF_BM, B);
+  // algorithmic work: conv0 + conv1 flops; algorithmic HBM bytes: waveform in, conv1's raw output out
+  const int pid = prof_begin(st, "conv01_fused", 2.0 * B * ((double)T0 * C0 * 10 + (double)T1 * 153.0 * 3 * C0),
+                             B * (4.0 * N + 4.0 * (double)T1 * N1p));
+  hipLaunchKernelGGL(conv01_fused_kernel, grid, dim3(256), lds, st, a);
+  prof_end(pid, st);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}

@@ -196,3 +196,34 @@ def test_seg_bf16_group_norm_models(built_lib, gpu, name):
     margin = top2[..., 0] - top2[..., 1]
     assert (margin[differ] <= 2e-1).all()
     assert differ.float().mean().item() <= 0.03
+
+
+def test_conv01_fusion_matches_unfused(built_lib, gpu, monkeypatch):
+    """frontend_fused.hip (f32h): conv0 + LN + GELU + conv1 in one kernel (conv0's activations never reach HBM) against
+    the same engine with the fusion switched off — both run through the oracle-checked f32h path; windows of different
+    lengths exercise the ragged last tile (T1 % 128 != 0) and conv0 frames past the end of the strip."""
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from diarizen_amd.weights import turn_taking_state_dict
+    from oracle import seg_model
+    from oracle.gen_golden import tt_windows
+    cfg = get_seg_config("wavlm_large_s80_md")
+    sd = turn_taking_state_dict(cfg, 0)
+    for N in (128000, 33333):
+        wave = tt_windows([0, 100000, 250000], N)
+        fused = Engine(cfg, sd, max_batch=3, max_samples=N, precision="f32h", device=gpu)
+        monkeypatch.setenv("DZN_NO_CONV01_FUSION", "1")
+        plain = Engine(cfg, sd, max_batch=3, max_samples=N, precision="f32h", device=gpu)
+        monkeypatch.delenv("DZN_NO_CONV01_FUSION")
+        lf, mf = fused.segment(wave.to(gpu))
+        lp_, mp = plain.segment(wave.to(gpu))
+        torch.cuda.synchronize()
+        d = (lf - lp_).abs().max().item()
+        print(f"N={N}: max |logp fused - unfused| = {d:.2e}")
+        assert d <= 2e-4
+        assert torch.equal(mf, mp)
+        if N == 33333:
+            ref = seg_model.seg_forward(sd, cfg, wave)
+            assert (lf.cpu() - ref).abs().max().item() <= 1e-3
+        fused.close()
+        plain.close()
