@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a)
 
   for (int slab = 0; slab < nslab; ++slab) {
     __syncthreads();   // statistics written (first slab) / previous slab's planes fully consumed
-    // ---- VALU phase: conv0 + LayerNorm + GELU + two-term split of channel (slab * 64 + lane), frames wave, wave + 4, ..
+    // ---- VALU phase: conv0 + LayerNorm + GELU + two-term split of channel (slab * 64 + lane).  A wavefront takes
+    // frames wave, wave + 4, ...; FOUR of them per iteration so that the long dependent chains (10 FMAs -> LayerNorm ->
+    // erf) of different frames interleave — with one frame at a time the chain latency, not the VALU rate, set the pace.
     {
       const int ch = slab * 64 + lane;
       float w0[10];
@@ -102,52 +104,74 @@ __global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a)
       for (int t = 0; t < 10; ++t) w0[t] = a.w0[ch * 10 + t];
       const float g0 = a.gamma0[ch], b0 = a.beta0[ch];
       const int cslot = lane >> 3, cbyte = (lane & 7) * 2;
-      for (int f = wave; f < FF_FR; f += 4) {
-        float o = 0.f;
-        if (f < nfr) {
+      constexpr int UF = 4;
+      for (int fb = wave; fb < FF_FR; fb += 4 * UF) {
+        float o[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+          const int f = fb + 4 * u;
+          const int fc = f < nfr ? f : nfr - 1;            // clamped: results of frames past the strip are zeroed below
           float acc0 = 0.f;
 #pragma unroll
-          for (int t = 0; t < 10; ++t) acc0 = fmaf(sx[f * 5 + t], w0[t], acc0);
-          const float2 st = sst[f];
-          o = gelu_erf((acc0 - st.x) * st.y * g0 + b0);
+          for (int t = 0; t < 10; ++t) acc0 = fmaf(sx[fc * 5 + t], w0[t], acc0);
+          const float2 st = sst[fc];
+          o[u] = (acc0 - st.x) * st.y * g0 + b0;
         }
-        const float xs = o * a.a_scale;
-        const _Float16 hi = (_Float16)xs;
-        const _Float16 lo = (_Float16)(xs - (float)hi);
-        const int off = f * FF_ROW + ((cslot ^ ((f >> 1) & 7)) << 4) + cbyte;
-        *reinterpret_cast<_Float16*>(pl0 + off) = hi;
-        *reinterpret_cast<_Float16*>(pl1 + off) = lo;
+#pragma unroll
+        for (int u = 0; u < UF; ++u) o[u] = gelu_erf(o[u]);
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+          const int f = fb + 4 * u;
+          if (f < FF_FR) {                                  // wave-uniform
+            const float xs = (f < nfr ? o[u] : 0.f) * a.a_scale;
+            const _Float16 hi = (_Float16)xs;
+            const _Float16 lo = (_Float16)(xs - (float)hi);
+            const int off = f * FF_ROW + ((cslot ^ ((f >> 1) & 7)) << 4) + cbyte;
+            *reinterpret_cast<_Float16*>(pl0 + off) = hi;
+            *reinterpret_cast<_Float16*>(pl1 + off) = lo;
+          }
+        }
       }
     }
     __syncthreads();
-    // ---- MFMA phase: 3 taps x 2 blocks of 32 channels ----
+    // ---- MFMA phase: 6 k-steps = 3 taps x 2 blocks of 32 channels; the W fragments of step ks + 1 are fetched
+    // (L2 -> registers) while step ks multiplies ----
+    auto load_w = [&](int ks, u32x4 (&wf)[NI][2]) {
+      const int j = ks >> 1, kb = ks & 1;
+      const int kblk = j * (a.C0 / 32) + slab * 2 + kb;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int kblk = j * (a.C0 / 32) + slab * 2 + kb;
-        u32x4 wf[NI][2];
-#pragma unroll
-        for (int jn = 0; jn < NI; ++jn) {
-          const int n = wn * 80 + jn * 16 + lr;
-          const u16* wpn = a.W2h + ((int64_t)n * KB + kblk) * 64 + lq * 8;
-          wf[jn][0] = *reinterpret_cast<const u32x4*>(wpn);
-          wf[jn][1] = *reinterpret_cast<const u32x4*>(wpn + 32);
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int f = 2 * (wm * 64 + i * 16 + lr) + j;
-          const int off = f * FF_ROW + (((kb * 4 + lq) ^ ((f >> 1) & 7)) << 4);
-          u32x4 af[2];
-          af[0] = *reinterpret_cast<const u32x4*>(pl0 + off);
-          af[1] = *reinterpret_cast<const u32x4*>(pl1 + off);
-#pragma unroll
-          for (int tt = 0; tt < 3; ++tt)
-#pragma unroll
-            for (int jn = 0; jn < NI; ++jn)
-              acc[i][jn] = mfma_np<2>(wf[jn][SplitTerms<2>::A[tt]], af[SplitTerms<2>::B[tt]], acc[i][jn]);
-        }
+      for (int jn = 0; jn < NI; ++jn) {
+        const int n = wn * 80 + jn * 16 + lr;
+        const u16* wpn = a.W2h + ((int64_t)n * KB + kblk) * 64 + lq * 8;
+        wf[jn][0] = *reinterpret_cast<const u32x4*>(wpn);
+        wf[jn][1] = *reinterpret_cast<const u32x4*>(wpn + 32);
       }
+    };
+    auto mma_step = [&](int ks, const u32x4 (&wf)[NI][2]) {
+      const int j = ks >> 1, kb = ks & 1;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int f = 2 * (wm * 64 + i * 16 + lr) + j;
+        const int off = f * FF_ROW + (((kb * 4 + lq) ^ ((f >> 1) & 7)) << 4);
+        u32x4 af[2];
+        af[0] = *reinterpret_cast<const u32x4*>(pl0 + off);
+        af[1] = *reinterpret_cast<const u32x4*>(pl1 + off);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+          for (int jn = 0; jn < NI; ++jn)
+            acc[i][jn] = mfma_np<2>(wf[jn][SplitTerms<2>::A[tt]], af[SplitTerms<2>::B[tt]], acc[i][jn]);
+      }
+    };
+    u32x4 wfa[NI][2], wfb[NI][2];
+    load_w(0, wfa);
+#pragma unroll
+    for (int ks = 0; ks < 6; ks += 2) {
+      load_w(ks + 1, wfb);
+      mma_step(ks, wfa);
+      if (ks + 2 < 6) load_w(ks + 2, wfa);
+      mma_step(ks + 1, wfb);
+    }
   }
 
   // ---- epilogue: lane (lr, lq) of block (i, jn) holds frame t1_0 + wm*64 + i*16 + lr, channels n0 .. n0 + 3 ----
