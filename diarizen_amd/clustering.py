@@ -94,9 +94,23 @@ def filter_embeddings(embeddings: np.ndarray, seg: np.ndarray, min_frames_ratio:
 def constrained_argmax(soft: np.ndarray) -> np.ndarray:
     """per window: Hungarian assignment of local speakers to clusters (maximise similarity)."""
     soft = np.nan_to_num(soft, nan=np.nanmin(soft))
-    C, S, _ = soft.shape
+    C, S, K = soft.shape
     hard = -2 * np.ones((C, S), dtype=np.int8)
-    for c in range(C):
+    todo = np.arange(C)
+    if K >= S and C > 64:
+        # Vectorised exact shortcut (row f1: 17 991 windows at 4 h): when every local speaker's best cluster is
+        # STRICTLY best and the S best clusters are distinct, that assignment attains the upper bound sum_s max_k and is
+        # the unique optimum, so the Hungarian solver must return it.  Everything else (ties, conflicts — e.g. several
+        # inactive speakers sharing the bias embedding) goes through scipy as in the reference.
+        best = soft.argmax(axis=2)                                            # [C, S]
+        part = np.partition(soft, K - 2, axis=2) if K > 1 else None
+        strict = (part[:, :, K - 1] > part[:, :, K - 2]).all(axis=1) if K > 1 else np.ones(C, bool)
+        srt = np.sort(best, axis=1)
+        distinct = (srt[:, 1:] != srt[:, :-1]).all(axis=1) if S > 1 else np.ones(C, bool)
+        easy = strict & distinct
+        hard[easy] = best[easy].astype(np.int8)
+        todo = np.nonzero(~easy)[0]
+    for c in todo:
         spk, clu = linear_sum_assignment(soft[c], maximize=True)
         hard[c, spk] = clu
     return hard

@@ -1,27 +1,28 @@
+# Round-2 measurement set (MI355X, 1 GPU).  Outputs under gpurun_out/final/, copied to profiles/r2_* afterwards.
+# PART=a : headline bench (+ other modes, e2e, cpu baseline), rocprofv3 kernel stats, the three PMC passes
+# PART=b : BASELINE configs[1] (base-s80 5 s x 32, segmentation only), 4 h single-GPU end to end, decision parity 256
 set -x
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/final
+O=$R/gpurun_out/final
+mkdir -p $O
 cd $R
-python bench.py > gpurun_out/final/bench_f32s.json 2> gpurun_out/final/bench.err
-python bench.py --precision bf16 --no-cpu-baseline --no-alt > gpurun_out/final/bench_bf16.json 2>> gpurun_out/final/bench.err; python bench.py --precision f32 --no-cpu-baseline --no-alt > gpurun_out/final/bench_f32.json 2>> gpurun_out/final/bench.err
+if [ "${PART:-a}" = "a" ]; then
+python bench.py > $O/bench_f32h.json 2> $O/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/kt -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt > $R/gpurun_out/final/bench_under_rocprof.json 2> $R/gpurun_out/final/kt.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-profile > /dev/null 2> $R/gpurun_out/final/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-profile > /dev/null 2> $R/gpurun_out/final/pmc_write.err
-rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_mfma -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-profile > /dev/null 2> $R/gpurun_out/final/pmc_mfma.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-e2e > $O/bench_under_rocprof.json 2> $O/kt.err
+for C in FETCH_SIZE WRITE_SIZE MfmaUtil; do
+rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-e2e --no-profile > /dev/null 2> $O/pmc_$C.err
+done
 cd $R
-U=$(find gpurun_out/final/pmc_mfma -name '*counter_collection.csv' | head -1)
-python scripts/pmc_mfma.py $U gpurun_out/final/pmc_mfma_util_f32s_b256.json
-F=$(find gpurun_out/final/pmc_fetch -name '*counter_collection.csv' | head -1)
-W=$(find gpurun_out/final/pmc_write -name '*counter_collection.csv' | head -1)
-python scripts/pmc_traffic.py $F $W gpurun_out/final/pmc_traffic_f32s_b256.json
-S=$(find gpurun_out/final/kt -name '*kernel_stats.csv' | head -1)
-cp $S gpurun_out/final/kernel_stats.csv
-# big raw traces do not need to come back
-find gpurun_out/final -name '*kernel_trace.csv' -delete
-find gpurun_out/final -name '*counter_collection.csv' -delete
-find gpurun_out/final -name '*agent_info.csv' -delete
-head -12 gpurun_out/final/kernel_stats.csv
-cat gpurun_out/final/bench_f32s.json | cut -c1-1500
-cat gpurun_out/final/bench_bf16.json | cut -c1-600
+python scripts/pmc_summary.py $O/pmc_f32h_30min_b256.json $(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) $(find $O/pmc_MfmaUtil -name '*counter_collection.csv' | head -1)
+cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*counter_collection.csv' -delete; find $O -name '*agent_info.csv' -delete
+head -14 $O/kernel_stats.csv
+cut -c1-1800 $O/bench_f32h.json
+else
+python bench.py --model wavlm_base_s80_md --window 5 --batch 32 --stage seg --minutes 30 --steps 3 --warmup 1 --no-alt > $O/bench_base_s80_5s_b32.json 2> $O/bench_base.err
+cut -c1-900 $O/bench_base_s80_5s_b32.json
+python scripts/e2e_timing.py 240 256 > $O/e2e_4h.log 2>&1; grep -m1 "^timings" $O/e2e_4h.log
+DZN_DECISION_WINDOWS=256 python -m pytest tests/test_decisions_gpu.py -m gpu -q 2>&1 | tail -3; cp gpurun_out/decision_parity.json $O/decision_parity_256.json
+fi

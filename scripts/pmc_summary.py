@@ -1,11 +1,40 @@
-"""Aggregate a rocprofv3 --pmc counter_collection.csv per kernel name substring."""
-import csv, collections, sys
-path, pat = sys.argv[1], sys.argv[2]
-rows = list(csv.DictReader(open(path)))
-agg = collections.defaultdict(float); disp = set()
-for r in rows:
-    if pat in r["Kernel_Name"]:
-        agg[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
-print("dispatches", len(disp))
-for k, v in sorted(agg.items()):
-    print(f"{k:32s} {v:.4g}  per-dispatch {v/len(disp):.4g}")
+"""Merge rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, MfmaUtil; one pass each) into one table per kernel symbol:
+    hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB   (gfx950: FETCH_SIZE counts 64 B per 128-B request on wide
+                           coalesced reads -> doubled, MI355X_MICROARCH.md HBM section; both counters are in KiB)
+    mfma_util_pct        = mean MfmaUtil (percent of SIMD cycles with the matrix pipe busy)
+usage: pmc_summary.py out.json fetch.csv write.csv mfma.csv"""
+import collections
+import csv
+import json
+import statistics
+import sys
+
+outp, fetch, write, mfma = sys.argv[1:5]
+
+
+def clean(n):
+    return n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+
+
+out = collections.defaultdict(dict)
+for tag, path in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write), ("MfmaUtil", mfma)):
+    vals = collections.defaultdict(list)
+    try:
+        rows = csv.DictReader(open(path))
+    except OSError:
+        continue
+    for r in rows:
+        if r["Counter_Name"] == tag:
+            vals[clean(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for n, v in vals.items():
+        out[n]["launches"] = len(v)
+        if tag == "MfmaUtil":
+            out[n]["mfma_util_pct"] = round(statistics.fmean(v), 2)
+        else:
+            out[n][tag + "_KiB_per_launch"] = round(statistics.fmean(v), 1)
+for n, e in out.items():
+    if "FETCH_SIZE_KiB_per_launch" in e or "WRITE_SIZE_KiB_per_launch" in e:
+        e["hbm_bytes_per_launch"] = int((2.0 * e.get("FETCH_SIZE_KiB_per_launch", 0.0) + e.get("WRITE_SIZE_KiB_per_launch", 0.0)) * 1024)
+json.dump(out, open(outp, "w"), indent=1, sort_keys=True)
+for n, e in sorted(out.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0) * kv[1].get("launches", 0))[:14]:
+    print(n, e)
