@@ -47,9 +47,11 @@ from diarizen_amd.synth import synth_recording  # noqa: E402
 
 
 # in-situ profiler class -> kernel symbol in the rocprofv3 tables (scripts/pmc_summary.py writes profiles/*.json)
-PMC_SYMBOLS = {"conv0_ln_gelu": "conv0_kernel", "attention_relpos_f32s": "attn_split_kernel<true>",
-               "attention_relpos_f32h": "attn_split_kernel<true>", "attention_f32s": "attn_split_kernel<false>",
-               "conv3x3_c32_f32s": "conv3x3_c32_split_kernel", "layernorm": "layernorm_kernel<16"}
+PMC_SYMBOLS = {"conv0_ln_gelu": "conv0_kernel", "conv01_fused": "conv01_fused_kernel",
+               "attention_relpos_f32s": "attn_split_kernel<true, 3>", "attention_relpos_f32h": "attn_split_kernel<true, 2>",
+               "attention_f32s": "attn_split_kernel<false, 3>", "attention_f32h": "attn_split_kernel<false, 2>",
+               "conv3x3_c32_f32s": "conv3x3_c32_split_kernel<3>", "conv3x3_c32_f32h": "conv3x3_c32_split_kernel<2>",
+               "layernorm": "layernorm_kernel<4", "row_stats": "row_stats_kernel<16>", "gate_ln_stats": "gate_stats_kernel"}
 
 
 def pmc_table(args):
@@ -71,7 +73,12 @@ def pmc_lookup(table, kernel_class: str, field: str):
         if kernel_class.startswith(tag):
             bm, bn = kernel_class[len(tag):].split("x")
             sym = "gemm_split_pre_kernel" if "_pre_" in tag else "gemm_split_kernel"
-            key = next((k for k in table if k.startswith(f"{sym}<{bm}, {bn},") and k.endswith(f", {planes}>")), None)
+            for k in table:     # template arguments: <BM, BN, WGM, WGN, S, NP[, OCC]>
+                if k.startswith(sym + "<"):
+                    targs = [t.strip() for t in k[len(sym) + 1:].rstrip(">").split(",")]
+                    if len(targs) >= 6 and targs[0] == bm and targs[1] == bn and targs[5] == str(planes):
+                        key = k
+                        break
             break
     else:
         sym = PMC_SYMBOLS.get(kernel_class)
@@ -362,6 +369,12 @@ def main():
                     e["frac_of_hbm_peak"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
                 e["pmc_hbm_bytes_per_launch"] = pmc_lookup(traffic, p["name"], "hbm_bytes_per_launch")
                 e["pmc_mfma_util_pct"] = pmc_lookup(traffic, p["name"], "mfma_util_pct")
+                if p["name"] == "conv01_fused":
+                    e["note"] = ("conv0 + LayerNorm + GELU + conv1 fused (frontend_fused.hip): conv0's 13.2 GB / launch of "
+                                 "activations never reach HBM (was conv0_ln_gelu: 13.2 GB written at 2.7-2.8 TB/s = 0.34 of "
+                                 "peak, then re-read by conv1); the kernel is MFMA/VALU-bound, its HBM traffic is the "
+                                 "waveform in + conv1's raw output out (alg_bytes_per_launch; PMC beside it)")
+                    e.pop("frac_of_hbm_peak", None)
                 extra[key] = e
             extra["kernel_ms_per_step"] = round(tot_ms / args.steps, 2)
             extra["non_kernel_frac"] = round(1.0 - tot_ms / args.steps / ms_per_step, 4)
