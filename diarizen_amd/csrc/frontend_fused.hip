@@ -17,10 +17,10 @@
 //     written by lanes that own one channel each); the fp16 weight planes W2h [Cp1][K/32][2][32] are split in that
 //     order by split_weights_h2_natural_kernel.  A fragments: frame 2 t + j, 16-byte slot (kb * 4 + lq) ^ ((frame >> 1)
 //     & 7): the 16 lanes of a fragment read 8 distinct slots (rows two frames apart would all hit the same banks).
-//   * per 64-channel slab: [VALU, wavefronts 0-3] 65 frames x 64 lanes each = conv0 + LN + GELU + split -> LDS planes;
-//     [MFMA, wavefronts 4-7] 2 x 2 over the tile, 64 x 80 outputs each, 6 k-steps (3 taps x 2 blocks), W fragments
-//     straight from L2 into registers (the slab's W would not fit LDS next to the planes).  The planes are double
-//     buffered (140 KB of LDS, one workgroup of 8 wavefronts per CU): slab s + 1 is produced while slab s multiplies.
+//   * phases per 64-channel slab: [VALU] 4 wavefronts x 65 frames x 64 lanes = conv0 + LN + GELU + split -> LDS;
+//     [MFMA] 2 x 2 wavefronts, 64 x 80 outputs each, 6 k-steps (3 taps x 2 blocks), W fragments straight from L2 into
+//     registers (the slab's W would not fit LDS next to the planes).  Two workgroups per CU (74 KB of LDS each), so one
+//     multiplies while the other computes activations.
 #include "common.h"
 #include "split.h"
 
@@ -45,14 +45,11 @@ struct FusedArgs {
   float eps, a_scale, a_inv;   // power-of-two scale of the conv0 activations (from their static bound) and inverse
 };
 
-// 8 wavefronts per workgroup, one workgroup per CU: wavefronts 0-3 PRODUCE the activation planes of slab s + 1 (VALU)
-// while wavefronts 4-7 CONSUME the planes of slab s (MFMA); the planes are double buffered and one barrier per slab
-// hands them over.  Wavefront w and w + 4 share a SIMD, so every SIMD always has VALU work and matrix work in flight
-// (the first version alternated the two phases inside every wavefront and ran at 9-10 ms per launch).
-__global__ __launch_bounds__(512, 1) void conv01_fused_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // [buffer 2][plane 2][FF_PLANE]: hi / lo planes [FF_FR][64 ch] fp16, slots swizzled
-  float* sx = reinterpret_cast<float*>(smem + 4 * FF_PLANE);   // normalised samples of the strip
+  unsigned char* pl0 = smem;                                   // hi plane  [FF_FR][64 ch] fp16, slots swizzled
+  unsigned char* pl1 = smem + FF_PLANE;                        // lo plane
+  float* sx = reinterpret_cast<float*>(smem + 2 * FF_PLANE);   // normalised samples of the strip
   float2* sst = reinterpret_cast<float2*>(sx + (5 * (FF_FR - 1) + 10 + 6));   // (mean, rstd) per conv0 frame
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -66,9 +63,9 @@ __global__ __launch_bounds__(512, 1) void conv01_fused_kernel(const FusedArgs a)
   const float wmean = a.wstats ? a.wstats[2 * b] : 0.f;
   const float wrstd = a.wstats ? a.wstats[2 * b + 1] : 1.f;
   const float* wp = a.wave + (int64_t)b * a.N + (int64_t)f0 * 5;
-  for (int i = tid; i < nsamp; i += 512) sx[i] = (wp[i] - wmean) * wrstd;
+  for (int i = tid; i < nsamp; i += 256) sx[i] = (wp[i] - wmean) * wrstd;
   __syncthreads();
-  for (int f = tid; f < nfr; f += 512) {     // LayerNorm statistics from the 10 samples of the frame (see header)
+  for (int f = tid; f < nfr; f += 256) {     // LayerNorm statistics from the 10 samples of the frame (see header)
     float xv[10];
 #pragma unroll
     for (int t = 0; t < 10; ++t) xv[t] = sx[f * 5 + t];
@@ -83,11 +80,9 @@ __global__ __launch_bounds__(512, 1) void conv01_fused_kernel(const FusedArgs a)
     }
     sst[f] = make_float2(mu, 1.0f / sqrtf(fmaxf(var, 0.f) + a.eps));
   }
-  __syncthreads();
 
-  const bool producer = wave < 4;                      // wave-uniform
-  const int cw = wave & 3;
-  const int wm = cw >> 1, wn = cw & 1;                 // consumers: 2 x 2 wavefronts over the 128 x 160 tile
+  // MFMA roles: 2 x 2 wavefronts over the 128 x 160 tile
+  const int wm = wave >> 1, wn = wave & 1;
   constexpr int MI = 4, NI = 5;
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -97,96 +92,89 @@ __global__ __launch_bounds__(512, 1) void conv01_fused_kernel(const FusedArgs a)
   const int KB = 3 * a.C0 / 32;            // 32-blocks of conv1's K
   const int nslab = a.C0 / 64;
 
-  for (int it = 0; it <= nslab; ++it) {
-    if (producer) {
-      if (it < nslab) {
-        // ---- VALU: conv0 + LayerNorm + GELU + two-term split of channel (it * 64 + lane), frames cw, cw + 4, ...;
-        // four frames per iteration so that their dependent chains (10 FMAs -> LayerNorm -> erf) interleave ----
-        unsigned char* pl0 = smem + (it & 1) * 2 * FF_PLANE;
-        unsigned char* pl1 = pl0 + FF_PLANE;
-        const int ch = it * 64 + lane;
-        float w0[10];
+  for (int slab = 0; slab < nslab; ++slab) {
+    __syncthreads();   // statistics written (first slab) / previous slab's planes fully consumed
+    // ---- VALU phase: conv0 + LayerNorm + GELU + two-term split of channel (slab * 64 + lane).  A wavefront takes
+    // frames wave, wave + 4, ...; FOUR of them per iteration so that the long dependent chains (10 FMAs -> LayerNorm ->
+    // erf) of different frames interleave — with one frame at a time the chain latency, not the VALU rate, set the pace.
+    {
+      const int ch = slab * 64 + lane;
+      float w0[10];
 #pragma unroll
-        for (int t = 0; t < 10; ++t) w0[t] = a.w0[ch * 10 + t];
-        const float g0 = a.gamma0[ch], b0 = a.beta0[ch];
-        const int cslot = lane >> 3, cbyte = (lane & 7) * 2;
-        constexpr int UF = 4;
-        for (int fb = cw; fb < FF_FR; fb += 4 * UF) {
-          float o[UF];
+      for (int t = 0; t < 10; ++t) w0[t] = a.w0[ch * 10 + t];
+      const float g0 = a.gamma0[ch], b0 = a.beta0[ch];
+      const int cslot = lane >> 3, cbyte = (lane & 7) * 2;
+      constexpr int UF = 4;
+      for (int fb = wave; fb < FF_FR; fb += 4 * UF) {
+        float o[UF];
 #pragma unroll
-          for (int u = 0; u < UF; ++u) {
-            const int f = fb + 4 * u;
-            const int fc = f < nfr ? f : nfr - 1;          // clamped: frames past the strip are zeroed below
-            float acc0 = 0.f;
+        for (int u = 0; u < UF; ++u) {
+          const int f = fb + 4 * u;
+          const int fc = f < nfr ? f : nfr - 1;            // clamped: results of frames past the strip are zeroed below
+          float acc0 = 0.f;
 #pragma unroll
-            for (int t = 0; t < 10; ++t) acc0 = fmaf(sx[fc * 5 + t], w0[t], acc0);
-            const float2 st = sst[fc];
-            o[u] = (acc0 - st.x) * st.y * g0 + b0;
-          }
+          for (int t = 0; t < 10; ++t) acc0 = fmaf(sx[fc * 5 + t], w0[t], acc0);
+          const float2 st = sst[fc];
+          o[u] = (acc0 - st.x) * st.y * g0 + b0;
+        }
 #pragma unroll
-          for (int u = 0; u < UF; ++u) o[u] = gelu_erf(o[u]);
+        for (int u = 0; u < UF; ++u) o[u] = gelu_erf(o[u]);
 #pragma unroll
-          for (int u = 0; u < UF; ++u) {
-            const int f = fb + 4 * u;
-            if (f < FF_FR) {                                // wave-uniform
-              const float xs = (f < nfr ? o[u] : 0.f) * a.a_scale;
-              const _Float16 hi = (_Float16)xs;
-              const _Float16 lo = (_Float16)(xs - (float)hi);
-              const int off = f * FF_ROW + ((cslot ^ ((f >> 1) & 7)) << 4) + cbyte;
-              *reinterpret_cast<_Float16*>(pl0 + off) = hi;
-              *reinterpret_cast<_Float16*>(pl1 + off) = lo;
-            }
+        for (int u = 0; u < UF; ++u) {
+          const int f = fb + 4 * u;
+          if (f < FF_FR) {                                  // wave-uniform
+            const float xs = (f < nfr ? o[u] : 0.f) * a.a_scale;
+            const _Float16 hi = (_Float16)xs;
+            const _Float16 lo = (_Float16)(xs - (float)hi);
+            const int off = f * FF_ROW + ((cslot ^ ((f >> 1) & 7)) << 4) + cbyte;
+            *reinterpret_cast<_Float16*>(pl0 + off) = hi;
+            *reinterpret_cast<_Float16*>(pl1 + off) = lo;
           }
         }
-      }
-    } else if (it > 0) {
-      // ---- MFMA: slab it - 1, 6 k-steps = 3 taps x 2 blocks of 32 channels; the W fragments of step ks + 1 are
-      // fetched (L2 -> registers) while step ks multiplies ----
-      const int slab = it - 1;
-      const unsigned char* pl0 = smem + (slab & 1) * 2 * FF_PLANE;
-      const unsigned char* pl1 = pl0 + FF_PLANE;
-      auto load_w = [&](int ks, u32x4 (&wf)[NI][2]) {
-        const int j = ks >> 1, kb = ks & 1;
-        const int kblk = j * (a.C0 / 32) + slab * 2 + kb;
-#pragma unroll
-        for (int jn = 0; jn < NI; ++jn) {
-          const int n = wn * 80 + jn * 16 + lr;
-          const u16* wpn = a.W2h + ((int64_t)n * KB + kblk) * 64 + lq * 8;
-          wf[jn][0] = *reinterpret_cast<const u32x4*>(wpn);
-          wf[jn][1] = *reinterpret_cast<const u32x4*>(wpn + 32);
-        }
-      };
-      auto mma_step = [&](int ks, const u32x4 (&wf)[NI][2]) {
-        const int j = ks >> 1, kb = ks & 1;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int f = 2 * (wm * 64 + i * 16 + lr) + j;
-          const int off = f * FF_ROW + (((kb * 4 + lq) ^ ((f >> 1) & 7)) << 4);
-          u32x4 af[2];
-          af[0] = *reinterpret_cast<const u32x4*>(pl0 + off);
-          af[1] = *reinterpret_cast<const u32x4*>(pl1 + off);
-#pragma unroll
-          for (int tt = 0; tt < 3; ++tt)
-#pragma unroll
-            for (int jn = 0; jn < NI; ++jn)
-              acc[i][jn] = mfma_np<2>(wf[jn][SplitTerms<2>::A[tt]], af[SplitTerms<2>::B[tt]], acc[i][jn]);
-        }
-      };
-      u32x4 wfa[NI][2], wfb[NI][2];
-      load_w(0, wfa);
-#pragma unroll
-      for (int ks = 0; ks < 6; ks += 2) {
-        load_w(ks + 1, wfb);
-        mma_step(ks, wfa);
-        if (ks + 2 < 6) load_w(ks + 2, wfa);
-        mma_step(ks + 1, wfb);
       }
     }
-    __syncthreads();   // planes of slab `it` complete; planes of slab it - 1 free for slab it + 1
+    __syncthreads();
+    // ---- MFMA phase: 6 k-steps = 3 taps x 2 blocks of 32 channels; the W fragments of step ks + 1 are fetched
+    // (L2 -> registers) while step ks multiplies ----
+    auto load_w = [&](int ks, u32x4 (&wf)[NI][2]) {
+      const int j = ks >> 1, kb = ks & 1;
+      const int kblk = j * (a.C0 / 32) + slab * 2 + kb;
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn) {
+        const int n = wn * 80 + jn * 16 + lr;
+        const u16* wpn = a.W2h + ((int64_t)n * KB + kblk) * 64 + lq * 8;
+        wf[jn][0] = *reinterpret_cast<const u32x4*>(wpn);
+        wf[jn][1] = *reinterpret_cast<const u32x4*>(wpn + 32);
+      }
+    };
+    auto mma_step = [&](int ks, const u32x4 (&wf)[NI][2]) {
+      const int j = ks >> 1, kb = ks & 1;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int f = 2 * (wm * 64 + i * 16 + lr) + j;
+        const int off = f * FF_ROW + (((kb * 4 + lq) ^ ((f >> 1) & 7)) << 4);
+        u32x4 af[2];
+        af[0] = *reinterpret_cast<const u32x4*>(pl0 + off);
+        af[1] = *reinterpret_cast<const u32x4*>(pl1 + off);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+          for (int jn = 0; jn < NI; ++jn)
+            acc[i][jn] = mfma_np<2>(wf[jn][SplitTerms<2>::A[tt]], af[SplitTerms<2>::B[tt]], acc[i][jn]);
+      }
+    };
+    u32x4 wfa[NI][2], wfb[NI][2];
+    load_w(0, wfa);
+#pragma unroll
+    for (int ks = 0; ks < 6; ks += 2) {
+      load_w(ks + 1, wfb);
+      mma_step(ks, wfa);
+      if (ks + 2 < 6) load_w(ks + 2, wfa);
+      mma_step(ks + 1, wfb);
+    }
   }
-  if (producer) return;
 
-  // ---- epilogue (consumers): lane (lr, lq) of block (i, jn) holds frame t1_0 + wm*64 + i*16 + lr, channels n0 .. ----
+  // ---- epilogue: lane (lr, lq) of block (i, jn) holds frame t1_0 + wm*64 + i*16 + lr, channels n0 .. n0 + 3 ----
   float* ob = a.out + (int64_t)b * a.T1 * a.N1p;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -252,7 +240,7 @@ int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, co
     a.a_scale = ldexpf(1.0f, 15 - e);
     a.a_inv = ldexpf(1.0f, e - 15);
   }
-  const size_t lds = 4 * FF_PLANE + sizeof(float) * (5 * (FF_FR - 1) + 10 + 6) + sizeof(float2) * FF_FR;
+  const size_t lds = 2 * FF_PLANE + sizeof(float) * (5 * (FF_FR - 1) + 10 + 6) + sizeof(float2) * FF_FR;
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -261,7 +249,7 @@ int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, co
   // algorithmic work: conv0 + conv1 flops; algorithmic HBM bytes: waveform in, conv1's raw output out
   const int pid = prof_begin(st, "conv01_fused", 2.0 * B * ((double)T0 * C0 * 10 + (double)T1 * 153.0 * 3 * C0),
                              B * (4.0 * N + 4.0 * (double)T1 * N1p));
-  hipLaunchKernelGGL(conv01_fused_kernel, grid, dim3(512), lds, st, a);
+  hipLaunchKernelGGL(conv01_fused_kernel, grid, dim3(256), lds, st, a);
   prof_end(pid, st);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
