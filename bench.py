@@ -335,7 +335,8 @@ def main():
                             "traffic": pmc_lookup(traffic, top["name"], "hbm_bytes_per_launch"),
                             "launches": top["launches"],
                             "avg_launch_ms": round(top["ms"] / top["launches"], 4),
-                            "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 3)}
+                            "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 3),
+                            "alg_bytes_per_launch": int(top["bytes"] / top["launches"]) if top["bytes"] > 0 else None}
                 if prec == "f32h":
                     roofline["note"] = ("achieved = algorithmic fp32 flops / s; every 16x16x32 block costs 3 fp16 MFMAs "
                                         "(hi*hi + hi*lo + lo*hi), so peak = fp16 dense peak 2500 / 3; executed MFMA rate = "

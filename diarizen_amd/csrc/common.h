@@ -207,6 +207,20 @@ static inline bool first_use_on_device(unsigned long long& mask) {
   return true;
 }
 
+// algorithmic HBM bytes of one contraction launch (profiling only): every operand once — A (rows that overlap, as in
+// the conv-as-contraction layouts, count once: min(K, lda) per row), the weight planes, C, the residual, the
+// layer-weighted-sum read-modify-write
+static inline double gemm_alg_bytes(const dzn_gemm_desc& d, int w_bytes_per_elem) {
+  const double nz = d.nz > 0 ? d.nz : 1;
+  const double a_cols = d.a_rowoff ? (double)d.kc : (d.lda > 0 && d.lda < d.K ? (double)d.lda : (double)d.K);
+  double b = (double)d.M * a_cols * (d.a_bf16 ? 2.0 : 4.0) * nz;
+  b += (double)d.N * d.K * w_bytes_per_elem * ((d.w_z0 || d.w_z1) ? nz : 1.0);
+  b += (double)d.M * d.N * (d.c_bf16 ? 2.0 : 4.0) * nz;
+  if (d.R) b += (double)d.M * d.N * (d.r_bf16 ? 2.0 : 4.0) * nz;
+  if (d.WS) b += 2.0 * (double)d.M * d.N * 4.0 * nz;
+  return b;
+}
+
 // brackets everything a launcher enqueues with one profiler record (no-op unless dzn_profile_enable(1))
 struct ProfScope {
   int id;

@@ -303,7 +303,7 @@ int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     else
       snprintf(cls, sizeof(cls), "gemm_f32%s_%dx%d", NP == 3 ? "s" : "h", BM, BN);
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
-    pid = prof_begin(s, cls, fl, 0.0);
+    pid = prof_begin(s, cls, fl, gemm_alg_bytes(d, NP * 2));
   }
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, d);
   prof_end(pid, s);
