@@ -118,6 +118,11 @@ def shard_slice(num_samples: int, window: int, step: int, rank: int, world: int)
     return c0, c1, c0 * step, (c1 - c0 - 1) * step + window
 
 
+def batches_note(n_windows: int, batch: int) -> str:
+    nb = max(1, -(-n_windows // batch))
+    return f"{nb} balanced launches of <= {-(-n_windows // nb)} windows (max batch {batch})"
+
+
 def run_mode(cfg, sd, esd, wave, args, window, precision, full, dev):
     """one untimed + one timed step of the same workload in another arithmetic mode (reported beside the headline)"""
     from diarizen_amd.configs import RESNET34
@@ -189,7 +194,8 @@ def main():
                          "f32 = the fp32 MFMA instruction")
     ap.add_argument("--minutes", type=float, default=30.0)
     ap.add_argument("--window", type=float, default=8.0)
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=384,
+                    help="maximum windows per launch (the runner balances: 2241 windows -> 6 launches of 374)")
     ap.add_argument("--model", default="wavlm_large_s80_md")
     ap.add_argument("--stage", default="full", choices=["full", "seg"],
                     help="seg = segmentation-only (BASELINE configs[1]: --model wavlm_base_s80_md --window 5 "
@@ -390,7 +396,7 @@ def main():
                                    f"{args.minutes:g} min synthetic 16 kHz mono {'sharded over the ranks' if strong else 'per GPU'}, window "
                                    f"{args.window:g} s, step {0.1 * args.window:g} s, {n_windows} windows, "
                                    f"batch {args.batch}; host clustering excluded from `value` (see `e2e`)",
-                       "windows_per_step": n_windows, "batch": args.batch,
+                       "windows_per_step": n_windows, "batch": args.batch, "launches": batches_note(n_windows, args.batch),
                        "weights": "seeded random init (no checkpoints offline)"},
             "windows_per_s": round((1 if strong else world) * n_windows * args.steps / dt, 1),
             "unprofiled_ms_per_step": round(unprofiled_ms, 2),

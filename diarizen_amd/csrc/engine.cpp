@@ -156,6 +156,7 @@ struct dzn_handle {
   float *x = nullptr, *xpad = nullptr, *y = nullptr, *ws = nullptr, *qkv = nullptr, *ao = nullptr,
         *gate = nullptr, *mid = nullptr;
   float *hz = nullptr, *ht = nullptr, *hmid = nullptr, *hv = nullptr;
+  float* spart = nullptr;   // [max_batch * maxL][32][2] per-row partial sums left by a producing epilogue (stat_partial)
   float* rstat = nullptr;   // [max_batch * maxL][2] (mean, rstd) of the LayerNorm folded into the next contraction
   // |max| trackers of activation tensors (DZN_PREC_F32_H2), ONE PER WINDOW of the batch (slot * max_batch + b): written
   // by the producer's epilogue / LayerNorm, read by the consuming contraction to scale its fp16 split
@@ -668,6 +669,7 @@ void finalize_seg(H* h) {
   h->hmid = dalloc<float>(h, ML * std::max(Fh, 3 * A));
   h->hv = dalloc<float>(h, ML * A);
   h->rstat = dalloc<float>(h, ML * 2);
+  h->spart = dalloc<float>(h, ML * 32 * 2);
   h->amax = dalloc<float>(h, (int64_t)dzn_handle::AM_COUNT * c.max_batch);
 }
 
@@ -1116,10 +1118,12 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   tap(h, "rep0", h->x, ML, D, D, st);
 
   // ---- transformer layers (components.py:920-942) ----
+  static const bool stats_from_epilogue = getenv("DZN_NO_EPILOGUE_STATS") == nullptr;
   ensure_table(h, L, st);
   for (int i = 0; i < c.n_layers; ++i) {
     EncLayer& Ly = h->layers[i];
     const float wl = h->wsum_w[i + 1];
+    bool have_stats = false;   // LN2's statistics already left in rstat by the out_proj epilogue
     if (Ly.attn) {
       const float* yin = h->x;
       bool y16 = false;
@@ -1157,13 +1161,21 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       o.R = h->x;
       o.a_amax = am(dzn_handle::AM_QKV);   // rows of ao are convex combinations of v rows: |ao| <= max |qkv|
       o.c_amax = am(dzn_handle::AM_X);
+      if (fold && c.layer_norm_first && Ly.ffn && stats_from_epilogue) {
+        // the rows it writes are exactly what the FFN's (folded) LayerNorm normalises: leave their statistics
+        o.stat_partial = h->spart;
+        o.stat_final = h->rstat;
+        o.stat_C = D;
+        o.stat_eps = 1e-5f;
+        have_stats = true;
+      }
       gemm(o, lp, false, "out_proj");
     }
     if (c.layer_norm_first) {
       if (Ly.ffn) {
         const float* fin = h->y;
         if (fold) {
-          chk(launch_row_stats(h->x, D, ML, D, 1e-5f, h->rstat, st), "row_stats");
+          if (!have_stats) chk(launch_row_stats(h->x, D, ML, D, 1e-5f, h->rstat, st), "row_stats");
           fin = h->x;
         } else {
           ln_t(h->x, false, D, h->y, lp, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y), L);

@@ -386,7 +386,10 @@ int launch_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
   }
   prof_end(pid, s);
-  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+  if (hipGetLastError() != hipSuccess) return DZN_E_HIP;
+  if (d.stat_partial && d.stat_final)
+    return launch_stats_finalize(d.stat_partial, d.M, ((d.N + BN - 1) / BN) * WGN, d.stat_C, d.stat_eps, d.stat_final, s);
+  return DZN_OK;
 }
 
 template <bool LOWP>

@@ -31,6 +31,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     // LayerNorm folded into the weights: finish it with the row statistics (dzn_ops.h)
     const float acc_scale = row_inv ? row_inv[i] : 1.f;
     float amax_row = 0.f;
+    float st_s = 0.f, st_q = 0.f;   // partial (sum, sum of squares) of this row over the wave tile's columns (d.stat_partial)
     float ln_mu = 0.f, ln_rs = 1.f;
     if (d.ln_stats) {
       const float2 st = *reinterpret_cast<const float2*>(d.ln_stats + 2 * (int64_t)m);
@@ -68,6 +69,8 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
         }
         *reinterpret_cast<float4*>(d.C + crow + n0) = make_float4(v[0], v[1], v[2], v[3]);
         amax_row = fmaxf(fmaxf(amax_row, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        st_s += (v[0] + v[1]) + (v[2] + v[3]);
+        st_q = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], st_q))));
         if (d.WS) {
           float4* w = reinterpret_cast<float4*>(d.WS + (int64_t)m * d.ldws + n0);
           float4 a = d.ws_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *w;
@@ -88,11 +91,26 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
           if (d.post_relu) x = fmaxf(x, 0.f);
           d.C[crow + n] = x;
           amax_row = fmaxf(amax_row, fabsf(x));
+          st_s += x;
+          st_q = fmaf(x, x, st_q);
           if (d.WS) {
             float* w = d.WS + (int64_t)m * d.ldws + n;
             *w = d.ws_init ? d.ws_w * x : (*w + d.ws_w * x);
           }
         }
+      }
+    }
+    if (d.stat_partial) {
+      // LayerNorm statistics of the rows this contraction WRITES, for the next (folded) LayerNorm: every wavefront
+      // leaves (sum, sum of squares) of its TN columns; stats_finalize_kernel adds the tilesN * (BN / TN) partials of a
+      // row in a fixed order (deterministic) and turns them into (mean, rstd) — the separate row_stats pass over the
+      // tensor disappears.  The row lives in lanes lr, lr + 16, lr + 32, lr + 48.
+      float s1 = st_s + __shfl_xor(st_s, 16, 64), q1 = st_q + __shfl_xor(st_q, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      q1 += __shfl_xor(q1, 32, 64);
+      if (lq == 0) {
+        const int P = ((d.N + BN - 1) / BN) * (BN / TN);
+        reinterpret_cast<float2*>(d.stat_partial)[(int64_t)m * P + tn * (BN / TN) + wn] = make_float2(s1, q1);
       }
     }
     if (d.c_amax) {

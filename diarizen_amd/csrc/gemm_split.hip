@@ -307,7 +307,10 @@ int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, d);
   prof_end(pid, s);
-  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+  if (hipGetLastError() != hipSuccess) return DZN_E_HIP;
+  if (d.stat_partial && d.stat_final)
+    return launch_stats_finalize(d.stat_partial, d.M, tilesN * WGN, d.stat_C, d.stat_eps, d.stat_final, s);
+  return DZN_OK;
 }
 
 // W [rows][K] fp32 (row stride ldw)  ->  W3 [rows][K/32][3][32] bf16, k permuted inside each block

@@ -105,6 +105,25 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
   if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mean, 1.0f / sqrtf(var + eps));
 }
 
+// per-row partial (sum, sum of squares) left by a contraction epilogue (dzn_gemm_desc.stat_partial) -> (mean, rstd);
+// the P partials of a row are added in index order in double: deterministic, and E[x^2] - mean^2 loses nothing to the
+// fp32 rounding already in the partials
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float2* __restrict__ part, int64_t rows, int P, int C,
+                                                             float eps, float2* __restrict__ stats) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < P; ++p) {
+    const float2 v = part[r * P + p];
+    s += (double)v.x;
+    q += (double)v.y;
+  }
+  const double mean = s / C;
+  double var = q / C - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  stats[r] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y,
                                                         int64_t n4) {
   const float4* xs = reinterpret_cast<const float4*>(x);
@@ -195,6 +214,15 @@ int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const f
                      const float* b, int64_t rows, int C, int Cpad, float eps, int gelu,
                      hipStream_t s) {
   return launch_layernorm_t(x, 0, ldx, y, 0, ldy, g, b, nullptr, rows, C, Cpad, eps, gelu, s);
+}
+
+int launch_stats_finalize(const float* partial, int64_t rows, int P, int C, float eps, float* stats, hipStream_t s) {
+  if (rows <= 0) return DZN_OK;
+  if (P < 1 || C < 1) return DZN_E_INVALID;
+  ProfScope prof_scope_(s, "stats_finalize", 0.0, (double)rows * (P + 1) * 8.0);
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)cdiv64(rows, 256)), dim3(256), 0, s,
+                     reinterpret_cast<const float2*>(partial), rows, P, C, eps, reinterpret_cast<float2*>(stats));
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
 int launch_amax(const float* x, int64_t n, float* amax, hipStream_t s) {

@@ -88,8 +88,13 @@ class WindowRunner:
         seg = torch.empty((C, self.num_frames, S), device=wave.device, dtype=torch.uint8)
         emb = (torch.empty((C, S, eng.emb.embed_dim), device=wave.device, dtype=torch.float32)
                if with_embeddings else None)
-        for s0 in range(c0, c1, self.batch_size):
-            s1 = min(s0 + self.batch_size, c1)
+        # balanced batches: ceil(C / batch_size) launches of (almost) equal size instead of full batches plus a short
+        # tail (2241 windows at batch 256: 9 x 249 rather than 8 x 256 + 193) — windows are independent and the
+        # engines are batch-invariant, so only the tail efficiency changes
+        nb = max(1, -(-C // self.batch_size))
+        bs = max(1, -(-C // nb))
+        for s0 in range(c0, c1, bs):
+            s1 = min(s0 + bs, c1)
             chunk = views[s0:s1].contiguous()
             _, ml = eng.segment(chunk, want_logp=False)
             filt, masks = eng.prepare_masks(ml, self.median_size, self.exclude_overlap,

@@ -25,7 +25,7 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
          ws_init=False, a_rowoff=None, c_rowoff=None, lda=None, kc=0, ldk=0, ldw=None, ldc=None,
          ldws=0, act=0, alpha=1.0, post_relu=False, nz=1, zdiv=1, zs=None, precision=0,
          W16=None, W3=None, a_planes=None, ln_stats=None, ln_colsum=None, W2h=None, col_scale=None,
-         a_amax=None, c_amax=None, amax_unit=None):
+         a_amax=None, c_amax=None, amax_unit=None, want_row_stats=False, stat_eps=1e-5):
     """C = epilogue(A @ W^T); see dzn_gemm_desc.  A: [M, K] (or raw buffer with lda / rowoff),
     W: [N, K] fp32 (and optionally W16 bf16)."""
     lib = _lib.load()
@@ -77,8 +77,13 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
     d.W2h, d.col_scale, d.a_amax, d.c_amax = _p(W2h), _p(col_scale), _p(a_amax), _p(c_amax)
     # one scale unit for the whole tensor unless told otherwise (engines use one unit per window)
     d.amax_unit = int(amax_unit) if amax_unit is not None else (max(M, 1) if nz == 1 else 0)
+    stats = None
+    if want_row_stats:      # LayerNorm statistics of the output rows, left by the epilogue + finalize kernel
+        part = torch.empty((M, 32, 2), device=A.device, dtype=torch.float32)
+        stats = torch.empty((M, 2), device=A.device, dtype=torch.float32)
+        d.stat_partial, d.stat_final, d.stat_C, d.stat_eps = _p(part), _p(stats), N, stat_eps
     check(lib.dzn_op_gemm(C.byref(d), _stream()), what="dzn_op_gemm")
-    return C_out
+    return (C_out, stats) if want_row_stats else C_out
 
 
 def split_weights(W):

@@ -96,6 +96,13 @@ typedef struct dzn_gemm_desc {
   /* a_amax / c_amax are ARRAYS with one |max| per scale unit, so that a window's result does not depend on the rest
    * of the batch: unit of row m = m / amax_unit when amax_unit > 0 (rows of one window), else the z0 batch index. */
   int32_t amax_unit;
+  /* LayerNorm statistics of the OUTPUT rows for a following folded LayerNorm: the epilogue leaves per-row partial
+   * (sum, sum of squares) in stat_partial (f32 [M][P][2] scratch, P = column tiles x wavefront columns <= 32) and the
+   * launcher reduces them to stat_final f32 [M][2] = (mean, rstd) over stat_C columns (plain z == 1 launches only). */
+  float* stat_partial;
+  float* stat_final;
+  int32_t stat_C;
+  float stat_eps;
 } dzn_gemm_desc;
 
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);

@@ -294,6 +294,23 @@ def test_gemm_layernorm_folded(built_lib, gpu, M, N, K, Kt, prec):
     assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("prec", F32_MODES)
+@pytest.mark.parametrize("M,N,K", [(700, 1024, 320), (333, 1024, 640), (515, 256, 1024)])
+def test_gemm_epilogue_row_stats(built_lib, gpu, M, N, K, prec):
+    """the contraction epilogue leaves the LayerNorm statistics (mean, rstd) of the rows it writes (partial sums per
+    wavefront tile + stats_finalize_kernel): equal to a LayerNorm-statistics pass over the stored result"""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    R = torch.randn(M, N, generator=g) * 3 + torch.randn(M, 1, generator=g)
+    out, stats = ops.gemm(A.to(gpu), W.to(gpu), R=R.to(gpu), precision=prec, want_row_stats=True)
+    o = out.cpu().double()
+    mean, rstd = o.mean(1), 1.0 / torch.sqrt(o.var(1, unbiased=False) + 1e-5)
+    assert (stats.cpu()[:, 0].double() - mean).abs().max() < 2e-6 * (1 + mean.abs().max())
+    assert ((stats.cpu()[:, 1].double() - rstd) / rstd).abs().max() < 2e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 200, 256), (513, 1024, 1056), (257, 64, 96), (1000, 32, 288)])
 def test_gemm_bf16_activations(built_lib, gpu, M, N, K):
     """both operands bf16 in HBM (LDS-DMA path), K tail at a 32-element half, bf16 / fp32 outputs,
