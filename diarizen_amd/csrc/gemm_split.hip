@@ -344,7 +344,7 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
     if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2, NP>(d, s);
     if constexpr (NP == 2) {   // wide-and-short wavefront tiles: every A row is split by one wavefront only
-      if (!strcmp(force, "128x128w4")) return launch_split_cfg<128, 128, 4, 1, 2, NP>(d, s);
+      if (!strcmp(force, "128x128w4")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);
     }
     if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
   }
@@ -359,7 +359,7 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   if (cols64 * 9 < cols128 * 8) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
   // NP = 2: 4 x 1 wavefronts (32 x 128 each): every A row is split by ONE wavefront instead of two; measured +3 %
   // over 2 x 2 on the pipeline's K = 1024 shapes (scripts/bench_gemm_h2.py).  NP = 3 keeps 2 x 2 (register budget).
-  if constexpr (NP == 2) return launch_split_cfg<128, 128, 4, 1, 2, NP>(d, s);
+  if constexpr (NP == 2) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);   // held to 2 wavefronts per SIMD
   return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
 }
 

@@ -322,6 +322,13 @@ def test_contraction_kernels_do_not_spill(src):
     assert r.returncode == 0, r.stderr[-2000:]
     sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
     assert sizes and max(sizes) == 0, f"scratch in {src}: {sorted(set(sizes))}"
+    # occupancy: the main contraction tiles must keep 2 wavefronts per SIMD (one extra register in the shared epilogue
+    # once dropped the 128x128 fp16 kernel to 1 and cost 35 % of its rate)
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", r.stderr)]
+    for n, o in zip(names, occ):
+        if "gemm_split_kernelILi128ELi" in n or "gemm_split_pre_kernelILi128ELi64" in n:   # the tiles the pipeline launches
+            assert o >= 2, f"{n}: {o} wavefront(s) per SIMD"
 
 
 # ---------------------------------------------------------------- e2e host stage vs the independent golden RTTM
