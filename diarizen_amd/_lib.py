@@ -93,8 +93,6 @@ class DznGemmDesc(C.Structure):
         ("W2h", C.c_void_p), ("col_scale", C.c_void_p), ("a_amax", C.c_void_p), ("c_amax", C.c_void_p),
         ("amax_unit", C.c_int32),
         ("stat_partial", C.c_void_p), ("stat_final", C.c_void_p), ("stat_C", C.c_int32), ("stat_eps", C.c_float),
-        ("side_x", C.c_void_p), ("side_ws", C.c_void_p), ("side_ld", C.c_int64), ("side_cols", C.c_int32),
-        ("side_w", C.c_float),
     ]
 
 

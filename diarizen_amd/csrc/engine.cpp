@@ -1119,22 +1119,6 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
 
   // ---- transformer layers (components.py:920-942) ----
   static const bool stats_from_epilogue = getenv("DZN_NO_EPILOGUE_STATS") == nullptr;
-  // the layer-weighted sum ws += w_l x_l is a 3-stream pass over [B*L, D]; inside the FFN-output epilogue (HBM-bound
-  // for the pruned widths) it costs its full HBM time, inside the NEXT layer's compute-bound q/k/v / FFN-in contraction
-  // it rides along (dzn_gemm_desc.side_*).  `pending` = weight of an x_l not yet accumulated.  Same additions in the
-  // same order per element as before: results are bit-identical.
-  static const bool side_ws = getenv("DZN_NO_SIDE_WS") == nullptr;
-  float pending = 0.f;
-  bool has_pending = false;
-  auto take_pending = [&](dzn_gemm_desc& d) {
-    if (!has_pending) return;
-    d.side_x = h->x;
-    d.side_ws = h->ws;
-    d.side_ld = D;
-    d.side_cols = D;
-    d.side_w = pending;
-    has_pending = false;
-  };
   ensure_table(h, L, st);
   for (int i = 0; i < c.n_layers; ++i) {
     EncLayer& Ly = h->layers[i];
@@ -1164,7 +1148,6 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       if (fold1) folded(d, Ly.qkv);
       d.a_amax = am(yin == h->x ? dzn_handle::AM_X : dzn_handle::AM_Y);
       d.c_amax = am(dzn_handle::AM_QKV);
-      take_pending(d);            // x still holds the previous layer's output here
       gemm(d, y16, false, "qkv");
       if (prec_is_split(c.precision))
         chk(launch_attention_split(h->qkv, h->ao, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd, hd,
@@ -1202,19 +1185,12 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
         f1.act = DZN_ACT_GELU;
         f1.a_amax = am(fin == h->x ? dzn_handle::AM_X : dzn_handle::AM_Y);
         f1.c_amax = am(dzn_handle::AM_MID);
-        if (!Ly.attn) take_pending(f1);   // attention-less layer: x is untouched since the previous layer's end
         gemm(f1, lp, lp, "ffn1");
         dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, h->x, ML, Ly.Fp, D);
         f2.R = h->x;
-        const bool defer = side_ws && !lp && i + 1 < c.n_layers && (h->layers[i + 1].attn || h->layers[i + 1].ffn);
-        if (defer) {
-          pending = wl;
-          has_pending = true;
-        } else {
-          f2.WS = h->ws;
-          f2.ldws = D;
-          f2.ws_w = wl;
-        }
+        f2.WS = h->ws;
+        f2.ldws = D;
+        f2.ws_w = wl;
         f2.a_amax = am(dzn_handle::AM_MID);
         f2.c_amax = am(dzn_handle::AM_X);
         gemm(f2, lp, false, "ffn2");

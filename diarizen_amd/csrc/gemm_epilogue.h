@@ -127,28 +127,6 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
       }
     }
   }
-  if (d.side_ws) {
-    // side job (dzn_ops.h): this wavefront's TM rows x its slice of the side_cols columns, float4 per lane, coalesced
-    const int tilesN = (d.N + BN - 1) / BN;
-    constexpr int WGN_ = BN / TN;
-    const int per = (((d.side_cols + tilesN * WGN_ - 1) / (tilesN * WGN_)) + 3) & ~3;
-    const int c0 = (tn * WGN_ + wn) * per;
-    const int nc4 = (d.side_cols - c0 < per ? d.side_cols - c0 : per) >> 2;      // float4 columns of the slice
-    if (nc4 > 0) {
-      const int lane = lr + 16 * lq;
-      for (int idx = lane; idx < TM * nc4; idx += 64) {
-        const int r = idx / nc4, c = idx - r * nc4;
-        const int m = wrow0 + r;
-        if (m < d.M) {
-          const int64_t o = (int64_t)m * d.side_ld + c0 + 4 * c;
-          const float4 xv = *reinterpret_cast<const float4*>(d.side_x + o);
-          float4 wv = *reinterpret_cast<float4*>(d.side_ws + o);
-          wv.x += d.side_w * xv.x; wv.y += d.side_w * xv.y; wv.z += d.side_w * xv.z; wv.w += d.side_w * xv.w;
-          *reinterpret_cast<float4*>(d.side_ws + o) = wv;
-        }
-      }
-    }
-  }
   if (two_unit) {
     track_amax(d.c_amax + unit0, amax);
     if (wrow0 + TM > boundary && boundary < d.M) track_amax(d.c_amax + unit0 + 1, amax_hi);   // wave-uniform

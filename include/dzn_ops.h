@@ -103,15 +103,6 @@ typedef struct dzn_gemm_desc {
   float* stat_final;
   int32_t stat_C;
   float stat_eps;
-  /* side job of a COMPUTE-bound launch: side_ws[m, :side_cols] (+)= side_w * side_x[m, :side_cols] for the rows of the
-   * launch (each column tile takes a slice of the columns).  Used to move the layer-weighted-sum accumulation
-   * (model_wavlm_conformer.py:236,253) out of the HBM-bound FFN-output epilogues: x_l is accumulated by the NEXT
-   * layer's q/k/v (or FFN-in) contraction, whose memory system idles.  Row stride side_ld for both. */
-  const float* side_x;
-  float* side_ws;
-  int64_t side_ld;
-  int32_t side_cols;
-  float side_w;
 } dzn_gemm_desc;
 
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
