@@ -15,7 +15,7 @@ for C in FETCH_SIZE WRITE_SIZE MfmaUtil; do
 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-e2e --no-profile > /dev/null 2> $O/pmc_$C.err
 done
 cd $R
-python scripts/pmc_summary.py $O/pmc_f32h_30min_b256.json $(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) $(find $O/pmc_MfmaUtil -name '*counter_collection.csv' | head -1)
+python scripts/pmc_summary.py $O/pmc_f32h_30min_b384.json $(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) $(find $O/pmc_MfmaUtil -name '*counter_collection.csv' | head -1)
 cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 find $O -name '*kernel_trace.csv' -delete; find $O -name '*counter_collection.csv' -delete; find $O -name '*agent_info.csv' -delete
 head -14 $O/kernel_stats.csv
