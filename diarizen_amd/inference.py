@@ -77,9 +77,12 @@ class WindowRunner:
         return torch.as_strided(wave, (C, self.window), (self.step, 1))
 
     def run(self, wave: torch.Tensor, with_embeddings: bool = True,
-            window_range: Optional[Tuple[int, int]] = None) -> SlideResult:
+            window_range: Optional[Tuple[int, int]] = None, hook=None) -> SlideResult:
         """wave: f32 [N_total] on the device.  window_range=(c0, c1) restricts to a contiguous
-        run of windows (multi-GPU sharding).  Enqueue only; results are device tensors."""
+        run of windows (multi-GPU sharding).  Enqueue only; results are device tensors.
+        hook: the progress callback of `Inference.slide` (PA/core/inference.py:308-340), called as
+        hook(completed=<windows done>, total=<windows>) before the first and after every batch; a hook makes the
+        call wait for each batch (otherwise "completed" would only mean "enqueued")."""
         eng = self.engine
         views = self.windows_view(wave)
         c0, c1 = window_range if window_range is not None else (0, views.shape[0])
@@ -93,6 +96,8 @@ class WindowRunner:
         # engines are batch-invariant, so only the tail efficiency changes
         nb = max(1, -(-C // self.batch_size))
         bs = max(1, -(-C // nb))
+        if hook is not None:
+            hook(completed=0, total=C)
         for s0 in range(c0, c1, bs):
             s1 = min(s0 + bs, c1)
             chunk = views[s0:s1].contiguous()
@@ -103,4 +108,7 @@ class WindowRunner:
             seg[s0 - c0:s1 - c0] = filt
             if with_embeddings:
                 emb[s0 - c0:s1 - c0] = eng.embed(chunk, masks)
+            if hook is not None:
+                torch.cuda.current_stream(wave.device).synchronize()
+                hook(completed=s1 - c0, total=C)
         return SlideResult(seg, emb, self.window, self.step, self.num_frames)

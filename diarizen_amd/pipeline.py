@@ -50,23 +50,33 @@ def _load_checkpoint(path: str) -> Dict[str, torch.Tensor]:
 
 def run_host_stage(seg: np.ndarray, emb: np.ndarray, *, chunks: SlidingWindow, clustering, min_speakers: int,
                    max_speakers: int, sample_rate: int = 16000, sess_name: Optional[str] = None,
-                   device=None) -> Annotation:
+                   device=None, hook=None) -> Annotation:
     """The host half of `DiariZenPipeline.__call__` (diarizen/pipelines/inference.py:137-185): speaker
     counting -> clustering -> inactive speakers to -2 -> reconstruction -> Binarize.  Needs no device, so
-    it is checked on the CPU against the oracle's loop-for-loop restatement (tests/test_host.py)."""
+    it is checked on the CPU against the oracle's loop-for-loop restatement (tests/test_host.py).
+    hook(step_name, artifact): the per-step callback of `SpeakerDiarization.apply`
+    (PA/pipelines/speaker_diarization.py:498,572: "speaker_counting", "discrete_diarization")."""
+    hook = hook or (lambda *a, **k: None)
     frames = receptive_field(sample_rate)
-    segf = seg.astype(np.float32)
+    hard_decisions = seg.dtype == np.uint8
     # device=...: the two overlap-add aggregations run on the HIP device (postprocess.DevicePost); None = numpy
     post = DevicePost(seg, chunks, frames, device) if device is not None else None
+    segf = seg.astype(np.float32) if (post is None or not hard_decisions) else None    # numpy path only
     count = post.speaker_count() if post is not None else speaker_count(segf, chunks, frames)
+    hook("speaker_counting", count)
+    # the clustering only counts frames of `segmentations`: u8 decisions are counted as bytes (clustering.py)
     hard, _, _ = clustering(embeddings=emb.astype(np.float64) if emb.dtype != np.float32 else emb,
-                            segmentations=segf, min_clusters=min_speakers, max_clusters=max_speakers)
+                            segmentations=seg if hard_decisions else segf, min_clusters=min_speakers,
+                            max_clusters=max_speakers)
     count.data = np.minimum(count.data, max_speakers).astype(np.int8)
-    inactive = np.sum(segf, axis=1) == 0
+    inactive = ~seg.any(axis=1) if hard_decisions else np.sum(segf, axis=1) == 0
     hard = np.array(hard, copy=True)
     hard[inactive] = -2
     res = post.reconstruct(hard, count) if post is not None else None
+    if res is None and segf is None:
+        segf = seg.astype(np.float32)
     discrete, _ = res if res is not None else reconstruct(segf, chunks, hard, count)
+    hook("discrete_diarization", discrete)
     return binarize(discrete, onset=0.5, offset=0.5, uri=sess_name)
 
 
@@ -164,7 +174,7 @@ class DiariZenPipeline:
         return SlidingWindow(start=0.0, duration=self.seg_duration,
                              step=self.segmentation_step * self.seg_duration)
 
-    def device_stage(self, waveform: np.ndarray):
+    def device_stage(self, waveform: np.ndarray, hook=None):
         """host float32 [N] -> (segmentations u8 [C, L, 4], embeddings f32 [C, 4, 256]) on the host.
         With torch.distributed initialised, this rank uploads ONLY the samples its contiguous window range touches
         (its slice + one window of halo), runs them, and the per-window results are all-gathered."""
@@ -182,7 +192,7 @@ class DiariZenPipeline:
             x = sl
         if len(x):
             wave = torch.from_numpy(x).to(self.device)
-            res = r.run(wave, with_embeddings=True)
+            res = r.run(wave, with_embeddings=True, hook=hook)
             seg_l, emb_l = res.segmentations, res.embeddings
         else:                                                      # more ranks than windows
             S = self.engine.seg.max_speakers_per_chunk
@@ -192,16 +202,26 @@ class DiariZenPipeline:
         torch.cuda.synchronize(self.device)
         return seg.cpu().numpy(), emb.cpu().numpy()
 
-    def host_stage(self, seg: np.ndarray, emb: np.ndarray, sess_name: Optional[str] = None) -> Annotation:
+    def host_stage(self, seg: np.ndarray, emb: np.ndarray, sess_name: Optional[str] = None, hook=None) -> Annotation:
         """counting -> clustering -> reconstruction -> Annotation (inference.py:137-185)."""
         return run_host_stage(seg, emb, chunks=self.chunks_window(), clustering=self.clustering,
                               min_speakers=self.min_speakers, max_speakers=self.max_speakers,
                               sample_rate=self.segmentation_model.sample_rate, sess_name=sess_name,
-                              device=self.device if self.device_postprocess else None)
+                              device=self.device if self.device_postprocess else None, hook=hook)
 
     # ------------------------------------------------------------------ __call__
-    def __call__(self, in_wav, sess_name: Optional[str] = None) -> Annotation:
+    def __call__(self, in_wav, sess_name: Optional[str] = None, hook=None) -> Annotation:
+        """`hook` (optional, not in the reference's DiariZenPipeline signature but in the pyannote pipeline it
+        derives from): hook(step_name, step_artifact, file=..., total=..., completed=...) as
+        PA/pipelines/utils/hook.py:36-224 expects (ProgressHook / ArtifactHook / TimingHook work unchanged).
+        Steps: "segmentation" (progress per batch of windows, then the SlidingWindowFeature), "speaker_counting",
+        "embeddings" (the [C, S, 256] array — computed in the same device pass as the segmentation, so it has no
+        progress of its own), "discrete_diarization"."""
+        import functools
         import time
+        file = in_wav if isinstance(in_wav, Mapping) else {"audio": in_wav}
+        if hook is not None:
+            hook = functools.partial(hook, file=file)       # Pipeline.setup_hook (PA/core/pipeline.py:267-271)
         if isinstance(in_wav, Mapping):                    # pyannote ProtocolFile (a Mapping, not a dict)
             in_wav = in_wav["audio"]
         assert isinstance(in_wav, (str, os.PathLike, BytesIO, bytes)), \
@@ -209,12 +229,17 @@ class DiariZenPipeline:
         t0 = time.perf_counter()
         waveform = audio_io.first_channel_16k(in_wav, self.segmentation_model.sample_rate)
         t1 = time.perf_counter()
-        seg, emb = self.device_stage(waveform)
+        seg, emb = self.device_stage(
+            waveform, hook=functools.partial(hook, "segmentation", None) if hook is not None else None)
+        if hook is not None:
+            from .core import SlidingWindowFeature
+            hook("segmentation", SlidingWindowFeature(seg, self.chunks_window()))
+            hook("embeddings", emb)
         t2 = time.perf_counter()
         from . import dist as dz_dist
         result = None
         if dz_dist.rank() == 0:
-            result = self.host_stage(seg, emb, sess_name)
+            result = self.host_stage(seg, emb, sess_name, hook=hook)
             if self.rttm_out_dir is not None:
                 assert sess_name is not None
                 with open(os.path.join(self.rttm_out_dir, sess_name + ".rttm"), "w") as f:

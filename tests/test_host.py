@@ -366,9 +366,42 @@ def test_product_host_stage_equals_independent_golden_rttm():
                                   threshold=clu["ahc_threshold"])
     hard, _, _ = ahc(embeddings=g["emb"], segmentations=g["seg"].astype(np.float32), min_clusters=1, max_clusters=20)
     assert np.array_equal(hard, g["hard_clusters"])                  # == reference clustering module
+    steps = []
     ann = run_host_stage(g["seg"], g["emb"], chunks=SlidingWindow(start=0.0, duration=8.0, step=0.8), clustering=ahc,
-                         min_speakers=clu["min_speakers"], max_speakers=clu["max_speakers"], sess_name="EN2002a")
+                         min_speakers=clu["min_speakers"], max_speakers=clu["max_speakers"], sess_name="EN2002a",
+                         hook=lambda name, artifact, **kw: steps.append((name, artifact.data.shape)))
     assert ann.to_rttm() == rttm
+    # the per-step callback of SpeakerDiarization.apply (PA/pipelines/speaker_diarization.py:498,572)
+    assert [n for n, _ in steps] == ["speaker_counting", "discrete_diarization"]
+    assert steps[0][1][1] == 1 and steps[1][1][0] == steps[0][1][0]
+    # u8 decisions (what the pipeline passes) and float32 ones (the reference's dtype) take the same decisions
+    ann_f = run_host_stage(g["seg"].astype(np.float32), g["emb"], chunks=SlidingWindow(start=0.0, duration=8.0, step=0.8),
+                           clustering=ahc, min_speakers=clu["min_speakers"], max_speakers=clu["max_speakers"],
+                           sess_name="EN2002a")
+    assert ann_f.to_rttm() == rttm
+
+
+def test_single_speaker_frame_mask_fast_paths_equal_reference_expression():
+    """clustering.single_speaker_frame_mask counts u8 decisions as packed words (S = 4) or bytes; both must equal the
+    reference expression PA/pipelines/clustering.py:111-131 on random decisions, for S = 3 / 4 and soft scores."""
+    from diarizen_amd.clustering import filter_embeddings, single_speaker_frame_mask
+    r = np.random.default_rng(3)
+    for S in (3, 4, 5):
+        seg = (r.random((57, 41, S)) < 0.35).astype(np.uint8)
+        seg[5] = 0
+        ref_n = np.sum(seg.astype(np.float32) * (np.sum(seg.astype(np.float32), axis=2, keepdims=True) == 1), axis=1)
+        for mf in (0, 1, 4, 9):
+            want = ref_n >= mf
+            assert np.array_equal(single_speaker_frame_mask(seg, mf), want)
+            assert np.array_equal(single_speaker_frame_mask(seg.astype(np.float32), mf), want)
+        emb = r.standard_normal((57, S, 8)).astype(np.float32)
+        emb[7, 1, 3] = np.nan
+        a = filter_embeddings(emb, seg)
+        b = filter_embeddings(emb, seg.astype(np.float32))
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
+    soft = r.random((9, 17, 4)).astype(np.float32)                  # soft scores keep the reference expression
+    want = np.sum(soft * (np.sum(soft, axis=2, keepdims=True) == 1), axis=1) >= 1
+    assert np.array_equal(single_speaker_frame_mask(soft, 1), want)
 
 
 def test_oracle_host_stage_reproduces_golden_rttm():

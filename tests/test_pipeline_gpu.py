@@ -62,6 +62,18 @@ def test_rttm_equal_and_api_surface(pipeline, tmp_path):
         assert f[0] == "SPEAKER" and f[1] == "EN2002a" and len(f) == 10
     t = pipeline.timings
     assert t["audio_s"] == 30.0 and t["device_s"] > 0
+    # hook protocol of the pyannote pipeline (PA/pipelines/utils/hook.py:36-224; PA/core/inference.py:308-340)
+    calls = []
+    file = {"audio": WAV}
+    ann2 = pipeline(file, sess_name="EN2002a",
+                    hook=lambda name, artifact, file=None, total=None, completed=None:
+                    calls.append((name, None if artifact is None else type(artifact).__name__, file, total, completed)))
+    assert ann2.to_rttm() == rttm
+    assert all(c[2] is file for c in calls)
+    prog = [c for c in calls if c[0] == "segmentation" and c[1] is None]
+    assert prog[0][3:] == (29, 0) and prog[-1][3:] == (29, 29)
+    assert [c[0] for c in calls if c[1] is not None] == ["segmentation", "embeddings", "speaker_counting",
+                                                         "discrete_diarization"]
 
 
 def test_plugin_facades(pipeline, gpu):
