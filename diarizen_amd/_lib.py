@@ -18,6 +18,7 @@ DZN_PREC_F32 = 0
 DZN_PREC_BF16 = 1
 DZN_PREC_F32_SPLIT = 2
 DZN_PREC_F32_H2 = 3
+DZN_PREC_F16 = 4
 
 DZN_ACT_NONE, DZN_ACT_GELU, DZN_ACT_SWISH, DZN_ACT_RELU = 0, 1, 2, 3
 
@@ -152,6 +153,7 @@ def load() -> C.CDLL:
     sig("dzn_profile_collect", i32, [C.POINTER(DznProfEntry), i32, C.POINTER(i32)])
     sig("dzn_op_relpos_bucket", i32, [i32, i32, i32])
     sig("dzn_linkage_centroid", i32, [vp, i32, i32, vp, i32])
+    sig("dzn_cdist_cosine", i32, [vp, i32, i32, vp, i32, vp, i32])
     sig("dzn_op_gemm", i32, [C.POINTER(DznGemmDesc), vp])
     sig("dzn_op_split_weights", i32, [vp, i64, i32, i64, vp, vp])
     sig("dzn_op_split_weights_h2", i32, [vp, i64, i32, i64, vp, vp, vp])
@@ -172,7 +174,7 @@ def load() -> C.CDLL:
 EXPORTED = [
     "dzn_create", "dzn_load_tensor", "dzn_finalize_weights", "dzn_num_frames",
     "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_speaker_count", "dzn_cluster_activations", "dzn_debug_fetch", "dzn_num_ignored",
-    "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid",
+    "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid", "dzn_cdist_cosine",
     "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",
     "dzn_profile_enable", "dzn_profile_collect", "dzn_op_relpos_bucket",
 ]

@@ -130,9 +130,26 @@ def constrained_argmax(soft: np.ndarray) -> np.ndarray:
     return hard
 
 
-def _soft_clusters(embeddings: np.ndarray, centroids: np.ndarray, metric: str) -> np.ndarray:
+HIP_CDIST_MIN = 8192     # rows; below this scipy's single-core loop is faster than upload + launch
+
+
+def _soft_clusters(embeddings: np.ndarray, centroids: np.ndarray, metric: str, backend: str = "auto",
+                   device: int = -1) -> np.ndarray:
+    """2 - cdist(embeddings, centroids) (PA/pipelines/clustering.py:207-216).  From HIP_CDIST_MIN rows up, float32
+    embeddings and the cosine metric go through csrc/linkage.hip's dzn_cdist_cosine, which keeps scipy's float64
+    operation order (tests/test_ops_gpu.py compares the two bit for bit); anything else is scipy's own call."""
     C, S, D = embeddings.shape
-    return 2 - cdist(embeddings.reshape(C * S, D), centroids, metric=metric).reshape(C, S, -1)
+    flat = embeddings.reshape(C * S, D)
+    if (metric == "cosine" and backend != "scipy" and flat.dtype == np.float32
+            and (backend == "hip" or (C * S >= HIP_CDIST_MIN and _hip_ready()))):
+        from . import ops
+        from ._lib import DznError
+        try:
+            return 2 - ops.cdist_cosine(flat, centroids, device=device).reshape(C, S, -1)
+        except (DznError, MemoryError):
+            if backend == "hip":
+                raise
+    return 2 - cdist(flat, centroids, metric=metric).reshape(C, S, -1)
 
 
 def _set_num_clusters(n, num_clusters, min_clusters, max_clusters):
@@ -230,7 +247,8 @@ class AgglomerativeClustering:
         K = int(np.max(train_clusters)) + 1
         train = embeddings[ci, si]
         centroids = np.vstack([np.mean(train[train_clusters == k], axis=0) for k in range(K)])
-        soft = _soft_clusters(embeddings, centroids, self.metric)
+        soft = _soft_clusters(embeddings, centroids, self.metric, getattr(self, 'cdist_backend', 'auto'),
+                              getattr(self, 'device', -1))
         hard = constrained_argmax(soft) if self.constrained_assignment else np.argmax(soft, axis=2)
         return hard, soft, centroids
 
@@ -320,7 +338,8 @@ class VBxClustering:
         q0 = softmax(q0 * 7.0, axis=1)                                  # init_smoothing = 7
         q, sp = vb_gmm(fea, Phi, q0, self.Fa, self.Fb, self.max_iters)
         centroids = q[:, sp > 1e-7].T @ train.reshape(-1, D)            # unnormalised: cosine follows
-        soft = _soft_clusters(embeddings, centroids, self.metric)
+        soft = _soft_clusters(embeddings, centroids, self.metric, getattr(self, 'cdist_backend', 'auto'),
+                              getattr(self, 'device', -1))
         hard = constrained_argmax(soft) if self.constrained_assignment else np.argmax(soft, axis=2)
         _, hard = np.unique(hard, return_inverse=True)
         return hard.reshape(C, S), soft, centroids

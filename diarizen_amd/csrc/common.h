@@ -110,7 +110,9 @@ static inline u16 f32_to_bf16_host(float f) {
 }
 
 // DZN_PREC_F32_H2 is DZN_PREC_F32_SPLIT for every kernel that has no two-term fp16 variant
-static inline bool prec_is_split(int p) { return p == DZN_PREC_F32_SPLIT || p == DZN_PREC_F32_H2; }
+// (DZN_PREC_F16 is the DZN_PREC_F32_H2 engine whose plain contractions keep one fp16 term: gemm_split*.hip NP = 1)
+static inline bool prec_is_h2(int p) { return p == DZN_PREC_F32_H2 || p == DZN_PREC_F16; }
+static inline bool prec_is_split(int p) { return p == DZN_PREC_F32_SPLIT || prec_is_h2(p); }
 
 // ---- kernel launchers (implemented in the .hip files) ----
 int launch_gemm(const dzn_gemm_desc& d, hipStream_t s);

@@ -250,7 +250,7 @@ Lin make_lin(H* h, const std::vector<float>& W, const float* bias, int N, int K,
     l.W3 = dalloc<u16>(h, (int64_t)3 * Np * Kp, false);
     if (launch_split_weights(l.W, Np, Kp, Kp, l.W3, nullptr) != DZN_OK)
       throw EngineError(DZN_E_HIP, "split_weights launch failed");
-    if (h->cfg.precision == DZN_PREC_F32_H2) {
+    if (prec_is_h2(h->cfg.precision)) {
       l.W2h = dalloc<u16>(h, (int64_t)2 * Np * Kp, false);
       l.wsc = dalloc<float>(h, Np, false);
       if (launch_split_weights_h2(l.W, Np, Kp, Kp, l.W2h, l.wsc, nullptr) != DZN_OK)
@@ -417,7 +417,7 @@ void finalize_seg(H* h) {
     h->conv[i] = make_lin(h, wp, nullptr, co, k * cip, h->Cp[i], k * cip);
     h->conv[i].Kt = k * ci;
     if (c.extractor_layer_norm) h->conv_ln[i] = ln_from_sd(h, pre + ".layer_norm", co);
-    if (i == 1 && c.precision == DZN_PREC_F32_H2 && c.extractor_layer_norm && h->conv0_lnq && c.conv_k[0] == 10 &&
+    if (i == 1 && prec_is_h2(c.precision) && c.extractor_layer_norm && h->conv0_lnq && c.conv_k[0] == 10 &&
         c.conv_s[0] == 5 && k == 3 && c.conv_s[1] == 2 && h->C[0] % 64 == 0 && h->Cp[0] == h->C[0] &&
         h->Cp[1] == 160 && !getenv("DZN_NO_CONV01_FUSION")) {
       h->conv1_W2n = dalloc<u16>(h, (int64_t)2 * h->Cp[1] * k * cip, false);
@@ -972,7 +972,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   };
   // DZN_PREC_F32_H2: |max| trackers (see dzn_handle::amax).  am(slot) is NULL in the other modes, which makes
   // every contraction take its bf16 three-term / fp32 kernel.
-  const bool h2 = c.precision == DZN_PREC_F32_H2;
+  const bool h2 = prec_is_h2(c.precision);
   const int64_t MB = c.max_batch;
   if (h2) {
     HIPCHK(hipMemsetAsync(h->amax, 0, dzn_handle::AM_IMG0 * MB * sizeof(float), st));
@@ -993,7 +993,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   }
   // DZN_PREC_F32_H2: conv0 + LN + GELU + conv1 in one kernel (frontend_fused.hip): conv0's 52 MB / window never
   // reach HBM.  (debug taps need the intermediate -> unfused)
-  const bool fuse01 = c.precision == DZN_PREC_F32_H2 && lnx && h->conv1_W2n && !h->debug && c.n_conv > 1 && T[1] > 0;
+  const bool fuse01 = prec_is_h2(c.precision) && lnx && h->conv1_W2n && !h->debug && c.n_conv > 1 && T[1] > 0;
   if (lnx && fuse01) {
   } else if (lnx) {
     chk(launch_conv0(wave, B, N, stats, h->conv0_w, h->conv_ln[0].g, h->conv_ln[0].b, h->C[0], h->Cp[0],
@@ -1349,7 +1349,7 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
   int cur = 0;
   // DZN_PREC_F32_H2: one |max| tracker per image buffer (sbuf[s][k] -> slot AM_IMG0 + 3 s + k), running over the
   // forward (stem kernel, stage-1 kernel and the contraction epilogues all track what they write)
-  const bool h2 = c.precision == DZN_PREC_F32_H2;
+  const bool h2 = prec_is_h2(c.precision);
   const int64_t MB = c.max_batch;
   if (h2) HIPCHK(hipMemsetAsync(h->amax + dzn_handle::AM_IMG0 * MB, 0, 12 * MB * sizeof(float), st));
   auto img_am = [&](const float* buf) -> float* {
@@ -1481,7 +1481,8 @@ int dzn_create(const dzn_config* cfg, dzn_handle** out) {
   }
   if (cfg->max_batch < 1 || cfg->max_samples < 400 ||
       (cfg->precision != DZN_PREC_F32 && cfg->precision != DZN_PREC_BF16 &&
-       cfg->precision != DZN_PREC_F32_SPLIT && cfg->precision != DZN_PREC_F32_H2)) {
+       cfg->precision != DZN_PREC_F32_SPLIT && cfg->precision != DZN_PREC_F32_H2 &&
+       cfg->precision != DZN_PREC_F16)) {
     last_create_error = "bad max_batch / max_samples / precision";
     return DZN_E_INVALID;
   }

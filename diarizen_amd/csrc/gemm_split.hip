@@ -74,6 +74,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   constexpr int ACH = BM * 128 / RB;      // rounds of the A tile (BM rows x 128 B)
   constexpr int WROWS = NW * 16;          // rows of one W plane per round (64-B rows)
   constexpr int WR = (BN + WROWS - 1) / WROWS;
+  constexpr int SP = NP == 3 ? 3 : 2;     // planes STORED per weight row (NP = 1 reads the leading one of two)
   constexpr int ABYTES = BM * 128, WPLANE = BN * 64, BUF = ABYTES + NP * WPLANE;
   constexpr int LPT = ACH + NP * WR;      // LDS-DMA instructions per thread per tile (NP fewer for the
                                           // wavefronts that sit out a partial last W round)
@@ -98,14 +99,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
   const float* __restrict__ A = d.A + z0 * d.a_z0 + z1 * d.a_z1;
   const u16* __restrict__ W3 =
-      reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + NP * (z0 * d.w_z0 + z1 * d.w_z1);
+      reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + SP * (z0 * d.w_z0 + z1 * d.w_z1);
   // NP = 2: exact power-of-two scale of every A row from the |max| tracker of the UNIT (window / image) the row
   // belongs to — unit = m / amax_unit, or the z batch index when amax_unit == 0 — so that a window's result does
   // not depend on what else is in the batch
   float a_scale[MI], row_inv[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) a_scale[i] = row_inv[i] = 1.f;
-  if constexpr (NP == 2) {
+  if constexpr (NP <= 2) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       int m = tm * BM + wm * TM + i * 16 + (lane & 15);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   for (int i = 0; i < WR; ++i) {
     int n = tn * BN + wr0 + WROWS * i;
     n = n < d.N ? n : d.N - 1;
-    wptr[i] = W3 + (int64_t)n * NP * d.ldw + wsw * 8;
+    wptr[i] = W3 + (int64_t)n * SP * d.ldw + wsw * 8;
   }
 
   // the next K tile to fetch: k index and its A element offset (two-level K addressing), advanced
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
       for (int i = 0; i < WR; ++i)
         if (i + 1 < WR || wfull)
           __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(wptr[i] + NP * ik + p * 32),
+              (const __attribute__((address_space(1))) void*)(wptr[i] + SP * ik + p * 32),
               (__attribute__((address_space(3))) void*)(sW + p * WPLANE + i * RB), 16, 0, 0);
     ik += BK;
     irem += BK;
@@ -209,12 +210,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][PW[t]], af[PA[t]], acc[i][j]);
-    } else {
+    } else if constexpr (NP == 2) {
       constexpr int PW[3] = {1, 0, 0}, PA[3] = {0, 1, 0};                     // lo*hi hi*lo hi*hi
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][PW[t]], af[PA[t]], acc[i][j]);
+    } else {                                                                  // hi*hi (DZN_PREC_F16)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][0], af[0], acc[i][j]);
     }
   };
   auto split = [&](const f32x4 (&a)[2], u32x4 (&af)[NP], float sc) {
@@ -224,8 +228,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
       af[0] = __builtin_bit_cast(u32x4, h_);
       af[1] = __builtin_bit_cast(u32x4, m_);
       af[2] = __builtin_bit_cast(u32x4, l_);
-    } else {
+    } else if constexpr (NP == 2) {
       split8_h2(a[0], a[1], sc, af[0], af[1]);
+    } else {
+      cvt8_h1(a[0], a[1], sc, af[0]);
     }
   };
 
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
     step(kt, wfa, wfb);
     if (kt + 1 < nk) step(kt + 1, wfb, wfa);
   }
-  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, NP == 2 ? d.col_scale : nullptr);
+  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr);
 }
 
 template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1>
@@ -299,9 +305,10 @@ int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     char cls[64];
     static const bool by_shape = getenv("DZN_PROFILE_SHAPES") != nullptr;
     if (by_shape)
-      snprintf(cls, sizeof(cls), "gemm_f32%s_%dx%d M%d N%d K%d z%d", NP == 3 ? "s" : "h", BM, BN, d.M, d.N, d.K, d.nz);
+      snprintf(cls, sizeof(cls), "gemm_%s_%dx%d M%d N%d K%d z%d", NP == 3 ? "f32s" : NP == 2 ? "f32h" : "f16", BM, BN, d.M,
+               d.N, d.K, d.nz);
     else
-      snprintf(cls, sizeof(cls), "gemm_f32%s_%dx%d", NP == 3 ? "s" : "h", BM, BN);
+      snprintf(cls, sizeof(cls), "gemm_%s_%dx%d", NP == 3 ? "f32s" : NP == 2 ? "f32h" : "f16", BM, BN);
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
     pid = prof_begin(s, cls, fl, gemm_alg_bytes(d, NP * 2));
   }
@@ -343,7 +350,7 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     if (!strcmp(force, "256x128")) return launch_split_cfg<256, 128, 4, 2, 2, NP>(d, s);
     if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
     if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2, NP>(d, s);
-    if constexpr (NP == 2) {   // wide-and-short wavefront tiles: every A row is split by one wavefront only
+    if constexpr (NP <= 2) {   // wide-and-short wavefront tiles: every A row is split by one wavefront only
       if (!strcmp(force, "128x128w4")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);
     }
     if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
@@ -359,7 +366,7 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   if (cols64 * 9 < cols128 * 8) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
   // NP = 2: 4 x 1 wavefronts (32 x 128 each): every A row is split by ONE wavefront instead of two; measured +3 %
   // over 2 x 2 on the pipeline's K = 1024 shapes (scripts/bench_gemm_h2.py).  NP = 3 keeps 2 x 2 (register budget).
-  if constexpr (NP == 2) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);   // held to 2 wavefronts per SIMD
+  if constexpr (NP <= 2) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);   // held to 2 wavefronts per SIMD
   return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
 }
 
@@ -395,8 +402,8 @@ int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s) {
   // fp16 two-term path: needs the fp16 planes + their row scales, the producer-tracked |max| of A, and weights
   // that do not move with z (col_scale is indexed by the output column alone)
   static const bool no_h2 = getenv("DZN_NO_H2") != nullptr;
-  if (d.precision == DZN_PREC_F32_H2 && d.W2h && d.col_scale && d.a_amax && !d.w_z0 && !d.w_z1 && !no_h2)
-    return launch_gemm_split_np<2>(d, s);
+  if (prec_is_h2(d.precision) && d.W2h && d.col_scale && d.a_amax && !d.w_z0 && !d.w_z1 && !no_h2)
+    return d.precision == DZN_PREC_F16 ? launch_gemm_split_np<1>(d, s) : launch_gemm_split_np<2>(d, s);
   if (!d.W3) return DZN_E_INVALID;
   return launch_gemm_split_np<3>(d, s);
 }

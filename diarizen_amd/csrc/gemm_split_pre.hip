@@ -39,6 +39,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
   constexpr int RB = NW * 1024;
   constexpr int ROWS = NW * 16;           // plane rows per LDS-DMA round (64-B rows)
   constexpr int AR = BM / ROWS, WR = BN / ROWS;
+  constexpr int SP = NP == 3 ? 3 : 2;     // planes STORED per weight row (NP = 1, DZN_PREC_F16, reads the leading one)
   constexpr int APLANE = BM * 64, WPLANE = BN * 64, BUF = NP * (APLANE + WPLANE);
   constexpr int LPT = NP * (AR + WR);
   static_assert(BM % ROWS == 0 && BN % ROWS == 0, "whole rounds");
@@ -61,11 +62,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
   const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
   const u16* __restrict__ A3 = reinterpret_cast<const u16*>(d.A) + z0 * d.a_z0 + z1 * d.a_z1;
   const u16* __restrict__ W3 =
-      reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + NP * (z0 * d.w_z0 + z1 * d.w_z1);
+      reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + SP * (z0 * d.w_z0 + z1 * d.w_z1);
   float row_inv[MI];     // NP = 2: inverse of the per-unit scale the producer applied (pad_rows_split2_kernel)
 #pragma unroll
   for (int i = 0; i < MI; ++i) row_inv[i] = 1.f;
-  if constexpr (NP == 2) {
+  if constexpr (NP <= 2) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       int m = tm * BM + wm * TM + i * 16 + (lane & 15);
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
   for (int i = 0; i < WR; ++i) {
     int n = tn * BN + pr0 + ROWS * i;
     n = n < d.N ? n : d.N - 1;
-    wptr[i] = W3 + (int64_t)n * NP * d.ldw + psw * 8;
+    wptr[i] = W3 + (int64_t)n * SP * d.ldw + psw * 8;
   }
 
   int ik = 0, irem = 0;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
 #pragma unroll
       for (int i = 0; i < WR; ++i)
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(wptr[i] + NP * ik + p * 32),
+            (const __attribute__((address_space(1))) void*)(wptr[i] + SP * ik + p * 32),
             (__attribute__((address_space(3))) void*)(sW + p * WPLANE + i * RB), 16, 0, 0);
     }
     ik += BK;
@@ -158,12 +159,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][PW[t]], a[PA[t]], acc[i][j]);
-    } else {
+    } else if constexpr (NP == 2) {
       constexpr int PW[3] = {1, 0, 0}, PA[3] = {0, 1, 0};
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][PW[t]], a[PA[t]], acc[i][j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][0], a[0], acc[i][j]);
     }
   };
 
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
     if (kt + 1 < nk) step(kt + 1, wfb, wfa);
   }
   gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv,
-                                        NP == 2 ? d.col_scale + z0 * d.b_z0 + z1 * d.b_z1 : nullptr);
+                                        NP <= 2 ? d.col_scale + z0 * d.b_z0 + z1 * d.b_z1 : nullptr);
 }
 
 template <int BM, int BN, int WGM, int WGN, int S, int NP>
@@ -226,9 +230,10 @@ int launch_pre_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     char cls[64];
     static const bool by_shape = getenv("DZN_PROFILE_SHAPES") != nullptr;
     if (by_shape)
-      snprintf(cls, sizeof(cls), "gemm_f32%s_pre_%dx%d M%d N%d K%d z%d", NP == 3 ? "s" : "h", BM, BN, d.M, d.N, d.K, d.nz);
+      snprintf(cls, sizeof(cls), "gemm_%s_pre_%dx%d M%d N%d K%d z%d", NP == 3 ? "f32s" : NP == 2 ? "f32h" : "f16", BM, BN,
+               d.M, d.N, d.K, d.nz);
     else
-      snprintf(cls, sizeof(cls), "gemm_f32%s_pre_%dx%d", NP == 3 ? "s" : "h", BM, BN);
+      snprintf(cls, sizeof(cls), "gemm_%s_pre_%dx%d", NP == 3 ? "f32s" : NP == 2 ? "f32h" : "f16", BM, BN);
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
     pid = prof_begin(s, cls, fl, gemm_alg_bytes(d, NP * 2));
   }
@@ -315,7 +320,7 @@ int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s) {
   if ((d.K & 31) || (d.kc & 31) || d.ldw != d.K || !d.a_split3 || d.a_plane <= 0) return DZN_E_INVALID;
   if (d.a_split3 == 2) {   // two fp16 planes
     if (!d.W2h || !d.col_scale || !d.a_amax || d.w_z0 * 1 != d.w_z0) return DZN_E_INVALID;
-    return launch_gemm_split_pre_np<2>(d, s);
+    return d.precision == DZN_PREC_F16 ? launch_gemm_split_pre_np<1>(d, s) : launch_gemm_split_pre_np<2>(d, s);
   }
   if (!d.W3) return DZN_E_INVALID;
   return launch_gemm_split_pre_np<3>(d, s);

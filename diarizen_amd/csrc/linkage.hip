@@ -237,3 +237,90 @@ done:
   (void)hipFree(nb); (void)hipFree(size); (void)hipFree(cid); (void)hipFree(st);
   return rc;
 }
+
+// ---- cosine distances of every embedding to the cluster centroids (row f1: `cdist` of the assignment step) -------
+// scipy.spatial.distance.cdist(E, Cn, metric="cosine") of BaseClustering.assign_embeddings
+// (PA/pipelines/clustering.py:207-216): float64, row norms first, then per pair
+//     d = 1 - clip(dot(u, v) / (|u| |v|))
+// with plain left-to-right sums (s += u[i] * v[i]; no FMA, no reassociation — scipy's C loops are built that way), so
+// the kernels below keep the SAME operation order: products and sums are separate roundings (contraction off), one
+// thread per (row[, centroid]) walks the 256 dimensions in order.  72 k embeddings x 13 centroids at 4 h of audio is
+// 0.24 G flop in float64 — the point is the 0.3-0.7 s scipy spends converting and scanning 147 MB on one host core.
+namespace {
+
+__global__ __launch_bounds__(256) void row_norm_f32_kernel(const float* __restrict__ E, int n, int dim,
+                                                           double* __restrict__ nrm) {
+#pragma clang fp contract(off)
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const float* e = E + (int64_t)r * dim;
+  double s = 0.0;
+  for (int i = 0; i < dim; ++i) {
+    const double c = (double)e[i];
+    const double p = c * c;
+    s = s + p;
+  }
+  nrm[r] = sqrt(s);
+}
+
+__global__ __launch_bounds__(256) void row_norm_f64_kernel(const double* __restrict__ X, int n, int dim,
+                                                           double* __restrict__ nrm) {
+#pragma clang fp contract(off)
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const double* x = X + (int64_t)r * dim;
+  double s = 0.0;
+  for (int i = 0; i < dim; ++i) {
+    const double p = x[i] * x[i];
+    s = s + p;
+  }
+  nrm[r] = sqrt(s);
+}
+
+// thread -> (row, centroid) with the centroid fastest: the lanes of a wavefront share a handful of rows
+__global__ __launch_bounds__(256) void cdist_cosine_kernel(const float* __restrict__ E, const double* __restrict__ Cn,
+                                                           const double* __restrict__ ne, const double* __restrict__ nc,
+                                                           int n, int dim, int k, double* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)n * k) return;
+  const int r = (int)(idx / k), c = (int)(idx - (int64_t)r * k);
+  const float* e = E + (int64_t)r * dim;
+  const double* v = Cn + (int64_t)c * dim;
+  double s = 0.0;
+  for (int i = 0; i < dim; ++i) {
+    const double p = (double)e[i] * v[i];
+    s = s + p;
+  }
+  const double den = ne[r] * nc[c];
+  double cosine = s / den;
+  if (fabs(cosine) > 1.0) cosine = copysign(1.0, cosine);      // scipy clips the rounding error
+  out[idx] = 1.0 - cosine;
+}
+
+}  // namespace
+
+extern "C" int dzn_cdist_cosine(const float* h_emb, int32_t n, int32_t dim, const double* h_cent, int32_t k,
+                                double* h_dist, int32_t device) {
+  if (!h_emb || !h_cent || !h_dist || n < 1 || dim < 1 || k < 1) return DZN_E_INVALID;
+  int rc = DZN_OK;
+  float* E = nullptr;
+  double *Cn = nullptr, *ne = nullptr, *nc = nullptr, *D = nullptr;
+  if (device >= 0) LCHK(hipSetDevice(device));
+  if (hipMalloc(&E, (size_t)n * dim * sizeof(float)) != hipSuccess) { rc = DZN_E_NOMEM; goto done; }
+  LCHK(hipMalloc(&Cn, (size_t)k * dim * sizeof(double)));
+  LCHK(hipMalloc(&ne, (size_t)n * sizeof(double)));
+  LCHK(hipMalloc(&nc, (size_t)k * sizeof(double)));
+  LCHK(hipMalloc(&D, (size_t)n * k * sizeof(double)));
+  LCHK(hipMemcpy(E, h_emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice));
+  LCHK(hipMemcpy(Cn, h_cent, (size_t)k * dim * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(row_norm_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, E, n, dim, ne);
+  hipLaunchKernelGGL(row_norm_f64_kernel, dim3((k + 255) / 256), dim3(256), 0, 0, Cn, k, dim, nc);
+  hipLaunchKernelGGL(cdist_cosine_kernel, dim3((unsigned)(((int64_t)n * k + 255) / 256)), dim3(256), 0, 0, E, Cn, ne, nc,
+                     n, dim, k, D);
+  LCHK(hipGetLastError());
+  LCHK(hipMemcpy(h_dist, D, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost));
+done:
+  (void)hipFree(E); (void)hipFree(Cn); (void)hipFree(ne); (void)hipFree(nc); (void)hipFree(D);
+  return rc;
+}

@@ -91,6 +91,17 @@ __device__ __forceinline__ void split8_h2(const f32x4& u, const f32x4& v, float 
   }
 }
 
+// DZN_PREC_F16: 8 fp32 values, pre-scaled by the power of two s -> ONE fp16x8 fragment (the leading term only)
+__device__ __forceinline__ void cvt8_h1(const f32x4& u, const f32x4& v, float s, u32x4& hi) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 x;
+    x[0] = (p < 2 ? u[2 * p] : v[2 * p - 4]) * s;
+    x[1] = (p < 2 ? u[2 * p + 1] : v[2 * p - 3]) * s;
+    hi[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+  }
+}
+
 // exact power-of-two scale that puts `amax` into [2^14, 2^15) (fp16 max is 65504), and its inverse
 __device__ __forceinline__ void h2_scale(float amax, float& s, float& inv) {
   int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;   // floor(log2 amax) for normal amax

@@ -17,7 +17,8 @@ from ._lib import (DZN_F32, DZN_F64, DZN_I64, DZN_PREC_BF16, DZN_PREC_F32, DZN_P
 from .configs import EmbConfig, SegConfig
 
 PRECISIONS = {"f32": DZN_PREC_F32, "fp32": DZN_PREC_F32, "bf16": DZN_PREC_BF16,
-              "f32s": DZN_PREC_F32_SPLIT, "f32_split": DZN_PREC_F32_SPLIT, "f32h": _lib.DZN_PREC_F32_H2}
+              "f32s": DZN_PREC_F32_SPLIT, "f32_split": DZN_PREC_F32_SPLIT, "f32h": _lib.DZN_PREC_F32_H2,
+              "f16": _lib.DZN_PREC_F16, "fp16": _lib.DZN_PREC_F16}
 
 
 def make_dzn_config(seg: SegConfig, emb: Optional[EmbConfig], max_batch: int, max_samples: int,

@@ -47,7 +47,7 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
         C_out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     if ldc is None:
         ldc = C_out.stride(0) if C_out.dim() == 2 else N
-    if precision in (_lib.DZN_PREC_F32_SPLIT, _lib.DZN_PREC_F32_H2) and W3 is None and K % 32 == 0 and ldw == K and W.is_contiguous():
+    if precision in (_lib.DZN_PREC_F32_SPLIT, _lib.DZN_PREC_F32_H2, _lib.DZN_PREC_F16) and W3 is None and K % 32 == 0 and ldw == K and W.is_contiguous():
         W3 = split_weights(W.reshape(-1, K))   # convenience for tests: engines split once at load
     d = DznGemmDesc()
     d.A, d.W, d.W16, d.C = _p(A), _p(W), _p(W16), _p(C_out)
@@ -70,7 +70,7 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
         d.A = _p(a_planes)
         d.a_split3, d.a_plane = 1, a_planes.stride(0)
     d.ln_stats, d.ln_colsum = _p(ln_stats), _p(ln_colsum)
-    if precision == _lib.DZN_PREC_F32_H2 and W2h is None and K % 32 == 0 and ldw == K and W.is_contiguous():
+    if precision in (_lib.DZN_PREC_F32_H2, _lib.DZN_PREC_F16) and W2h is None and K % 32 == 0 and ldw == K and W.is_contiguous():
         W2h, col_scale = split_weights_h2(W.reshape(-1, K))
         if a_amax is None:      # one |max| for the whole tensor, replicated for every z scale unit
             a_amax = amax(A).repeat(max(1, nz // max(zdiv, 1)))
@@ -160,6 +160,22 @@ def linkage_centroid(emb, device: int = -1):
     check(lib.dzn_linkage_centroid(e.ctypes.data_as(C.c_void_p), n, dim, Z.ctypes.data_as(C.c_void_p), device),
           what="dzn_linkage_centroid")
     return Z
+
+
+def cdist_cosine(emb, centroids, device: int = -1):
+    """scipy.spatial.distance.cdist(emb, centroids, "cosine") on the device in scipy's float64 operation order
+    (csrc/linkage.hip): emb = host float32 [n, dim], centroids [k, dim] -> float64 [n, k]."""
+    import numpy as np
+    lib = _lib.load()
+    e = np.ascontiguousarray(emb, dtype=np.float32)
+    c = np.ascontiguousarray(centroids, dtype=np.float64)
+    n, dim = e.shape
+    k = c.shape[0]
+    assert c.shape[1] == dim
+    out = np.empty((n, k), dtype=np.float64)
+    check(lib.dzn_cdist_cosine(e.ctypes.data_as(C.c_void_p), n, dim, c.ctypes.data_as(C.c_void_p), k,
+                               out.ctypes.data_as(C.c_void_p), device), what="dzn_cdist_cosine")
+    return out
 
 
 def layernorm(x, gamma, beta, C_true=None, eps=1e-5, gelu=False, out=None):

@@ -68,6 +68,12 @@ extern "C" {
                            * v_mfma_f32_16x16x32_f16 products in fp32 ("3xFP16", the error-corrected scheme
                            * known from 3xTF32): csrc/gemm_split.hip NP = 2.  Kernels without an fp16
                            * variant run as DZN_PREC_F32_SPLIT. */
+#define DZN_PREC_F16 4 /* REDUCED precision (BASELINE configs[4] "fp16"): the DZN_PREC_F32_H2 engine with the
+                        * linear-layer / positional-conv / ResNet contractions keeping only the LEADING fp16 term
+                        * of both operands (one v_mfma_f32_16x16x32_f16 product, fp32 accumulate; the same
+                        * per-window power-of-two scaling, so no fp16 range issue).  Attention, the fused
+                        * conv0->conv1 frontend and the 32-channel 3x3 convolutions keep two terms; data,
+                        * norms, softmax and the residual stream stay fp32.  Tolerance class: the bf16 one. */
 
 /*
  * Architecture description.  Mirrors the kwargs of
@@ -212,6 +218,14 @@ const char* dzn_version(void);
  * lives in HBM (8 n^2 bytes -> DZN_E_NOMEM when it does not fit).  Blocking; device < 0 = current.
  */
 int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, double* h_Z, int32_t device);
+
+/* Row f1, assignment step: scipy.spatial.distance.cdist(emb, centroids, metric="cosine") of
+ * BaseClustering.assign_embeddings (pyannote/audio/pipelines/clustering.py:207-216) on the device, in scipy's own
+ * float64 operation order (row norms, then 1 - clip(dot / (|u||v|)) with in-order sums, no FMA), so the scores the
+ * constrained assignment sees are the reference's.  HOST pointers: h_emb f32 [n, dim], h_cent f64 [k, dim],
+ * h_dist f64 [n, k].  Blocking; device < 0 = current.  Rows with a NaN / zero norm give NaN like scipy. */
+int dzn_cdist_cosine(const float* h_emb, int32_t n, int32_t dim, const double* h_cent, int32_t k, double* h_dist,
+                     int32_t device);
 
 #ifdef __cplusplus
 }

@@ -43,3 +43,4 @@ print("E2E_JSON", json.dumps({"minutes": minutes, "batch": batch, "timings_s": {
                               "speakers": len(ann.labels()), "turns": len(list(ann.itertracks())),
                               "weights": "seeded turn-taking weights", "precision": pipe.engine.precision}))
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+pstats.Stats(pr).sort_stats("tottime").print_stats(16)

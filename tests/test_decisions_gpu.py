@@ -51,7 +51,7 @@ def decision_parity(gpu, n_windows: int, batch: int = 32):
                          "min_top2_margin": float(margin.min()),
                          "frames_with_margin_below_1e-3": int((margin < 1e-3).sum())},
               "modes": {}}
-    for precision in ("f32s", "f32h", "f32", "bf16"):
+    for precision in ("f32s", "f32h", "f32", "bf16", "f16"):
         eng = Engine(cfg, sd, max_batch=batch, max_samples=N, precision=precision, device=gpu)
         outs = []
         for b in range(0, n_windows, batch):
@@ -82,3 +82,5 @@ def test_argmax_flip_rate_vs_oracle(built_lib, gpu):
         assert m["max_oracle_margin_of_flipped_frames"] <= 2e-3, (p, m)
     m = rep["modes"]["bf16"]
     assert m["flip_rate"] <= 0.2 and np.isfinite(m["max_abs_dlogp"]), m
+    m = rep["modes"]["f16"]                 # single-term fp16 (2^-11 per operand): reported, loose bound like bf16
+    assert m["flip_rate"] <= 0.05 and np.isfinite(m["max_abs_dlogp"]), m

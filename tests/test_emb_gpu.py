@@ -114,14 +114,16 @@ def test_embedding_16s_window_and_masks_kernel(built_lib, gpu):
     assert rel < 1e-4
 
 
-def test_embedding_bf16_engine(built_lib, gpu):
-    """bf16 engine mode (bf16 ResNet images / operands, fp32 accumulate, fbank + pooling + seg_1 fp32):
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_embedding_reduced_precision_engines(built_lib, gpu, precision):
+    """bf16 engine mode (bf16 ResNet images / operands, fp32 accumulate, fbank + pooling + seg_1 fp32) and f16 mode
+    (fp32 images, single-term fp16 contractions in stages 2-4, two-term 3x3 convs in stage 1):
     cosine >= 0.999 vs the reference golden, inactive speaker still exactly the bias"""
     from oracle import emb_model
     from oracle.gen_golden import synth_wave
     g = np.load(os.path.join(GOLD, "emb_resnet.npz"))
     B, N = int(g["B"]), int(g["N"])
-    eng = _engine(gpu, B, N, precision="bf16")
+    eng = _engine(gpu, B, N, precision=precision)
     emb = eng.embed(synth_wave(B, N, int(g["wave_seed"])).to(gpu), torch.from_numpy(g["masks"]).to(gpu))
     torch.cuda.synchronize()
     ref = torch.from_numpy(g["emb"])

@@ -161,6 +161,35 @@ def test_gemm_split_is_fp32_grade(built_lib, gpu):
     assert (W2[:, :, 0].abs().amax(dim=(1, 2)) < 2.0 ** 15).all() and (W2[:, :, 0].abs().amax(dim=(1, 2)) >= 2.0 ** 14).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 384, 2048), (399 * 3, 1024, 1024), (777, 64, 256), (300, 96, 544)])
+def test_gemm_f16_single_term(built_lib, gpu, M, N, K):
+    """DZN_PREC_F16 (gemm_split.hip NP = 1): both operands rounded ONCE to fp16 after the exact per-unit /
+    per-row power-of-two scaling, one MFMA product, fp32 accumulate.  Reference = the float64 product of the operands
+    rounded the same way (must agree to fp32-accumulation level, so nothing else is lost), and the plain float64
+    product (error at the fp16 rounding level 2^-11 per operand, relative to sum |a||w|).  Wide dynamic range between
+    rows of A is harmless: the scale is per window (here: one unit), fp16 keeps 11 bits below it."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * 3.0
+    W = torch.randn(N, K, generator=g) * 0.05 * torch.exp(torch.randn(N, 1, generator=g))
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), R=R.to(gpu), precision=4).cpu().double()
+    out3 = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), R=R.to(gpu), precision=3).cpu().double()
+    # operands as the kernel rounds them
+    sa = 2.0 ** (14 - torch.floor(torch.log2(A.abs().max())))
+    Ah = (A.double() * sa).to(torch.float16).double() / sa
+    sw = 2.0 ** (14 - torch.floor(torch.log2(W.abs().amax(dim=1, keepdim=True))))
+    Wh = (W.double() * sw).to(torch.float16).double() / sw
+    ref_h = Ah @ Wh.T + bias.double() + R.double()
+    ref = A.double() @ W.double().T + bias.double() + R.double()
+    scale = A.double().abs() @ W.double().abs().T + 1.0
+    assert ((out - ref_h).abs() / scale).max().item() < 2e-6          # exactly the rounded operands, fp32 accumulate
+    e = ((out - ref).abs() / scale)
+    assert e.max().item() < 2.0 ** -10 and e.pow(2).mean().sqrt().item() < 2.0 ** -12
+    assert ((out3 - ref).abs() / scale).max().item() < 2e-6           # the two-term mode on the same data, for scale
+
+
 def test_gemm_bf16(built_lib, gpu):
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(9)
@@ -373,8 +402,45 @@ def test_linkage_centroid_equals_scipy(built_lib, gpu, C):
         assert np.array_equal(fcluster(Zs, thr, "distance"), fcluster(Zg, thr, "distance"))
 
 
+def test_cdist_cosine_equals_scipy(built_lib, gpu):
+    """csrc/linkage.hip dzn_cdist_cosine vs scipy.spatial.distance.cdist(metric="cosine") (the assignment step,
+    PA/pipelines/clustering.py:207-216): the kernel keeps scipy's float64 operation order, so the bar is <= 2 ulp of
+    the distance and identical per-row argmin; the bit-exact fraction is recorded (gpurun_out/cdist_bitexact.json).
+    Includes a NaN row, a zero row, duplicated rows and a centroid equal to a row (distance clipped at 0)."""
+    import json
+    import os
+    import numpy as np
+    from scipy.spatial.distance import cdist
+    from diarizen_amd import ops
+    r = np.random.default_rng(11)
+    n, dim, k = 20011, 256, 13
+    cent = r.standard_normal((k, dim))
+    lab = r.integers(0, k, n)
+    e = (cent[lab] + 0.6 * r.standard_normal((n, dim))).astype(np.float32)
+    e[5] = np.nan
+    e[6] = 0.0
+    e[100:140] = e[99]                                   # the inactive speakers share one embedding
+    cent32 = np.vstack([e[lab == j].mean(axis=0) if j else e[7] for j in range(k)])   # float32 rows, one == e[7]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want = cdist(e, cent32, metric="cosine")
+    got = ops.cdist_cosine(e, cent32)
+    assert np.array_equal(np.isnan(want), np.isnan(got)) and np.isnan(got[5]).all() and np.isnan(got[6]).all()
+    ok = ~np.isnan(want)
+    ulp = np.abs(got[ok] - want[ok]) / np.spacing(np.maximum(np.abs(want[ok]), 1e-300))
+    exact = float(np.mean(got[ok] == want[ok]))
+    rows = ok.all(axis=1)
+    assert np.array_equal(np.argmin(got[rows], axis=1), np.argmin(want[rows], axis=1))
+    assert np.array_equal(got[100:140], np.broadcast_to(got[99], (40, k)))        # identical rows -> identical scores
+    assert got[7, 0] == want[7, 0] and abs(got[7, 0]) < 1e-15
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/cdist_bitexact.json", "w") as f:
+            json.dump({"n": n, "k": k, "dim": dim, "bit_exact_fraction": exact, "max_ulp": float(ulp.max())}, f)
+    assert ulp.max() <= 2.0, (ulp.max(), exact)
+
+
 def test_clustering_backends_agree(built_lib, gpu):
-    """AHC and VBx-style AHC initialisation through both linkage backends: identical hard clusters."""
+    """AHC and VBx-style AHC initialisation through both linkage backends and both cdist backends: identical hard
+    clusters."""
     import numpy as np
     from diarizen_amd import clustering as cl
     from oracle.gen_golden import synth_host_case
@@ -382,10 +448,12 @@ def test_clustering_backends_agree(built_lib, gpu):
     out = {}
     for backend in ("scipy", "hip"):
         ahc = cl.AgglomerativeClustering(threshold=0.7, min_cluster_size=13, linkage_backend=backend)
-        hard, soft, cent = ahc(embeddings=emb.copy(), segmentations=seg, min_clusters=1, max_clusters=20)
-        out[backend] = (hard, cent)
+        ahc.cdist_backend = backend
+        hard, soft, cent = ahc(embeddings=emb.astype(np.float32), segmentations=seg, min_clusters=1, max_clusters=20)
+        out[backend] = (hard, cent, soft)
     assert np.array_equal(out["scipy"][0], out["hip"][0])
     assert np.allclose(out["scipy"][1], out["hip"][1])
+    assert np.allclose(out["scipy"][2], out["hip"][2], rtol=0, atol=1e-15, equal_nan=True)
 
 
 @pytest.mark.parametrize("H,W,B", [(5, 37, 2), (80, 798, 1), (12, 126, 3)])

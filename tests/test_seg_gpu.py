@@ -122,6 +122,20 @@ def test_seg_bf16_within_tolerance(built_lib, gpu, name):
     assert agree >= 0.995
 
 
+@pytest.mark.parametrize("name", ["tiny_ln", "wavlm_large_s80_md", "wavlm_base_s80_md"])
+def test_seg_f16_within_tolerance(built_lib, gpu, name):
+    """DZN_PREC_F16 (BASELINE configs[4] "fp16"): single-term fp16 contractions inside the f32h engine.  Reduced
+    precision bar of SURVEY §8(d): max |d logp| <= 5e-2, argmax agreement >= 99.5 % — on the reference-made goldens
+    and on the turn-taking fixtures (non-degenerate decisions)."""
+    cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, "f16")
+    ref = torch.from_numpy(g["logp"])
+    err = (logp - ref).abs().max().item()
+    agree = (logp.argmax(-1) == ref.argmax(-1)).float().mean().item()
+    print(f"[{name} f16] max|dlogp|={err:.2e} argmax agreement={agree:.4f}")
+    assert err <= 5e-2, f"max |dlogp| = {err}"
+    assert agree >= 0.995
+
+
 def test_seg_batch_and_ragged_lengths(built_lib, gpu):
     """windows are independent: a batch equals its items run alone; shorter N re-uses the engine."""
     from diarizen_amd.configs import get_seg_config
