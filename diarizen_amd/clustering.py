@@ -136,8 +136,9 @@ HIP_CDIST_MIN = 8192     # rows; below this scipy's single-core loop is faster t
 def _soft_clusters(embeddings: np.ndarray, centroids: np.ndarray, metric: str, backend: str = "auto",
                    device: int = -1) -> np.ndarray:
     """2 - cdist(embeddings, centroids) (PA/pipelines/clustering.py:207-216).  From HIP_CDIST_MIN rows up, float32
-    embeddings and the cosine metric go through csrc/linkage.hip's dzn_cdist_cosine, which keeps scipy's float64
-    operation order (tests/test_ops_gpu.py compares the two bit for bit); anything else is scipy's own call."""
+    embeddings and the cosine metric go through csrc/linkage.hip's dzn_cdist_cosine (float64, same formula, in-order
+    sums: agrees with scipy to 2e-15 and keeps identical rows identical, tests/test_ops_gpu.py); anything else is
+    scipy's own call."""
     C, S, D = embeddings.shape
     flat = embeddings.reshape(C * S, D)
     if (metric == "cosine" and backend != "scipy" and flat.dtype == np.float32

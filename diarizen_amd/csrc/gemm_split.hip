@@ -342,9 +342,21 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
+// DZN_GEMM_CFG (read once) or dzn_op_set_gemm_cfg() (tuning scripts: several shapes in one process)
+char g_force_buf[32] = {0};
+bool g_force_init = false;
+const char* g_force_cfg() {
+  if (!g_force_init) {
+    const char* e = getenv("DZN_GEMM_CFG");
+    if (e) snprintf(g_force_buf, sizeof(g_force_buf), "%s", e);
+    g_force_init = true;
+  }
+  return g_force_buf[0] ? g_force_buf : nullptr;
+}
+
 template <int NP>
 int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
-  static const char* force = getenv("DZN_GEMM_CFG");   // tuning knob: force one tile shape
+  const char* force = g_force_cfg();                    // tuning knob: force one tile shape
   if (force) {
     if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
     if (!strcmp(force, "256x128")) return launch_split_cfg<256, 128, 4, 2, 2, NP>(d, s);
@@ -352,6 +364,13 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2, NP>(d, s);
     if constexpr (NP <= 2) {   // wide-and-short wavefront tiles: every A row is split by one wavefront only
       if (!strcmp(force, "128x128w4")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);
+      // deeper LDS-DMA pipelines (more K tiles in flight per CU): probes of the load-latency bound
+      if (!strcmp(force, "256x128s3")) return launch_split_cfg<256, 128, 4, 2, 3, NP>(d, s);
+      if (!strcmp(force, "256x128w8s3")) return launch_split_cfg<256, 128, 8, 1, 3, NP, 2>(d, s);
+      if (!strcmp(force, "128x128s3")) return launch_split_cfg<128, 128, 4, 1, 3, NP>(d, s);
+      if (!strcmp(force, "128x128s4")) return launch_split_cfg<128, 128, 4, 1, 4, NP>(d, s);
+      if (!strcmp(force, "128x64s3")) return launch_split_cfg<128, 64, 4, 1, 3, NP>(d, s);
+      if (!strcmp(force, "256x64s3")) return launch_split_cfg<256, 64, 8, 1, 3, NP>(d, s);
     }
     if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
   }
@@ -406,6 +425,12 @@ int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s) {
     return d.precision == DZN_PREC_F16 ? launch_gemm_split_np<1>(d, s) : launch_gemm_split_np<2>(d, s);
   if (!d.W3) return DZN_E_INVALID;
   return launch_gemm_split_np<3>(d, s);
+}
+
+extern "C" int dzn_op_set_gemm_cfg(const char* cfg) {
+  g_force_init = true;
+  snprintf(g_force_buf, sizeof(g_force_buf), "%s", cfg && strcmp(cfg, "auto") ? cfg : "");
+  return DZN_OK;
 }
 
 int launch_split_weights_h2(const float* W, int64_t rows, int K, int64_t ldw, void* W2, float* col_scale, hipStream_t s) {

@@ -220,9 +220,9 @@ const char* dzn_version(void);
 int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, double* h_Z, int32_t device);
 
 /* Row f1, assignment step: scipy.spatial.distance.cdist(emb, centroids, metric="cosine") of
- * BaseClustering.assign_embeddings (pyannote/audio/pipelines/clustering.py:207-216) on the device, in scipy's own
- * float64 operation order (row norms, then 1 - clip(dot / (|u||v|)) with in-order sums, no FMA), so the scores the
- * constrained assignment sees are the reference's.  HOST pointers: h_emb f32 [n, dim], h_cent f64 [k, dim],
+ * BaseClustering.assign_embeddings (pyannote/audio/pipelines/clustering.py:207-216) on the device: float64, row
+ * norms, then 1 - clip(dot / (|u||v|)) with in-order sums and no FMA (agrees with scipy to 2e-15 on distances of
+ * order 1; identical rows give identical scores).  HOST pointers: h_emb f32 [n, dim], h_cent f64 [k, dim],
  * h_dist f64 [n, k].  Blocking; device < 0 = current.  Rows with a NaN / zero norm give NaN like scipy. */
 int dzn_cdist_cosine(const float* h_emb, int32_t n, int32_t dim, const double* h_cent, int32_t k, double* h_dist,
                      int32_t device);

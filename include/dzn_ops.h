@@ -116,6 +116,11 @@ int dzn_op_split_weights(const float* W, int64_t rows, int32_t K, int64_t ldw, v
 int dzn_op_split_weights_h2(const float* W, int64_t rows, int32_t K, int64_t ldw, void* W2h, float* col_scale,
                             void* stream);
 
+/* tuning knob (scripts/bench_gemm_h2.py): force one tile configuration of csrc/gemm_split.hip for the calls that
+ * follow ("128x128", "256x128s3", ...; "auto" / NULL = the shape heuristic).  Same effect as the DZN_GEMM_CFG
+ * environment variable, which is read once per process. */
+int dzn_op_set_gemm_cfg(const char* cfg);
+
 /* amax[0] = max(amax[0], max |x[0..n)|) — the |max| tracker of a tensor whose producer has no fused tracker */
 int dzn_op_amax(const float* x, int64_t n, float* amax, void* stream);
 
