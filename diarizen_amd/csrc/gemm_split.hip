@@ -64,7 +64,10 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 //     rows is multiplied, then [wait tile kt+1, barrier, refill the stage of tile kt], then the
 //     fragments of tile kt+1 are read into the second register set while the second half of
 //     tile kt is multiplied — the matrix pipe has work queued across the barrier.
-template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1>
+// ABL != 0: ABLATION probes for scripts/bench_gemm_cfgs.py (wrong results on purpose; never launched by the engines):
+//   1 = no operand split (raw bits as fragments), 2 = no MFMAs, 3 = no steady-state LDS-DMA refills, 4 = no barrier,
+//   5 = no fragment reads after the first tile
+template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0>
 __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const dzn_gemm_desc d) {
   constexpr int NW = WGM * WGN;           // wavefronts per workgroup
   constexpr int BK = 32;
@@ -204,7 +207,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   // the products of one 16-row block against all NI column blocks: smallest terms first, NI independent
   // accumulators between dependent MFMAs.  af[] = A terms (hi, [mid,] lo), wf[j][] = W planes (hi, [mid,] lo).
   auto mma = [&](int i, const u32x4 (&wf)[NI][NP], const u32x4 (&af)[NP]) {
-    if constexpr (NP == 3) {
+    if constexpr (ABL == 2) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j][0] += __uint_as_float(wf[j][0][0] ^ af[0][0]);   // keep the operands live
+    } else if constexpr (NP == 3) {
       constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};   // lo*hi hi*lo mid*mid mid*hi hi*mid hi*hi
 #pragma unroll
       for (int t = 0; t < 6; ++t)
@@ -222,7 +228,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
     }
   };
   auto split = [&](const f32x4 (&a)[2], u32x4 (&af)[NP], float sc) {
-    if constexpr (NP == 3) {
+    if constexpr (ABL == 1) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) af[p] = __builtin_bit_cast(u32x4, a[p & 1]);
+    } else if constexpr (NP == 3) {
       bf16x8 h_, m_, l_;
       split8(a[0], a[1], h_, m_, l_);
       af[0] = __builtin_bit_cast(u32x4, h_);
@@ -252,6 +261,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   f32x4 ar[MI][2];
   read_w(0, wfa);
   read_a(0, ar);
+  if constexpr (ABL == 5) read_w(0, wfb);
   int stage = 0;
 
   // one K tile: `wc` holds its W fragments, `ar` its raw A fragments; leaves tile kt+1 in (wn_, ar)
@@ -272,10 +282,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
       // tile kt+1 landed (tiles kt+2 .. kt+S-1 may stay in flight); all my reads of tile kt retired
       if (kt + S <= nk) wait_tiles(std::integral_constant<int, S - 2>{});
       else wait_vm_lgkm0<0>();
-      __builtin_amdgcn_s_barrier();
-      if (kt + S < nk) issue(stage);  // every wave is past its reads of tile kt
-      read_w(nstage, wn_);
-      read_a(nstage, ar);
+      if constexpr (ABL != 4) __builtin_amdgcn_s_barrier();
+      if constexpr (ABL != 3)
+        if (kt + S < nk) issue(stage);  // every wave is past its reads of tile kt
+      if constexpr (ABL != 5) {
+        read_w(nstage, wn_);
+        read_a(nstage, ar);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -289,11 +302,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr);
 }
 
-template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1>
+template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0>
 int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
   const size_t lds = (size_t)S * (BM * 128 + NP * BN * 64);
-  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, NP, OCC>;
+  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, NP, OCC, ABL>;
   static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
   if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -371,6 +384,11 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
       if (!strcmp(force, "128x128s4")) return launch_split_cfg<128, 128, 4, 1, 4, NP>(d, s);
       if (!strcmp(force, "128x64s3")) return launch_split_cfg<128, 64, 4, 1, 3, NP>(d, s);
       if (!strcmp(force, "256x64s3")) return launch_split_cfg<256, 64, 8, 1, 3, NP>(d, s);
+      if (!strcmp(force, "abl1")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2, 1>(d, s);
+      if (!strcmp(force, "abl2")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2, 2>(d, s);
+      if (!strcmp(force, "abl3")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2, 3>(d, s);
+      if (!strcmp(force, "abl4")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2, 4>(d, s);
+      if (!strcmp(force, "abl5")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2, 5>(d, s);
     }
     if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
   }
@@ -385,7 +403,10 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   if (cols64 * 9 < cols128 * 8) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
   // NP = 2: 4 x 1 wavefronts (32 x 128 each): every A row is split by ONE wavefront instead of two; measured +3 %
   // over 2 x 2 on the pipeline's K = 1024 shapes (scripts/bench_gemm_h2.py).  NP = 3 keeps 2 x 2 (register budget).
-  if constexpr (NP <= 2) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);   // held to 2 wavefronts per SIMD
+  // NP = 1 (DZN_PREC_F16) is bound by the global -> LDS fill, not by MFMA / VALU (ablation: profiles/r2_gemm_ablation.txt):
+  // 256 x 128 tiles halve the W bytes per flop and a third stage keeps two K tiles in flight: +7..13 % (r2_gemm_cfg_probe.txt)
+  if constexpr (NP == 1) return launch_split_cfg<256, 128, 8, 1, 3, NP, 2>(d, s);
+  if constexpr (NP == 2) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);   // held to 2 wavefronts per SIMD
   return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
 }
 

@@ -422,7 +422,8 @@ def test_cdist_cosine_equals_scipy(built_lib, gpu):
     e[5] = np.nan
     e[6] = 0.0
     e[100:140] = e[99]                                   # the inactive speakers share one embedding
-    cent32 = np.vstack([e[lab == j].mean(axis=0) if j else e[7] for j in range(k)])   # float32 rows, one == e[7]
+    good = np.isfinite(e).all(axis=1)
+    cent32 = np.vstack([e[(lab == j) & good].mean(axis=0) if j else e[7] for j in range(k)])   # float32; one == e[7]
     with np.errstate(invalid="ignore", divide="ignore"):
         want = cdist(e, cent32, metric="cosine")
     got = ops.cdist_cosine(e, cent32)
