@@ -28,6 +28,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-re
          # the fused epilogue (4 x 6 accumulator blocks x erf-GELU ...) is fully unrolled by pragma; past the
          # default cost cap clang silently keeps the loop and the accumulators go to scratch (tests/test_host.py)
          "-mllvm", "-pragma-unroll-threshold=65536"]
+if os.environ.get("DZN_TUNING"):     # probe / ablation kernel instantiations for scripts/bench_gemm_cfgs.py
+    FLAGS.append("-DDZN_TUNING")
 
 
 def _headers_mtime() -> float:

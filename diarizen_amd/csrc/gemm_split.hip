@@ -371,17 +371,29 @@ template <int NP>
 int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   const char* force = g_force_cfg();                    // tuning knob: force one tile shape
   if (force) {
-    if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
-    if (!strcmp(force, "256x128")) return launch_split_cfg<256, 128, 4, 2, 2, NP>(d, s);
+    // production tiles by name
     if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
     if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2, NP>(d, s);
-    if constexpr (NP <= 2) {   // wide-and-short wavefront tiles: every A row is split by one wavefront only
+    if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
+    if constexpr (NP == 3) {
+      if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
+    } else {
       if (!strcmp(force, "128x128w4")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);
-      // deeper LDS-DMA pipelines (more K tiles in flight per CU): probes of the load-latency bound
+    }
+    if constexpr (NP == 1) {
+      if (!strcmp(force, "256x128w8s3")) return launch_split_cfg<256, 128, 8, 1, 3, NP, 2>(d, s);
+    }
+#ifdef DZN_TUNING   // probe / ablation instantiations (profiles/r2_gemm_cfg_probe.txt, r2_gemm_ablation.txt): build with
+                    // DZN_TUNING=1 (diarizen_amd/build.py); they triple the compile time of this file
+    if (!strcmp(force, "256x128")) return launch_split_cfg<256, 128, 4, 2, 2, NP>(d, s);
+    if constexpr (NP != 3) {
+      if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
+    }
+    if constexpr (NP <= 2) {
+      // deeper LDS-DMA pipelines (more K tiles in flight per CU): probes of the load-latency bound.  (128x128 with
+      // S = 3 / 4 were probed too — one wavefront per SIMD in the two-term kernel, 30 % slower)
       if (!strcmp(force, "256x128s3")) return launch_split_cfg<256, 128, 4, 2, 3, NP>(d, s);
       if (!strcmp(force, "256x128w8s3")) return launch_split_cfg<256, 128, 8, 1, 3, NP, 2>(d, s);
-      if (!strcmp(force, "128x128s3")) return launch_split_cfg<128, 128, 4, 1, 3, NP>(d, s);
-      if (!strcmp(force, "128x128s4")) return launch_split_cfg<128, 128, 4, 1, 4, NP>(d, s);
       if (!strcmp(force, "128x64s3")) return launch_split_cfg<128, 64, 4, 1, 3, NP>(d, s);
       if (!strcmp(force, "256x64s3")) return launch_split_cfg<256, 64, 8, 1, 3, NP>(d, s);
       if (!strcmp(force, "abl1")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2, 1>(d, s);
@@ -390,7 +402,7 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
       if (!strcmp(force, "abl4")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2, 4>(d, s);
       if (!strcmp(force, "abl5")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2, 5>(d, s);
     }
-    if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
+#endif
   }
   if (d.N <= 32) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
   // 128x64 tiles run 4 wavefronts as 4x1 (32 rows x 64 columns each): the in-register operand

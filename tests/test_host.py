@@ -307,28 +307,32 @@ def test_host_stage_silence_and_single_speaker():
 
 
 # ----------------------------------------------------------------------------- build hygiene
-@pytest.mark.parametrize("src", ["gemm.hip", "gemm_split.hip", "gemm_split_pre.hip", "conv_split.hip"])
-def test_contraction_kernels_do_not_spill(src):
+def test_contraction_kernels_do_not_spill():
     """The contraction kernels keep their accumulators in registers: hipcc must report ScratchSize 0 for every
-    kernel of these files (a fused-epilogue change once sent the 128x192 accumulators to scratch and cost 60 %)."""
+    kernel of these files (a fused-epilogue change once sent the 128x192 accumulators to scratch and cost 60 %).
+    The four files are compiled concurrently (the resource report needs a full device compile of each)."""
     import re
     import shutil
     import subprocess
     from diarizen_amd import build as b
     if not shutil.which(b.HIPCC) and not os.path.exists(b.HIPCC):
         pytest.skip("hipcc not available")
-    r = subprocess.run([b.HIPCC, *b.FLAGS, "-c", str(b.CSRC / src), "-o", os.devnull,
-                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
-    assert sizes and max(sizes) == 0, f"scratch in {src}: {sorted(set(sizes))}"
-    # occupancy: the main contraction tiles must keep 2 wavefronts per SIMD (one extra register in the shared epilogue
-    # once dropped the 128x128 fp16 kernel to 1 and cost 35 % of its rate)
-    names = re.findall(r"Function Name: (\S+)", r.stderr)
-    occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", r.stderr)]
-    for n, o in zip(names, occ):
-        if "gemm_split_kernelILi128ELi" in n or "gemm_split_pre_kernelILi128ELi64" in n:   # the tiles the pipeline launches
-            assert o >= 2, f"{n}: {o} wavefront(s) per SIMD"
+    srcs = ["gemm.hip", "gemm_split.hip", "gemm_split_pre.hip", "conv_split.hip"]
+    procs = {src: subprocess.Popen([b.HIPCC, *b.FLAGS, "-c", str(b.CSRC / src), "-o", os.devnull,
+                                    "-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, text=True) for src in srcs}
+    for src, pr in procs.items():
+        _, err = pr.communicate()
+        assert pr.returncode == 0, err[-2000:]
+        sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", err)]
+        assert sizes and max(sizes) == 0, f"scratch in {src}: {sorted(set(sizes))}"
+        # occupancy: the main contraction tiles must keep 2 wavefronts per SIMD (one extra register in the shared
+        # epilogue once dropped the 128x128 fp16 kernel to 1 and cost 35 % of its rate)
+        names = re.findall(r"Function Name: (\S+)", err)
+        occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", err)]
+        for n, o in zip(names, occ):
+            if "gemm_split_kernelILi128ELi" in n or "gemm_split_pre_kernelILi128ELi64" in n:   # the pipeline's tiles
+                assert o >= 2, f"{n}: {o} wavefront(s) per SIMD"
 
 
 # ---------------------------------------------------------------- e2e host stage vs the independent golden RTTM
