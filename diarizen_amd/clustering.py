@@ -255,10 +255,25 @@ class AgglomerativeClustering:
 
 
 # --------------------------------------------------------------------------- VBx
+HIP_VBX_MIN = 4096       # embeddings; below this numpy's BLAS calls are faster than upload + launches
+
+
 def vb_gmm(X: np.ndarray, Phi: np.ndarray, gamma: np.ndarray, Fa: float, Fb: float, max_iters: int,
-           epsilon: float = 1e-4):
+           epsilon: float = 1e-4, backend: str = "auto", device: int = -1):
     """VBx with loopProb = 0 (the only branch the pipeline exercises, VBx.py:99-107): variational
-    Bayes mixture over speakers in PLDA space; returns responsibilities and speaker priors."""
+    Bayes mixture over speakers in PLDA space; returns responsibilities and speaker priors.
+    backend "numpy": the reference's expressions.  "hip" / "auto" (from HIP_VBX_MIN embeddings up): the two E-sized
+    passes of every iteration (gamma^T rho and the E-step) run on the device in float64 (csrc/vbx.hip) while invL,
+    alpha, the ELBO and the stopping rule stay the expressions below on the K x D statistics."""
+    if backend not in ("auto", "numpy", "hip"):
+        raise ValueError(f"unknown VBx backend {backend!r}")
+    if backend == "hip" or (backend == "auto" and X.shape[0] >= HIP_VBX_MIN and _hip_ready()):
+        from ._lib import DznError
+        try:
+            return _vb_gmm_hip(X, Phi, gamma, Fa, Fb, max_iters, epsilon, device)
+        except (DznError, MemoryError):
+            if backend == "hip":
+                raise
     D = X.shape[1]
     pi = np.ones(gamma.shape[1]) / gamma.shape[1]
     G = -0.5 * (np.sum(X ** 2, axis=1, keepdims=True) + D * np.log(2 * np.pi))
@@ -279,6 +294,34 @@ def vb_gmm(X: np.ndarray, Phi: np.ndarray, gamma: np.ndarray, Fa: float, Fb: flo
             break
         prev = elbo
     return gamma, pi
+
+
+def _vb_gmm_hip(X, Phi, gamma, Fa, Fb, max_iters, epsilon, device):
+    """the loop of vb_gmm with `gamma.T.dot(rho)`, `gamma.sum(0)` (VbxState.stats) and the E-step (VbxState.estep)
+    on the device; everything K x D sized is computed here exactly as above."""
+    from . import ops
+    D = X.shape[1]
+    Phi = np.asarray(Phi, dtype=np.float64)
+    st = ops.VbxState(X, Phi, gamma, device)
+    try:
+        pi = np.ones(gamma.shape[1]) / gamma.shape[1]
+        stats = st.stats()
+        prev = None
+        for it in range(max_iters):
+            invL = 1.0 / (1 + Fa / Fb * stats[:, D:D + 1] * Phi)
+            alpha = Fa / Fb * invL * stats[:, :D]
+            ck = 0.5 * (invL + alpha ** 2).dot(Phi)
+            total = st.estep(alpha, ck, np.log(pi + 1e-8), Fa)
+            stats = st.stats()
+            pi = stats[:, D].copy()
+            pi = pi / pi.sum()
+            elbo = total + Fb * 0.5 * np.sum(np.log(invL) - invL - alpha ** 2 + 1)
+            if it > 0 and elbo - prev < epsilon:
+                break
+            prev = elbo
+        return st.gamma(), pi
+    finally:
+        st.close()
 
 
 def _l2n(x):
@@ -337,7 +380,8 @@ class VBxClustering:
         q0 = np.zeros((len(ahc), ahc.max() + 1))
         q0[range(len(ahc)), ahc.astype(int)] = 1.0
         q0 = softmax(q0 * 7.0, axis=1)                                  # init_smoothing = 7
-        q, sp = vb_gmm(fea, Phi, q0, self.Fa, self.Fb, self.max_iters)
+        q, sp = vb_gmm(fea, Phi, q0, self.Fa, self.Fb, self.max_iters, backend=getattr(self, 'vbx_backend', 'auto'),
+                       device=getattr(self, 'device', -1))
         centroids = q[:, sp > 1e-7].T @ train.reshape(-1, D)            # unnormalised: cosine follows
         soft = _soft_clusters(embeddings, centroids, self.metric, getattr(self, 'cdist_backend', 'auto'),
                               getattr(self, 'device', -1))

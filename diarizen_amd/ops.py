@@ -178,6 +178,57 @@ def cdist_cosine(emb, centroids, device: int = -1):
     return out
 
 
+class VbxState:
+    """the E-sized arrays of the VBx mixture resident on the device (csrc/vbx.hip): X f64 [E, D], Phi f64 [D],
+    gamma0 f64 [E, K]; see diarizen_amd/clustering.py:vb_gmm for the loop that drives it."""
+
+    def __init__(self, X, Phi, gamma0, device: int = -1):
+        import numpy as np
+        self.np, self.lib = np, _lib.load()
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        Phi = np.ascontiguousarray(Phi, dtype=np.float64)
+        g0 = np.ascontiguousarray(gamma0, dtype=np.float64)
+        self.E, self.D = X.shape
+        self.K = g0.shape[1]
+        assert Phi.shape == (self.D,) and g0.shape[0] == self.E
+        self.state = C.c_void_p()
+        check(self.lib.dzn_vbx_create(X.ctypes.data_as(C.c_void_p), Phi.ctypes.data_as(C.c_void_p),
+                                      g0.ctypes.data_as(C.c_void_p), self.E, self.D, self.K, device,
+                                      C.byref(self.state)), what="dzn_vbx_create")
+
+    def stats(self):
+        out = self.np.empty((self.K, self.D + 1), dtype=self.np.float64)
+        check(self.lib.dzn_vbx_stats(self.state, out.ctypes.data_as(C.c_void_p)), what="dzn_vbx_stats")
+        return out
+
+    def estep(self, alpha, ck, lpi, Fa: float) -> float:
+        np = self.np
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        ck = np.ascontiguousarray(ck, dtype=np.float64)
+        lpi = np.ascontiguousarray(lpi, dtype=np.float64)
+        assert alpha.shape == (self.K, self.D) and ck.shape == (self.K,) and lpi.shape == (self.K,)
+        total = C.c_double(0.0)
+        check(self.lib.dzn_vbx_estep(self.state, alpha.ctypes.data_as(C.c_void_p), ck.ctypes.data_as(C.c_void_p),
+                                     lpi.ctypes.data_as(C.c_void_p), float(Fa), C.byref(total)), what="dzn_vbx_estep")
+        return total.value
+
+    def gamma(self):
+        out = self.np.empty((self.E, self.K), dtype=self.np.float64)
+        check(self.lib.dzn_vbx_gamma(self.state, out.ctypes.data_as(C.c_void_p)), what="dzn_vbx_gamma")
+        return out
+
+    def close(self):
+        if self.state:
+            self.lib.dzn_vbx_destroy(self.state)
+            self.state = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # pragma: no cover
+            pass
+
+
 def layernorm(x, gamma, beta, C_true=None, eps=1e-5, gelu=False, out=None):
     lib = _lib.load()
     rows, ld = x.shape[0], x.stride(0)

@@ -227,6 +227,24 @@ int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, double* h_Z
 int dzn_cdist_cosine(const float* h_emb, int32_t n, int32_t dim, const double* h_cent, int32_t k, double* h_dist,
                      int32_t device);
 
+/* Row f1, VBx: the variational-Bayes mixture of diarizen/clustering/VBx.py:27-125 (loopProb = 0 branch :99-107, the
+ * one VBxClustering.__call__ runs) with its two E-sized passes per iteration on the device (csrc/vbx.hip), float64.
+ * The K x D statistics pass through the host, which keeps the reference's expressions for invL / alpha / ELBO and its
+ * stopping rule (diarizen_amd/clustering.py:vb_gmm).  HOST pointers, blocking calls; device < 0 = current.
+ *   dzn_vbx_create   X f64 [E, D] (PLDA-space features), Phi f64 [D], gamma0 f64 [E, K] -> opaque state
+ *   dzn_vbx_stats    h_stats f64 [K, D + 1] <- (gamma^T rho | column sums of gamma), rho = X sqrt(Phi)
+ *   dzn_vbx_estep    alpha f64 [K, D], ck f64 [K] = 0.5 sum_d (invL + alpha^2) Phi, lpi f64 [K] = log(pi + 1e-8):
+ *                    gamma <- softmax_k(Fa (rho alpha^T - ck + G) + lpi); *h_total = sum_e logsumexp_k(...)
+ *   dzn_vbx_gamma    h_gamma f64 [E, K] <- the current responsibilities
+ */
+int dzn_vbx_create(const double* h_X, const double* h_Phi, const double* h_gamma0, int32_t E, int32_t D, int32_t K,
+                   int32_t device, void** out_state);
+int dzn_vbx_stats(void* state, double* h_stats);
+int dzn_vbx_estep(void* state, const double* h_alpha, const double* h_ck, const double* h_lpi, double Fa,
+                  double* h_total);
+int dzn_vbx_gamma(void* state, double* h_gamma);
+int dzn_vbx_destroy(void* state);
+
 #ifdef __cplusplus
 }
 #endif

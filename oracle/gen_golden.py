@@ -251,6 +251,21 @@ def gen_statspool_powerset():
 
 
 # ------------------------------------------------------------------ host clustering
+def synth_vbx_case(E, K, D=128, seed=4):
+    """PLDA-space features with K - 1 real speakers, a diagonal Phi and an imperfect one-hot AHC initialisation smoothed
+    as VBxClustering does (softmax(7 q)): input of the VBx mixture tests (tests/test_host.py, tests/test_ops_gpu.py)."""
+    from scipy.special import softmax
+    r = np.random.default_rng(seed)
+    mu = 3.0 * r.standard_normal((K - 1, D))
+    lab = r.integers(0, K - 1, E)
+    X = mu[lab] + r.standard_normal((E, D))
+    Phi = np.abs(r.standard_normal(D)) * 2.0 + 0.05
+    q0 = np.zeros((E, K))
+    noisy = np.where(r.random(E) < 0.15, r.integers(0, K, E), lab)       # an imperfect AHC initialisation
+    q0[np.arange(E), noisy] = 1.0
+    return X, Phi, softmax(q0 * 7.0, axis=1)
+
+
 def synth_host_case(seed: int, C: int = 60, L: int = 99, S: int = 4, D: int = 256, n_spk: int = 3):
     """synthetic per-window decisions + embeddings with a known speaker structure"""
     g = np.random.default_rng(seed)

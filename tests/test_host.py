@@ -69,6 +69,50 @@ def test_vbx_equals_reference(i, tmp_path):
     assert np.allclose(cent, g[f"vbx{i}_centroids"], rtol=1e-5, atol=1e-6)
 
 
+from oracle.gen_golden import synth_vbx_case as _vbx_case  # noqa: E402
+
+
+class _NumpyVbxState:
+    """what csrc/vbx.hip computes, in numpy: the stand-in that lets the CPU suite check the loop of _vb_gmm_hip"""
+
+    def __init__(self, X, Phi, gamma0, device=-1):
+        self.rho = X * np.sqrt(Phi)
+        self.G = -0.5 * (np.sum(X ** 2, axis=1) + X.shape[1] * np.log(2 * np.pi))
+        self.g = np.array(gamma0, dtype=np.float64)
+
+    def stats(self):
+        return np.concatenate([self.g.T.dot(self.rho), self.g.sum(axis=0)[:, None]], axis=1)
+
+    def estep(self, alpha, ck, lpi, Fa):
+        from scipy.special import logsumexp
+        a = Fa * (self.rho.dot(alpha.T) - ck[None, :] + self.G[:, None]) + lpi[None, :]
+        lpx = logsumexp(a, axis=-1)
+        self.g = np.exp(a - lpx[:, None])
+        return float(np.sum(lpx))
+
+    def gamma(self):
+        return self.g
+
+    def close(self):
+        pass
+
+
+def test_vb_gmm_device_loop_equals_reference_loop(monkeypatch):
+    """clustering._vb_gmm_hip restructures the VBx iteration around two device passes (statistics, E-step); with the
+    passes replaced by their numpy definition the loop must reproduce the reference-shaped vb_gmm: same responsibilities,
+    same priors, same number of iterations (the GPU suite then checks the kernels against this same numpy loop)."""
+    from diarizen_amd import clustering as cl
+    from diarizen_amd import ops
+    monkeypatch.setattr(ops, "VbxState", _NumpyVbxState)
+    for E, K, iters in ((700, 6, 20), (300, 3, 4), (50, 9, 20)):
+        X, Phi, q0 = _vbx_case(E, K)
+        g_ref, pi_ref = cl.vb_gmm(X, Phi, q0.copy(), 0.07, 0.8, iters, backend="numpy")
+        g_new, pi_new = cl._vb_gmm_hip(X, Phi, q0.copy(), 0.07, 0.8, iters, 1e-4, -1)
+        assert np.allclose(g_new, g_ref, rtol=0, atol=1e-10)
+        assert np.allclose(pi_new, pi_ref, rtol=0, atol=1e-12)
+        assert np.array_equal(g_new.argmax(1), g_ref.argmax(1))
+
+
 def test_ahc_does_not_overmerge_reference_unit_test():
     """pyannote-audio/tests/test_clustering.py:6-29: 2 embeddings, threshold 0 -> [0, 1]."""
     from diarizen_amd.clustering import AgglomerativeClustering

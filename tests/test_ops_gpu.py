@@ -444,6 +444,28 @@ def test_cdist_cosine_equals_scipy(built_lib, gpu):
     assert abs(got[7, 0]) < 1e-15 and abs(want[7, 0]) < 1e-15                     # a row that IS a centroid
 
 
+@pytest.mark.parametrize("E,K", [(5000, 7), (20011, 40), (300, 3)])
+def test_vbx_gmm_equals_numpy(built_lib, gpu, E, K):
+    """csrc/vbx.hip (statistics + E-step on the device, float64) against the numpy loop of
+    diarizen/clustering/VBx.py:99-107 as restated in clustering.vb_gmm: responsibilities to 1e-9, priors to 1e-10,
+    identical hard decisions, and the same number of iterations (the ELBO stopping rule sees the same values)."""
+    import numpy as np
+    from diarizen_amd import clustering as cl
+    from oracle.gen_golden import synth_vbx_case as _vbx_case
+    X, Phi, q0 = _vbx_case(E, K)
+    g_ref, pi_ref = cl.vb_gmm(X, Phi, q0.copy(), 0.07, 0.8, 20, backend="numpy")
+    g_dev, pi_dev = cl.vb_gmm(X, Phi, q0.copy(), 0.07, 0.8, 20, backend="hip")
+    assert g_dev.shape == g_ref.shape and np.isfinite(g_dev).all()
+    assert np.abs(g_dev - g_ref).max() <= 1e-9
+    assert np.abs(pi_dev - pi_ref).max() <= 1e-10
+    assert np.array_equal(g_dev.argmax(1), g_ref.argmax(1))
+    assert np.allclose(g_dev.sum(1), 1.0, atol=1e-12)
+    # a single iteration (the stopping rule never fires): the E-step alone
+    g1_ref, _ = cl.vb_gmm(X, Phi, q0.copy(), 0.07, 0.8, 1, backend="numpy")
+    g1_dev, _ = cl.vb_gmm(X, Phi, q0.copy(), 0.07, 0.8, 1, backend="hip")
+    assert np.abs(g1_dev - g1_ref).max() <= 1e-11
+
+
 def test_clustering_backends_agree(built_lib, gpu):
     """AHC and VBx-style AHC initialisation through both linkage backends and both cdist backends: identical hard
     clusters."""
