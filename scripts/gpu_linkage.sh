@@ -1,0 +1,36 @@
+cd $GRAFT_REPO_ROOT
+timeout 300 python -m pytest tests/test_ops_gpu.py -q -k "linkage or backends" 2>&1 | tail -4
+timeout 300 python - <<'PY'
+import sys, time, os
+sys.path.insert(0, '.')
+import numpy as np
+from scipy.cluster.hierarchy import linkage
+from diarizen_amd import ops
+from oracle.gen_golden import synth_host_case
+for minutes in (30, 240):
+    C = int((minutes * 60 - 8.0) / 0.8) + 1
+    seg, emb = synth_host_case(3, C=C, L=99, n_spk=4)
+    e = emb[seg.sum(1) > 0].astype(np.float32)
+    e /= np.linalg.norm(e, axis=-1, keepdims=True)
+    ops.linkage_centroid(e[:3000])
+    t0 = time.perf_counter(); Zg = ops.linkage_centroid(e); tg = time.perf_counter() - t0
+    os.environ["DZN_LINKAGE_NO_GRAPH_PY"] = "1"
+    print(f"LINKAGE {minutes} min: n={len(e)} graph replay {tg:.3f} s", flush=True)
+    if minutes == 30:
+        Zs = linkage(e, method="centroid", metric="euclidean")
+        print("  == scipy:", np.array_equal(Zs[:, [0, 1, 3]], Zg[:, [0, 1, 3]]), float(np.abs(Zs[:, 2] - Zg[:, 2]).max()))
+PY
+DZN_LINKAGE_NO_GRAPH=1 timeout 300 python - <<'PY'
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+from diarizen_amd import ops
+from oracle.gen_golden import synth_host_case
+C = int((240 * 60 - 8.0) / 0.8) + 1
+seg, emb = synth_host_case(3, C=C, L=99, n_spk=4)
+e = emb[seg.sum(1) > 0].astype(np.float32)
+e /= np.linalg.norm(e, axis=-1, keepdims=True)
+ops.linkage_centroid(e[:3000])
+t0 = time.perf_counter(); Zg = ops.linkage_centroid(e); tg = time.perf_counter() - t0
+print(f"LINKAGE 240 min: n={len(e)} plain launches {tg:.3f} s", flush=True)
+PY
