@@ -134,10 +134,6 @@ __global__ __launch_bounds__(1024) void select_kernel(double* __restrict__ D, in
   __shared__ double sval[16];
   __shared__ int sidx[16];
   const int k = st->k;
-  if (k >= n - 1) {            // replayed past the last merge (the launches come in graph-sized batches): nothing to do
-    if (threadIdx.x == 0) st->lo = -1;
-    return;
-  }
   int x, y;
   double d;
   for (int guard = 0; guard <= n; ++guard) {
@@ -178,7 +174,6 @@ __global__ __launch_bounds__(256) void update_kernel(double* __restrict__ D, int
   const int z = blockIdx.x * 256 + threadIdx.x;
   if (z >= n) return;
   const int lo = st->lo, hi = st->hi;
-  if (lo < 0) return;          // no merge was selected (see select_kernel)
   const int nz = size[z];
   if (z == hi) { D[(int64_t)hi * n + lo] = DINF; return; }
   if (nz == 0) return;      // inactive (includes z == lo)
@@ -209,9 +204,6 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   double *D = nullptr, *lb = nullptr, *Z = nullptr;
   int *nb = nullptr, *size = nullptr, *cid = nullptr;
   MergeState* st = nullptr;
-  hipStream_t stream = nullptr;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t gexec = nullptr;
   std::vector<int> ones(n, 1), ids(n);
   for (int i = 0; i < n; ++i) ids[i] = i;
   MergeState st0{};
@@ -230,48 +222,19 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   LCHK(hipMemcpy(st, &st0, sizeof(MergeState), hipMemcpyHostToDevice));
   {
     const int tiles = (n + 63) / 64;
+    hipLaunchKernelGGL(pdist_kernel, dim3(tiles, tiles), dim3(256), 0, 0, E, n, dim, D);
+    hipLaunchKernelGGL(init_rows_kernel, dim3(n), dim3(256), 0, 0, D, n, lb, nb);
     const int ug = (n + 255) / 256;
-    LCHK(hipStreamCreate(&stream));
-    hipLaunchKernelGGL(pdist_kernel, dim3(tiles, tiles), dim3(256), 0, stream, E, n, dim, D);
-    hipLaunchKernelGGL(init_rows_kernel, dim3(n), dim3(256), 0, stream, D, n, lb, nb);
-    // The merge loop is 2 (n - 1) dependent launches of microsecond kernels: launch-bound.  The two launches of
-    // LINK_BATCH merges are captured ONCE into a hipGraph (their arguments never change: the merge index lives in
-    // *st) and the graph is replayed; launches past the last merge return at once (select_kernel's guard).  Large
-    // inputs only; plain launches below that and whenever capture / instantiation is refused.
-    constexpr int LINK_BATCH = 512;
-    static const bool no_graph = getenv("DZN_LINKAGE_NO_GRAPH") != nullptr;
-    bool replayed = false;
-    if (n - 1 >= 4 * LINK_BATCH && !no_graph) {
-      if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        for (int k = 0; k < LINK_BATCH; ++k) {
-          hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, stream, D, n, lb, nb, size, cid, Z, st);
-          hipLaunchKernelGGL(update_kernel, dim3(ug), dim3(256), 0, stream, D, n, lb, nb, size, st);
-        }
-        if (hipStreamEndCapture(stream, &graph) == hipSuccess && graph &&
-            hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess) {
-          replayed = true;
-          for (int k = 0; k < n - 1; k += LINK_BATCH)
-            if (hipGraphLaunch(gexec, stream) != hipSuccess) { rc = DZN_E_HIP; goto done; }
-        }
-      }
-      (void)hipGetLastError();   // a refused capture leaves a sticky error; the plain loop below starts clean
-    }
-    if (!replayed) {
-      for (int k = 0; k < n - 1; ++k) {
-        hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, stream, D, n, lb, nb, size, cid, Z, st);
-        hipLaunchKernelGGL(update_kernel, dim3(ug), dim3(256), 0, stream, D, n, lb, nb, size, st);
-      }
+    for (int k = 0; k < n - 1; ++k) {
+      hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, 0, D, n, lb, nb, size, cid, Z, st);
+      hipLaunchKernelGGL(update_kernel, dim3(ug), dim3(256), 0, 0, D, n, lb, nb, size, st);
     }
   }
   LCHK(hipGetLastError());
-  LCHK(hipStreamSynchronize(stream));
   LCHK(hipMemcpy(h_Z, Z, (size_t)(n - 1) * 4 * sizeof(double), hipMemcpyDeviceToHost));
 done:
   (void)hipFree(D); (void)hipFree(E); (void)hipFree(lb); (void)hipFree(Z);
   (void)hipFree(nb); (void)hipFree(size); (void)hipFree(cid); (void)hipFree(st);
-  if (gexec) (void)hipGraphExecDestroy(gexec);
-  if (graph) (void)hipGraphDestroy(graph);
-  if (stream) (void)hipStreamDestroy(stream);
   return rc;
 }
 
