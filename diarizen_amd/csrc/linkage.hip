@@ -83,15 +83,8 @@ __global__ __launch_bounds__(256) void pdist_kernel(const float* __restrict__ E,
     }
 }
 
-// block-wide argmin (lowest index on ties) of p[0..n); result valid in every thread
-__device__ __forceinline__ void block_argmin(const double* __restrict__ p, int n, double& val, int& idx,
-                                             double* sval, int* sidx) {
-  double v = DINF;
-  int id = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double x = p[i];
-    if (x < v) { v = x; id = i; }   // ascending i per thread: first occurrence kept
-  }
+// block-wide minimum of per-thread (value, index) pairs, lowest index on ties; result valid in every thread
+__device__ __forceinline__ void block_min_pair(double v, int id, double& val, int& idx, double* sval, int* sidx) {
   // wave reduction
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -114,6 +107,31 @@ __device__ __forceinline__ void block_argmin(const double* __restrict__ p, int n
   idx = id;
 }
 
+// block-wide argmin (lowest index on ties) of p[0..n); result valid in every thread
+__device__ __forceinline__ void block_argmin(const double* __restrict__ p, int n, double& val, int& idx,
+                                             double* sval, int* sidx) {
+  double v = DINF;
+  int id = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double x = p[i];
+    if (x < v) { v = x; id = i; }   // ascending i per thread: first occurrence kept
+  }
+  block_min_pair(v, id, val, idx, sval, sidx);
+}
+
+// minima of the bounds per block of LB_BLK rows: the global argmin of lb then scans n / LB_BLK values instead of n
+constexpr int LB_BLK = 256;
+__global__ __launch_bounds__(LB_BLK) void block_minima_kernel(const double* __restrict__ lb, int n,
+                                                              double* __restrict__ bmin, int* __restrict__ barg) {
+  __shared__ double sval[4];
+  __shared__ int sidx[4];
+  const int z = blockIdx.x * LB_BLK + threadIdx.x;
+  double v;
+  int id;
+  block_min_pair(z < n ? lb[z] : DINF, z < n ? z : 0x7fffffff, v, id, sval, sidx);
+  if (threadIdx.x == 0) { bmin[blockIdx.x] = v; barg[blockIdx.x] = id; }
+}
+
 // initial bounds: one workgroup per row
 __global__ __launch_bounds__(256) void init_rows_kernel(const double* __restrict__ D, int n, double* __restrict__ lb,
                                                         int* __restrict__ nb) {
@@ -126,18 +144,61 @@ __global__ __launch_bounds__(256) void init_rows_kernel(const double* __restrict
   if (threadIdx.x == 0) { lb[z] = v; nb[z] = id; }
 }
 
-// one merge, part 1 (single workgroup): find the closest pair, emit the dendrogram row
+// one merge, part 1 (single workgroup): find the closest pair, emit the dendrogram row.
+// The global argmin of the bounds runs over the per-block minima (bmin / barg, kept current by update_kernel and
+// refreshed here for the one block whose row was rescanned); the bound of the row merged LAST (hi of merge k - 1)
+// arrives exact from update_kernel's partial minima of the new row (hp_val / hp_idx) instead of being rescanned.
 __global__ __launch_bounds__(1024) void select_kernel(double* __restrict__ D, int n, double* __restrict__ lb,
                                                       int* __restrict__ nb, int* __restrict__ size,
                                                       int* __restrict__ cid, double* __restrict__ Z,
-                                                      MergeState* __restrict__ st) {
+                                                      MergeState* __restrict__ st, double* __restrict__ bmin,
+                                                      int* __restrict__ barg, const double* __restrict__ hp_val,
+                                                      const int* __restrict__ hp_idx) {
   __shared__ double sval[16];
   __shared__ int sidx[16];
   const int k = st->k;
+  const int nblk = (n + LB_BLK - 1) / LB_BLK;
+  auto refresh_block = [&](int row) {     // recompute the minimum of the block holding `row` (all threads call)
+    const int b = row / LB_BLK, z = b * LB_BLK + threadIdx.x;
+    double v;
+    int id;
+    const bool in = threadIdx.x < LB_BLK && z < n;
+    block_min_pair(in ? lb[z] : DINF, in ? z : 0x7fffffff, v, id, sval, sidx);
+    if (threadIdx.x == 0) { bmin[b] = v; barg[b] = id; }
+    __threadfence_block();
+    __syncthreads();
+  };
+  if (k > 0) {   // exact bound of the row created by the previous merge
+    const int hp = st->hi;
+    double v;
+    int id;
+    double tv = DINF;
+    int ti = 0x7fffffff;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+      const double x = hp_val[i];
+      const int xi = hp_idx[i];
+      if (x < tv || (x == tv && xi < ti)) { tv = x; ti = xi; }
+    }
+    block_min_pair(tv, ti, v, id, sval, sidx);
+    __syncthreads();
+    if (threadIdx.x == 0) { lb[hp] = v; nb[hp] = v < DINF ? id : -1; }
+    __threadfence_block();
+    __syncthreads();
+    refresh_block(hp);
+  }
   int x, y;
   double d;
   for (int guard = 0; guard <= n; ++guard) {
-    block_argmin(lb, n, d, x, sval, sidx);
+    {   // argmin over the block minima (ascending block index per thread, lowest row index on ties)
+      double tv = DINF;
+      int ti = 0x7fffffff;
+      for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        const double v = bmin[i];
+        const int id = barg[i];
+        if (v < tv || (v == tv && id < ti)) { tv = v; ti = id; }
+      }
+      block_min_pair(tv, ti, d, x, sval, sidx);
+    }
     y = nb[x];
     const bool exact = y >= 0 && D[(int64_t)x * n + y] == d;
     if (exact) break;
@@ -148,6 +209,7 @@ __global__ __launch_bounds__(1024) void select_kernel(double* __restrict__ D, in
     if (threadIdx.x == 0) { lb[x] = rv; nb[x] = ri; }
     __threadfence_block();
     __syncthreads();
+    refresh_block(x);
   }
   if (threadIdx.x == 0) {
     const int lo = x < y ? x : y, hi = x < y ? y : x;
@@ -161,33 +223,49 @@ __global__ __launch_bounds__(1024) void select_kernel(double* __restrict__ D, in
     size[hi] = nlo + nhi;    // ... cluster hi becomes the union
     cid[hi] = n + k;
     lb[lo] = DINF;
-    lb[hi] = -1.0;           // below every distance: row hi is rescanned before it can be selected
+    lb[hi] = DINF;           // set exactly by the next select_kernel from update_kernel's partial minima
     nb[hi] = -1;
     st->lo = lo; st->hi = hi; st->nlo = nlo; st->nhi = nhi; st->dist = d; st->k = k + 1;
   }
 }
 
-// one merge, part 2: Lance-Williams centroid update of row / column hi, column lo retired
-__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ D, int n, double* __restrict__ lb,
-                                                     int* __restrict__ nb, const int* __restrict__ size,
-                                                     const MergeState* __restrict__ st) {
-  const int z = blockIdx.x * 256 + threadIdx.x;
-  if (z >= n) return;
+// one merge, part 2: Lance-Williams centroid update of row / column hi, column lo retired; every block leaves the
+// minimum of its slice of the NEW row hi (hp_val / hp_idx) and the minimum of its rows' bounds (bmin / barg)
+__global__ __launch_bounds__(LB_BLK) void update_kernel(double* __restrict__ D, int n, double* __restrict__ lb,
+                                                        int* __restrict__ nb, const int* __restrict__ size,
+                                                        const MergeState* __restrict__ st, double* __restrict__ bmin,
+                                                        int* __restrict__ barg, double* __restrict__ hp_val,
+                                                        int* __restrict__ hp_idx) {
+  __shared__ double sval[4];
+  __shared__ int sidx[4];
+  const int z = blockIdx.x * LB_BLK + threadIdx.x;
   const int lo = st->lo, hi = st->hi;
-  const int nz = size[z];
-  if (z == hi) { D[(int64_t)hi * n + lo] = DINF; return; }
-  if (nz == 0) return;      // inactive (includes z == lo)
-  const int sx = st->nlo, sy = st->nhi;
-  const double dxy = st->dist;
-  const double dxi = D[(int64_t)lo * n + z], dyi = D[(int64_t)hi * n + z];
-  // scipy _hierarchy_distance_update.pxi, _centroid(d_xi, d_yi, d_xy, size_x, size_y, size_i), same order
-  const double nd =
-      sqrt((((sx * dxi * dxi) + (sy * dyi * dyi)) - (sx * sy * dxy * dxy) / (sx + sy)) / (sx + sy));
-  D[(int64_t)hi * n + z] = nd;
-  D[(int64_t)z * n + hi] = nd;
-  D[(int64_t)z * n + lo] = DINF;
-  if (nb[z] == lo) nb[z] = hi;             // a guess; lb[z] stays a valid lower bound
-  if (nd < lb[z]) { lb[z] = nd; nb[z] = hi; }
+  double nd = DINF;          // D[hi][z] after the merge (inf for inactive z, z == hi, z >= n)
+  double myb = DINF;         // lb[z] after the merge
+  if (z < n) {
+    const int nz = size[z];
+    if (z == hi) {
+      D[(int64_t)hi * n + lo] = DINF;
+    } else if (nz != 0) {    // active (z == lo has size 0)
+      const int sx = st->nlo, sy = st->nhi;
+      const double dxy = st->dist;
+      const double dxi = D[(int64_t)lo * n + z], dyi = D[(int64_t)hi * n + z];
+      // scipy _hierarchy_distance_update.pxi, _centroid(d_xi, d_yi, d_xy, size_x, size_y, size_i), same order
+      nd = sqrt((((sx * dxi * dxi) + (sy * dyi * dyi)) - (sx * sy * dxy * dxy) / (sx + sy)) / (sx + sy));
+      D[(int64_t)hi * n + z] = nd;
+      D[(int64_t)z * n + hi] = nd;
+      D[(int64_t)z * n + lo] = DINF;
+      if (nb[z] == lo) nb[z] = hi;             // a guess; lb[z] stays a valid lower bound
+      if (nd < lb[z]) { lb[z] = nd; nb[z] = hi; }
+    }
+    myb = lb[z];             // rows lo / hi hold +inf here (select_kernel); hi gets its exact bound next
+  }
+  double v;
+  int id;
+  block_min_pair(nd, z < n ? z : 0x7fffffff, v, id, sval, sidx);
+  if (threadIdx.x == 0) { hp_val[blockIdx.x] = v; hp_idx[blockIdx.x] = id; }
+  block_min_pair(myb, z < n ? z : 0x7fffffff, v, id, sval, sidx);
+  if (threadIdx.x == 0) { bmin[blockIdx.x] = v; barg[blockIdx.x] = id; }
 }
 
 #define LCHK(call)                                   \
@@ -201,8 +279,9 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   if (!h_emb || !h_Z || n < 2 || dim < 1) return DZN_E_INVALID;
   int rc = DZN_OK;
   float* E = nullptr;
-  double *D = nullptr, *lb = nullptr, *Z = nullptr;
-  int *nb = nullptr, *size = nullptr, *cid = nullptr;
+  double *D = nullptr, *lb = nullptr, *Z = nullptr, *bmin = nullptr, *hp_val = nullptr;
+  int *nb = nullptr, *size = nullptr, *cid = nullptr, *barg = nullptr, *hp_idx = nullptr;
+  const int nblk = (n + LB_BLK - 1) / LB_BLK;
   MergeState* st = nullptr;
   std::vector<int> ones(n, 1), ids(n);
   for (int i = 0; i < n; ++i) ids[i] = i;
@@ -216,6 +295,10 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   LCHK(hipMalloc(&size, (size_t)n * sizeof(int)));
   LCHK(hipMalloc(&cid, (size_t)n * sizeof(int)));
   LCHK(hipMalloc(&st, sizeof(MergeState)));
+  LCHK(hipMalloc(&bmin, (size_t)nblk * sizeof(double)));
+  LCHK(hipMalloc(&hp_val, (size_t)nblk * sizeof(double)));
+  LCHK(hipMalloc(&barg, (size_t)nblk * sizeof(int)));
+  LCHK(hipMalloc(&hp_idx, (size_t)nblk * sizeof(int)));
   LCHK(hipMemcpy(E, h_emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice));
   LCHK(hipMemcpy(size, ones.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
   LCHK(hipMemcpy(cid, ids.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
@@ -224,10 +307,12 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
     const int tiles = (n + 63) / 64;
     hipLaunchKernelGGL(pdist_kernel, dim3(tiles, tiles), dim3(256), 0, 0, E, n, dim, D);
     hipLaunchKernelGGL(init_rows_kernel, dim3(n), dim3(256), 0, 0, D, n, lb, nb);
-    const int ug = (n + 255) / 256;
+    hipLaunchKernelGGL(block_minima_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, lb, n, bmin, barg);
     for (int k = 0; k < n - 1; ++k) {
-      hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, 0, D, n, lb, nb, size, cid, Z, st);
-      hipLaunchKernelGGL(update_kernel, dim3(ug), dim3(256), 0, 0, D, n, lb, nb, size, st);
+      hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, 0, D, n, lb, nb, size, cid, Z, st, bmin, barg, hp_val,
+                         hp_idx);
+      hipLaunchKernelGGL(update_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, D, n, lb, nb, size, st, bmin, barg, hp_val,
+                         hp_idx);
     }
   }
   LCHK(hipGetLastError());
@@ -235,6 +320,7 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
 done:
   (void)hipFree(D); (void)hipFree(E); (void)hipFree(lb); (void)hipFree(Z);
   (void)hipFree(nb); (void)hipFree(size); (void)hipFree(cid); (void)hipFree(st);
+  (void)hipFree(bmin); (void)hipFree(hp_val); (void)hipFree(barg); (void)hipFree(hp_idx);
   return rc;
 }
 
