@@ -123,6 +123,20 @@ __device__ __forceinline__ void block_argmin(const double* __restrict__ p, int n
   block_min_pair(v, id, val, idx, sval, sidx);
 }
 
+// the same over the ACTIVE columns only (size[i] != 0): retired clusters keep their last distances in D — blanking
+// column `lo` in every row was a second scattered 8-byte write per row and merge, and those writes (one DRAM page
+// each) are what a merge costs at n >= 30 k
+__device__ __forceinline__ void block_argmin_active(const double* __restrict__ p, const int* __restrict__ size, int n,
+                                                    double& val, int& idx, double* sval, int* sidx) {
+  double v = DINF;
+  int id = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double x = size[i] != 0 ? p[i] : DINF;
+    if (x < v) { v = x; id = i; }
+  }
+  block_min_pair(v, id, val, idx, sval, sidx);
+}
+
 // minima of the bounds per block of LB_BLK rows: the global argmin of lb then scans n / LB_BLK values instead of n
 constexpr int LB_BLK = 256;
 __global__ __launch_bounds__(LB_BLK) void block_minima_kernel(const double* __restrict__ lb, int n,
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(1024) void select_kernel(double* __restrict__ D, in
     if (exact) break;
     double rv;
     int ri;
-    block_argmin(D + (int64_t)x * n, n, rv, ri, sval, sidx);   // stale bound: rescan row x
+    block_argmin_active(D + (int64_t)x * n, size, n, rv, ri, sval, sidx);   // stale bound: rescan row x
     __syncthreads();
     if (threadIdx.x == 0) { lb[x] = rv; nb[x] = ri; }
     __threadfence_block();
@@ -257,8 +271,7 @@ __global__ __launch_bounds__(LB_BLK) void update_kernel(double* __restrict__ D, 
       // scipy _hierarchy_distance_update.pxi, _centroid(d_xi, d_yi, d_xy, size_x, size_y, size_i), same order
       nd = sqrt((((sx * dxi * dxi) + (sy * dyi * dyi)) - (sx * sy * dxy * dxy) / (sx + sy)) / (sx + sy));
       D[(int64_t)hi * n + z] = nd;
-      D[(int64_t)z * n + hi] = nd;
-      D[(int64_t)z * n + lo] = DINF;
+      D[(int64_t)z * n + hi] = nd;             // column lo is NOT blanked: readers of a row mask by size[] instead
       if (nb[z] == lo) nb[z] = hi;             // a guess; lb[z] stays a valid lower bound
       if (nd < lb[z]) { lb[z] = nd; nb[z] = hi; }
     }
