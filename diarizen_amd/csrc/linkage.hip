@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void pdist_kernel(const float* __restrict__ E,
     }
 }
 
+constexpr int SCAN_U = 8;   // loads in flight per thread in the row scans
+
 // block-wide minimum of per-thread (value, index) pairs, lowest index on ties; result valid in every thread
 __device__ __forceinline__ void block_min_pair(double v, int id, double& val, int& idx, double* sval, int* sidx) {
   // wave reduction
@@ -116,9 +118,18 @@ __device__ __forceinline__ void block_argmin(const double* __restrict__ p, int n
                                              double* sval, int* sidx) {
   double v = DINF;
   int id = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double x = p[i];
-    if (x < v) { v = x; id = i; }   // ascending i per thread: first occurrence kept
+  // SCAN_U independent loads in flight per thread: one load per iteration left the single workgroup of the
+  // selection kernel waiting a full memory latency per 8 KB of the row
+  for (int i0 = threadIdx.x; i0 < n; i0 += SCAN_U * blockDim.x) {
+    double xs[SCAN_U];
+#pragma unroll
+    for (int u = 0; u < SCAN_U; ++u) {
+      const int i = i0 + u * blockDim.x;
+      xs[u] = i < n ? p[i] : DINF;
+    }
+#pragma unroll
+    for (int u = 0; u < SCAN_U; ++u)
+      if (xs[u] < v) { v = xs[u]; id = i0 + u * blockDim.x; }   // ascending i per thread: first occurrence kept
   }
   block_min_pair(v, id, val, idx, sval, sidx);
 }
@@ -130,9 +141,18 @@ __device__ __forceinline__ void block_argmin_active(const double* __restrict__ p
                                                     double& val, int& idx, double* sval, int* sidx) {
   double v = DINF;
   int id = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double x = size[i] != 0 ? p[i] : DINF;
-    if (x < v) { v = x; id = i; }
+  for (int i0 = threadIdx.x; i0 < n; i0 += SCAN_U * blockDim.x) {
+    double xs[SCAN_U];
+    int sz[SCAN_U];
+#pragma unroll
+    for (int u = 0; u < SCAN_U; ++u) {
+      const int i = i0 + u * blockDim.x;
+      xs[u] = i < n ? p[i] : DINF;
+      sz[u] = i < n ? size[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < SCAN_U; ++u)
+      if (sz[u] != 0 && xs[u] < v) { v = xs[u]; id = i0 + u * blockDim.x; }
   }
   block_min_pair(v, id, val, idx, sval, sidx);
 }
