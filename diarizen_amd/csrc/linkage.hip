@@ -17,7 +17,8 @@
 //     written in scipy's operation order in float64, bounds refreshed);
 //   * the global argmin of lb runs over per-block minima (256 rows per block, kept current by the update kernel), and
 //     the bound of the row a merge creates arrives exact from the update kernel's partial minima of that row — the
-//     remaining cost is the rescan of rows whose bound went stale (one 8 n-byte row read by one workgroup each);
+//     rescans of rows whose bound went stale (0.6 per merge) keep 8 loads in flight per thread and mask retired
+//     columns by size[] (retired columns are not blanked: that was a second scattered write per row and merge);
 //   * no host round trip inside the loop: 2(n-1) launches are queued back to back (replaying them from a hipGraph
 //     was measured: no gain, the loop is not launch-bound).
 // With no exact ties in the data the merge sequence — hence the dendrogram Z and every flat
