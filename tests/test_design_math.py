@@ -109,3 +109,104 @@ def test_weight_plane_k_permutation_matches_the_a_slots():
         ks_in_order = sorted(ks, key=lambda k: pos[k])
         # ... = fp32 slot q (k = 4q .. 4q+3) followed by slot 4 + q (k = 16+4q .. 16+4q+3) of the A row
         assert ks_in_order == list(range(4 * q, 4 * q + 4)) + list(range(16 + 4 * q, 16 + 4 * q + 4))
+
+
+# ----------------------------------------------------------------------------- 4. device linkage, as an algorithm
+def _linkage_model(e, BLK):
+    """csrc/linkage.hip step for step in numpy: lower bounds lb / guesses nb per row, the global argmin over per-block
+    minima (bmin / barg), the merged row's bound taken exact from the partial minima of the NEW row, stale bounds rescanned
+    over ACTIVE columns only (retired columns keep their last distances), Lance-Williams centroid update in scipy's
+    operation order.  Returns the dendrogram and the number of rescans."""
+    n = len(e)
+    nblk = (n + BLK - 1) // BLK
+    x64 = e.astype(np.float64)
+    D = np.sqrt(((x64[:, None, :] - x64[None, :, :]) ** 2).sum(-1))
+    np.fill_diagonal(D, np.inf)
+    lb = D.min(axis=1)
+    nb = D.argmin(axis=1)
+    size = np.ones(n, dtype=np.int64)
+    cid = np.arange(n)
+    Z = np.zeros((n - 1, 4))
+
+    def block_minima():
+        bm = np.full(nblk, np.inf)
+        ba = np.full(nblk, 2 ** 31 - 1, dtype=np.int64)
+        for b in range(nblk):
+            seg = lb[b * BLK:(b + 1) * BLK]
+            j = int(np.argmin(seg))                     # lowest row on ties
+            bm[b], ba[b] = seg[j], b * BLK + j
+        return bm, ba
+
+    def refresh(bm, ba, row):
+        b = row // BLK
+        seg = lb[b * BLK:(b + 1) * BLK]
+        j = int(np.argmin(seg))
+        bm[b], ba[b] = seg[j], b * BLK + j
+
+    bm, ba = block_minima()
+    hp = None
+    rescans = 0
+    for k in range(n - 1):
+        if hp is not None:                              # select_kernel, k > 0: exact bound of the previous merge's row
+            hi_prev, hp_val, hp_idx = hp
+            order = np.lexsort((hp_idx, hp_val))
+            v, i = hp_val[order[0]], hp_idx[order[0]]
+            lb[hi_prev], nb[hi_prev] = v, (i if v < np.inf else -1)
+            refresh(bm, ba, hi_prev)
+        while True:
+            o = np.lexsort((ba, bm))[0]                 # lowest value, then lowest row index
+            d, x = bm[o], int(ba[o])
+            y = int(nb[x])
+            if y >= 0 and D[x, y] == d:
+                break
+            row = np.where(size != 0, D[x], np.inf)     # block_argmin_active
+            j = int(np.argmin(row))
+            lb[x], nb[x] = row[j], j
+            refresh(bm, ba, x)
+            rescans += 1
+        lo, hi = (x, y) if x < y else (y, x)
+        nlo, nhi = int(size[lo]), int(size[hi])
+        Z[k] = (min(cid[lo], cid[hi]), max(cid[lo], cid[hi]), d, nlo + nhi)
+        size[lo], size[hi], cid[hi] = 0, nlo + nhi, n + k
+        lb[lo] = lb[hi] = np.inf
+        nb[hi] = -1
+        # update_kernel
+        sx, sy, dxy = float(nlo), float(nhi), d
+        newrow = np.full(n, np.inf)
+        for z in range(n):
+            if z == hi or size[z] == 0:
+                continue
+            dxi, dyi = D[lo, z], D[hi, z]
+            nd = np.sqrt((((sx * dxi * dxi) + (sy * dyi * dyi)) - (sx * sy * dxy * dxy) / (sx + sy)) / (sx + sy))
+            newrow[z] = nd
+            D[hi, z] = D[z, hi] = nd                    # column lo is NOT blanked
+            if nb[z] == lo:
+                nb[z] = hi
+            if nd < lb[z]:
+                lb[z], nb[z] = nd, hi
+        hp_val = np.full(nblk, np.inf)
+        hp_idx = np.full(nblk, 2 ** 31 - 1, dtype=np.int64)
+        for b in range(nblk):
+            seg = newrow[b * BLK:(b + 1) * BLK]
+            j = int(np.argmin(seg))
+            hp_val[b], hp_idx[b] = seg[j], b * BLK + j
+        hp = (hi, hp_val, hp_idx)
+        bm, ba = block_minima()
+    return Z, rescans
+
+
+def test_linkage_algorithm_model_equals_scipy():
+    """The restructured selection of csrc/linkage.hip (block minima, exact bound of the merged row, masked rescans) is a
+    different route to the SAME greedy centroid linkage: the model reproduces scipy's dendrogram on clustered unit vectors
+    for several block sizes, including n not a multiple of the block and blocks larger than n."""
+    from scipy.cluster.hierarchy import linkage
+    r = np.random.default_rng(7)
+    for n, K, BLK in ((23, 3, 4), (60, 4, 8), (61, 5, 3), (40, 2, 64), (97, 6, 16)):
+        cent = r.standard_normal((K, 12))
+        e = (cent[r.integers(0, K, n)] + 0.3 * r.standard_normal((n, 12))).astype(np.float32)
+        e /= np.linalg.norm(e, axis=1, keepdims=True)
+        Z, rescans = _linkage_model(e, BLK)
+        Zs = linkage(e.astype(np.float64), method="centroid", metric="euclidean")
+        assert np.array_equal(Z[:, [0, 1, 3]], Zs[:, [0, 1, 3]]), (n, K, BLK)
+        assert np.abs(Z[:, 2] - Zs[:, 2]).max() < 1e-12
+        assert rescans < 2 * n                          # stale bounds are the exception, not the rule
