@@ -167,7 +167,16 @@ def _set_num_clusters(n, num_clusters, min_clusters, max_clusters):
 
 
 # --------------------------------------------------------------------------- AHC
-class AgglomerativeClustering:
+class _DeviceBackends:
+    """where the optional device accelerators of the host stage run; DiariZenPipeline sets `device` to its own HIP device.
+    Each backend is "auto" (device from a size threshold up when a HIP device is present), "hip", or the host library."""
+    device: int = -1              # HIP device ordinal for csrc/linkage.hip / vbx.hip (-1 = current)
+    linkage_backend: str = "auto"  # "scipy" = scipy.cluster.hierarchy.linkage
+    cdist_backend: str = "auto"    # "scipy" = scipy.spatial.distance.cdist
+    vbx_backend: str = "auto"      # "numpy" = the reference-shaped loop in vb_gmm
+
+
+class AgglomerativeClustering(_DeviceBackends):
     def __init__(self, metric: str = "cosine", max_num_embeddings: float = np.inf,
                  constrained_assignment: bool = True, method: str = "centroid", threshold: float = 0.6,
                  min_cluster_size: int = 13, linkage_backend: str = "auto"):
@@ -185,7 +194,7 @@ class AgglomerativeClustering:
         if self.metric == "cosine" and self.method in ("centroid", "median", "ward"):
             with np.errstate(divide="ignore", invalid="ignore"):
                 emb /= np.linalg.norm(emb, axis=-1, keepdims=True)      # in place, like the reference
-            dendro = (centroid_linkage(emb, self.linkage_backend, getattr(self, 'device', -1)) if self.method == "centroid"
+            dendro = (centroid_linkage(emb, self.linkage_backend, self.device) if self.method == "centroid"
                       else linkage(emb, method=self.method, metric="euclidean"))
         else:
             dendro = linkage(emb, method=self.method, metric=self.metric)
@@ -248,8 +257,8 @@ class AgglomerativeClustering:
         K = int(np.max(train_clusters)) + 1
         train = embeddings[ci, si]
         centroids = np.vstack([np.mean(train[train_clusters == k], axis=0) for k in range(K)])
-        soft = _soft_clusters(embeddings, centroids, self.metric, getattr(self, 'cdist_backend', 'auto'),
-                              getattr(self, 'device', -1))
+        soft = _soft_clusters(embeddings, centroids, self.metric, self.cdist_backend,
+                              self.device)
         hard = constrained_argmax(soft) if self.constrained_assignment else np.argmax(soft, axis=2)
         return hard, soft, centroids
 
@@ -349,7 +358,7 @@ def load_plda(plda_dir: str):
     return xvec_tf, plda_tf, psi
 
 
-class VBxClustering:
+class VBxClustering(_DeviceBackends):
     def __init__(self, metric: str = "cosine", max_num_embeddings: float = np.inf,
                  constrained_assignment: bool = True, plda_dir: str = "", lda_dim: int = 128,
                  max_iters: int = 20, ahc_criterion: str = "distance", ahc_threshold: float = 0.6,
@@ -369,7 +378,7 @@ class VBxClustering:
             return (np.zeros((C, S), dtype=np.int8), np.ones((C, S, 1)),
                     np.mean(train, axis=0, keepdims=True))
         normed = train / np.linalg.norm(train, axis=1, keepdims=True)
-        dendro = centroid_linkage(normed, self.linkage_backend, getattr(self, 'device', -1))
+        dendro = centroid_linkage(normed, self.linkage_backend, self.device)
         ahc = fcluster(dendro, self.ahc_threshold, criterion=self.ahc_criterion) - 1
         _, ahc = np.unique(ahc, return_inverse=True)
         if self._plda is None:
@@ -380,11 +389,11 @@ class VBxClustering:
         q0 = np.zeros((len(ahc), ahc.max() + 1))
         q0[range(len(ahc)), ahc.astype(int)] = 1.0
         q0 = softmax(q0 * 7.0, axis=1)                                  # init_smoothing = 7
-        q, sp = vb_gmm(fea, Phi, q0, self.Fa, self.Fb, self.max_iters, backend=getattr(self, 'vbx_backend', 'auto'),
-                       device=getattr(self, 'device', -1))
+        q, sp = vb_gmm(fea, Phi, q0, self.Fa, self.Fb, self.max_iters, backend=self.vbx_backend,
+                       device=self.device)
         centroids = q[:, sp > 1e-7].T @ train.reshape(-1, D)            # unnormalised: cosine follows
-        soft = _soft_clusters(embeddings, centroids, self.metric, getattr(self, 'cdist_backend', 'auto'),
-                              getattr(self, 'device', -1))
+        soft = _soft_clusters(embeddings, centroids, self.metric, self.cdist_backend,
+                              self.device)
         hard = constrained_argmax(soft) if self.constrained_assignment else np.argmax(soft, axis=2)
         _, hard = np.unique(hard, return_inverse=True)
         return hard.reshape(C, S), soft, centroids
