@@ -3,12 +3,17 @@
 // accumulate.  The accumulator block of lane (lr, lq) is C[m = ..+lr][n0 .. n0+3] (operands are
 // fed to the MFMA swapped, so a lane owns 4 consecutive columns -> float4 traffic).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
+// General form: every feature test and every column guard sits inside the (i, j) block loop.  Correct for any N / stride,
+// but each block then is its own chain of load -> s_waitcnt vmcnt(0) -> use (col_scale, ln_colsum, bias, R, WS ...):
+// 16 blocks x 3-5 dependent round trips.  Kept for unaligned shapes only; gemm_epilogue() below is the one that runs.
 template <int BM, int BN, int TM, int TN, int MI, int NI>
-__device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
+__device__ __forceinline__ void gemm_epilogue_general(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
                                               int wm, int wn, int lr, int lq, int64_t cz, int64_t bz, int z0 = 0,
                                               const float* row_inv = nullptr, const float* col_scale = nullptr) {
   // ---- epilogue: lane (lr, lq) of block (i, j) holds row m = ..+lr, columns n0..n0+3 ----
@@ -125,6 +130,182 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
       } else {
         amax = fmaxf(amax, amax_row);
       }
+    }
+  }
+  if (two_unit) {
+    track_amax(d.c_amax + unit0, amax);
+    if (wrow0 + TM > boundary && boundary < d.M) track_amax(d.c_amax + unit0 + 1, amax_hi);   // wave-uniform
+  } else if (d.c_amax && d.amax_unit <= 0) {
+    track_amax(d.c_amax + z0, amax);
+  }
+}
+
+template <int ACT>
+__device__ __forceinline__ float apply_act_c(float v) {
+  if constexpr (ACT == DZN_ACT_GELU) return gelu_erf(v);
+  else if constexpr (ACT == DZN_ACT_SWISH) return swishf_(v);
+  else if constexpr (ACT == DZN_ACT_RELU) return fmaxf(v, 0.0f);
+  else return v;
+}
+
+// The epilogue that runs (round 3).  r2's form (gemm_epilogue_general) cost a fixed ~400 us per launch on the M = 149 k,
+// N = 1024 contractions whatever K was — 1.2 GB of C + R moved at 3 TB/s, a third of the K = 1024 launch — because
+// every (i, j) block waited for its own loads one after the other.  Here the loads are BATCHED: the column vectors
+// (col_scale, ln_colsum, bias: one float4 per j) are fetched once, then per 16-row block all NI residual float4s are
+// in flight together, all NI stores follow, and the layer-weighted-sum read-modify-write is a second batched pass.
+// Out-of-range rows / columns load from clamped (valid) addresses and only their STORES are predicated, so there is
+// no control flow between the loads.  Needs 4-element alignment of N and every stride (else the general form).
+template <int BM, int BN, int TM, int TN, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
+                                              int wm, int wn, int lr, int lq, int64_t cz, int64_t bz, int z0 = 0,
+                                              const float* row_inv = nullptr, const float* col_scale = nullptr) {
+  const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0 && d.N >= 4;
+  if (!vec) {
+    gemm_epilogue_general<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, col_scale);
+    return;
+  }
+  const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
+  const int ncol0 = tn * BN + wn * TN + lq * 4;          // column of block j: ncol0 + 16 j
+  int nc[NI];                                            // ... clamped for the loads
+  bool nok[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n0 = ncol0 + j * 16;
+    nok[j] = n0 < d.N;                                   // N % 4 == 0: a float4 is inside or outside as a whole
+    nc[j] = nok[j] ? n0 : d.N - 4;
+  }
+  // column vectors, one batch
+  float4 cs4[NI], lc4[NI], b4[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    cs4[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+    lc4[j] = b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (col_scale) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) cs4[j] = *reinterpret_cast<const float4*>(col_scale + nc[j]);
+  }
+  if (d.ln_stats) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) lc4[j] = *reinterpret_cast<const float4*>(d.ln_colsum + nc[j]);
+  }
+  if (bias) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) b4[j] = *reinterpret_cast<const float4*>(bias + nc[j]);
+  }
+  float amax = 0.f, amax_hi = 0.f;
+  const int wrow0 = tm * BM + wm * TM;
+  const bool two_unit = d.c_amax && d.amax_unit >= TM;
+  const int unit0 = two_unit ? (wrow0 < d.M ? wrow0 : d.M - 1) / d.amax_unit : 0;
+  const int boundary = two_unit ? (unit0 + 1) * d.amax_unit : 0;
+  int64_t crow[MI];
+  bool mok[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = tm * BM + wm * TM + i * 16 + lr;
+    mok[i] = m < d.M;
+    const int mc = mok[i] ? m : d.M - 1;
+    crow[i] = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[mc] : (int64_t)mc * d.ldc);
+  }
+  // one 16-row block; the activation is a template argument so that the element loop has no control flow
+  auto row_block = [&](auto actc, const int i) {
+    constexpr int ACT = decltype(actc)::value;
+    const int m = tm * BM + wm * TM + i * 16 + lr;
+    const int mc = mok[i] ? m : d.M - 1;
+    const float acc_scale = (col_scale && row_inv) ? row_inv[i] : 1.f;
+    float ln_mu = 0.f, ln_rs = 1.f;
+    if (d.ln_stats) {
+      const float2 st = *reinterpret_cast<const float2*>(d.ln_stats + 2 * (int64_t)mc);
+      ln_mu = st.x;
+      ln_rs = st.y;
+    }
+    float4 r4[NI];
+    if (d.R) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) r4[j] = *reinterpret_cast<const float4*>(d.R + crow[i] + nc[j]);
+    }
+    float amax_row = 0.f, st_s = 0.f, st_q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      f32x4 v = acc[i][j];
+      if (col_scale) {   // fp16 two-term operands were scaled by exact powers of two: undo (exact)
+        v[0] *= acc_scale * cs4[j].x; v[1] *= acc_scale * cs4[j].y; v[2] *= acc_scale * cs4[j].z; v[3] *= acc_scale * cs4[j].w;
+      }
+      if (d.ln_stats) {
+        v[0] = ln_rs * (v[0] - ln_mu * lc4[j].x); v[1] = ln_rs * (v[1] - ln_mu * lc4[j].y);
+        v[2] = ln_rs * (v[2] - ln_mu * lc4[j].z); v[3] = ln_rs * (v[3] - ln_mu * lc4[j].w);
+      }
+      if (bias) { v[0] += b4[j].x; v[1] += b4[j].y; v[2] += b4[j].z; v[3] += b4[j].w; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act_c<ACT>(v[e]) * d.alpha;
+      if (d.R) { v[0] += r4[j].x; v[1] += r4[j].y; v[2] += r4[j].z; v[3] += r4[j].w; }
+      if (d.post_relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      acc[i][j] = v;
+      if (nok[j]) {      // statistics / |max| over the columns that exist
+        amax_row = fmaxf(fmaxf(amax_row, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        st_s += (v[0] + v[1]) + (v[2] + v[3]);
+        st_q = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], st_q))));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      if (mok[i] && nok[j])
+        *reinterpret_cast<float4*>(d.C + crow[i] + nc[j]) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    if (!mok[i]) return;
+    if (d.stat_partial) {
+      float s1 = st_s + __shfl_xor(st_s, 16, 64), q1 = st_q + __shfl_xor(st_q, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      q1 += __shfl_xor(q1, 32, 64);
+      if (lq == 0) {
+        const int P = ((d.N + BN - 1) / BN) * (BN / TN);
+        reinterpret_cast<float2*>(d.stat_partial)[(int64_t)m * P + tn * (BN / TN) + wn] = make_float2(s1, q1);
+      }
+    }
+    if (d.c_amax) {
+      if (two_unit) {
+        if (m < boundary) amax = fmaxf(amax, amax_row);
+        else amax_hi = fmaxf(amax_hi, amax_row);
+      } else if (d.amax_unit > 0) {
+        float r = fmaxf(amax_row, __shfl_xor(amax_row, 16, 64));
+        r = fmaxf(r, __shfl_xor(r, 32, 64));
+        if (lq == 0) track_amax_lane(d.c_amax + m / d.amax_unit, r);
+      } else {
+        amax = fmaxf(amax, amax_row);
+      }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    switch (d.act) {
+      case DZN_ACT_GELU: row_block(std::integral_constant<int, DZN_ACT_GELU>{}, i); break;
+      case DZN_ACT_SWISH: row_block(std::integral_constant<int, DZN_ACT_SWISH>{}, i); break;
+      case DZN_ACT_RELU: row_block(std::integral_constant<int, DZN_ACT_RELU>{}, i); break;
+      default: row_block(std::integral_constant<int, DZN_ACT_NONE>{}, i); break;
+    }
+  }
+  // layer-weighted sum: WS (+)= ws_w * v, a second batched read-modify-write pass over the finished values
+  if (d.WS) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = tm * BM + wm * TM + i * 16 + lr;
+      const int mc = mok[i] ? m : d.M - 1;
+      float* wrow = d.WS + (int64_t)mc * d.ldws;
+      float4 w4[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) w4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!d.ws_init) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) w4[j] = *reinterpret_cast<const float4*>(wrow + nc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        if (mok[i] && nok[j])
+          *reinterpret_cast<float4*>(wrow + nc[j]) =
+              make_float4(w4[j].x + d.ws_w * acc[i][j][0], w4[j].y + d.ws_w * acc[i][j][1], w4[j].z + d.ws_w * acc[i][j][2],
+                          w4[j].w + d.ws_w * acc[i][j][3]);
     }
   }
   if (two_unit) {

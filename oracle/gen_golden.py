@@ -472,8 +472,78 @@ def gen_e2e():
     (GOLD / "e2e_EN2002a_30s.rttm").write_text(rttm)
 
 
+
+# ------------------------------------------------------------------ host stage by the REFERENCE's own functions
+HOST_REF_CASES = [
+    # name, seed, C, L, S, window duration (s), step ratio, clusters, max_speakers
+    ("w2s_c60", 21, 60, 99, 4, 2.0, 0.1, 3, 20),
+    ("w2s_c200", 22, 200, 99, 4, 2.0, 0.1, 6, 20),
+    ("w5s_c40_step50", 23, 40, 249, 4, 5.0, 0.5, 4, 20),
+    ("w8s_c1", 24, 1, 399, 4, 8.0, 0.1, 2, 20),
+    ("w8s_c7_cap1", 25, 7, 399, 4, 8.0, 0.1, 3, 1),          # count capped by max_speakers (inference.py:163)
+    ("w2s_c30_pad", 26, 30, 99, 4, 2.0, 0.1, 1, 20),         # fewer clusters than the frame count: np.pad branch
+    ("w2s_c25_s3", 27, 25, 99, 3, 2.0, 0.25, 5, 20),
+]
+
+
+def synth_decisions(seed, C, L, S, K):
+    """hard decisions with overlap, silence and inactive local speakers + a cluster per (window, local speaker),
+    several local speakers of one window sometimes sharing a cluster (the max branch of reconstruct)"""
+    g = np.random.default_rng(seed)
+    seg = np.zeros((C, L, S), dtype=np.uint8)
+    for c in range(C):
+        for s in range(S):
+            if g.random() < 0.3:
+                continue                                 # inactive local speaker
+            for _ in range(g.integers(1, 4)):
+                a = int(g.integers(0, L - 3))
+                b = int(min(L, a + g.integers(2, max(3, L // 2))))
+                seg[c, a:b, s] = 1
+    hard = g.integers(0, K, size=(C, S)).astype(np.int8)
+    return seg, hard
+
+
+def gen_host_ref():
+    """tests/golden/host_ref.npz: the reference's OWN aggregate / speaker_count / reconstruct / to_diarization / Binarize
+    (oracle/ref_host.py imports them by path) on seeded decisions -> count, discrete diarization, RTTM text; plus
+    Inference.aggregate with hamming / warm-up / NaN.  oracle/host_stage.py and the product's run_host_stage must both
+    reproduce every array and every RTTM byte (tests/test_host.py)."""
+    from oracle import ref_host
+    out = {}
+    g = np.load(GOLD / "e2e_EN2002a_30s.npz")
+    for tag, hard in (("", g["hard_clusters"]), ("_vbx", g["hard_clusters_vbx"])):
+        rttm = ref_host.host_stage(g["seg"], hard, 8.0, 0.1, 20, "EN2002a")
+        assert rttm == (GOLD / f"e2e_EN2002a_30s{tag}.rttm").read_text(), "reference host stage != committed e2e golden"
+    names = []
+    for name, seed, C, L, S, dur, ratio, K, max_spk in HOST_REF_CASES:
+        seg, hard = synth_decisions(seed, C, L, S, K)
+        rttm, parts = ref_host.host_stage(seg, hard, dur, ratio, max_spk, name, return_parts=True)
+        out[f"{name}_seg"], out[f"{name}_hard"] = seg, hard
+        out[f"{name}_args"] = np.array([dur, ratio, max_spk], dtype=np.float64)
+        out[f"{name}_count"], out[f"{name}_binary"] = parts["count"], parts["binary"].astype(np.uint8)
+        out[f"{name}_activations"] = parts["activations"]
+        out[f"{name}_frames"] = parts["frames"]
+        out[f"{name}_rttm"] = np.frombuffer(rttm.encode(), dtype=np.uint8)
+        names.append(name)
+        print(f"host_ref {name}: frames {parts['binary'].shape}, max count {int(parts['count'].max())}, "
+              f"{len(rttm.splitlines())} RTTM lines")
+    # Inference.aggregate on soft scores: hamming window, warm-up, missing (NaN) chunks
+    r = np.random.default_rng(31)
+    for i, (C, L, K, dur, step, ham, wu, skip) in enumerate([(12, 99, 3, 2.0, 0.2, True, (0.0, 0.0), False),
+                                                               (9, 249, 2, 5.0, 1.0, False, (0.5, 0.25), False),
+                                                               (15, 99, 4, 2.0, 0.4, True, (0.2, 0.2), True)]):
+        sc = r.random((C, L, K)).astype(np.float32)
+        sc[r.random((C, 1, K)).repeat(L, 1) < 0.2] = np.nan
+        data, fr = ref_host.aggregate(sc, 0.0, dur, step, hamming=ham, warm_up=wu, skip_average=skip, missing=np.nan)
+        out[f"agg{i}_scores"], out[f"agg{i}_out"] = sc, data
+        out[f"agg{i}_args"] = np.array([dur, step, float(ham), wu[0], wu[1], float(skip)], dtype=np.float64)
+        out[f"agg{i}_frames"] = np.array(fr)
+    out["cases"] = np.array(names)
+    np.savez_compressed(GOLD / "host_ref.npz", **out)
+
+
 GENERATORS = {"seg": gen_seg, "seg_tt": gen_seg_tt, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
-              "e2e": gen_e2e}
+              "e2e": gen_e2e, "host_ref": gen_host_ref}
 
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
