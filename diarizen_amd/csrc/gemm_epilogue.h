@@ -150,20 +150,31 @@ __device__ __forceinline__ float apply_act_c(float v) {
 
 // The epilogue that runs (round 3).  r2's form (gemm_epilogue_general) cost a fixed ~400 us per launch on the M = 149 k,
 // N = 1024 contractions whatever K was — 1.2 GB of C + R moved at 3 TB/s, a third of the K = 1024 launch — because
-// every (i, j) block waited for its own loads one after the other.  Here the loads are BATCHED: the column vectors
-// (col_scale, ln_colsum, bias: one float4 per j) are fetched once, then per 16-row block all NI residual float4s are
-// in flight together, all NI stores follow, and the layer-weighted-sum read-modify-write is a second batched pass.
-// Out-of-range rows / columns load from clamped (valid) addresses and only their STORES are predicated, so there is
-// no control flow between the loads.  Needs 4-element alignment of N and every stride (else the general form).
-template <int BM, int BN, int TM, int TN, int MI, int NI>
+// every (i, j) block waited for its own loads one after the other.  Here:
+//   * the column vectors (col_scale, ln_colsum, bias) are fetched ONCE per wavefront — into registers, or, when the
+//     caller hands over a wavefront-private LDS scratch (`lds_cols`, 3 x TN floats; wide tiles), into LDS, from where
+//     the element loop reads them back as broadcast ds_read_b128s;
+//   * the tile is walked in batches of one 16-row block x JC column blocks; the residual float4s of batch b+1 are
+//     issued BEFORE batch b is computed and stored (two-deep ring), so one global round trip is exposed per wavefront,
+//     not one per block;
+//   * the layer-weighted-sum read-modify-write is a second pass with the same two-deep ring;
+//   * out-of-range rows / columns load from clamped (valid) addresses and only their STORES are predicated: no control
+//     flow between the loads; the activation is a template argument (one switch per wavefront).
+// Needs 4-element alignment of N and every stride (else the general form).
+template <int BM, int BN, int TM, int TN, int MI, int NI, bool LDSCOLS = false>
 __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
                                               int wm, int wn, int lr, int lq, int64_t cz, int64_t bz, int z0 = 0,
-                                              const float* row_inv = nullptr, const float* col_scale = nullptr) {
+                                              const float* row_inv = nullptr, const float* col_scale = nullptr,
+                                              float* lds_cols = nullptr) {
   const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0 && d.N >= 4;
   if (!vec) {
     gemm_epilogue_general<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, col_scale);
     return;
   }
+  // column blocks per batch: 4 keeps acc + two residual batches + the hoisted column-vector reads inside 256 registers
+  constexpr int JC = NI % 8 == 0 ? 8 : NI % 6 == 0 ? 6 : NI % 4 == 0 ? 4 : NI % 3 == 0 ? 3 : NI % 5 == 0 ? 5 : NI % 2 == 0 ? 2 : 1;
+  constexpr int NJC = NI / JC, NB = MI * NJC;            // batch b = (row block b / NJC, column chunk b % NJC)
+  constexpr bool REGCOLS = !LDSCOLS && NI <= 4;          // register column vectors need 12 NI registers
   const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
   const int ncol0 = tn * BN + wn * TN + lq * 4;          // column of block j: ncol0 + 16 j
   int nc[NI];                                            // ... clamped for the loads
@@ -174,89 +185,190 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     nok[j] = n0 < d.N;                                   // N % 4 == 0: a float4 is inside or outside as a whole
     nc[j] = nok[j] ? n0 : d.N - 4;
   }
-  // column vectors, one batch
-  float4 cs4[NI], lc4[NI], b4[NI];
+  int64_t crow[MI];
+  bool mok[MI];
+  int mcl[MI];
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    cs4[j] = make_float4(1.f, 1.f, 1.f, 1.f);
-    lc4[j] = b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < MI; ++i) {
+    const int m = tm * BM + wm * TM + i * 16 + lr;
+    mok[i] = m < d.M;
+    mcl[i] = mok[i] ? m : d.M - 1;
+    crow[i] = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[mcl[i]] : (int64_t)mcl[i] * d.ldc);
   }
-  if (col_scale) {
+  // ---- residual ring: batch 0 goes out first, the column vectors and row statistics travel beside it ----
+  float4 r4[2][JC];
+  auto issue_r = [&](const int b, const int slot) {
+    const int i = b / NJC, jc = b % NJC;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) cs4[j] = *reinterpret_cast<const float4*>(col_scale + nc[j]);
+    for (int jj = 0; jj < JC; ++jj) r4[slot][jj] = *reinterpret_cast<const float4*>(d.R + crow[i] + nc[jc * JC + jj]);
+  };
+  if (d.R) issue_r(0, 0);
+  float ln_mu[MI], ln_rs[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    ln_mu[i] = 0.f;
+    ln_rs[i] = 1.f;
   }
   if (d.ln_stats) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) lc4[j] = *reinterpret_cast<const float4*>(d.ln_colsum + nc[j]);
+    for (int i = 0; i < MI; ++i) {
+      const float2 st = *reinterpret_cast<const float2*>(d.ln_stats + 2 * (int64_t)mcl[i]);
+      ln_mu[i] = st.x;
+      ln_rs[i] = st.y;
+    }
   }
-  if (bias) {
+  float4 cs4[REGCOLS ? NI : 1], lc4[REGCOLS ? NI : 1], b4[REGCOLS ? NI : 1];
+  if constexpr (REGCOLS) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) b4[j] = *reinterpret_cast<const float4*>(bias + nc[j]);
+    for (int j = 0; j < NI; ++j) {
+      cs4[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+      lc4[j] = b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (col_scale) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) cs4[j] = *reinterpret_cast<const float4*>(col_scale + nc[j]);
+    }
+    if (d.ln_stats) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) lc4[j] = *reinterpret_cast<const float4*>(d.ln_colsum + nc[j]);
+    }
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b4[j] = *reinterpret_cast<const float4*>(bias + nc[j]);
+    }
+  } else if constexpr (LDSCOLS) {
+    // lane l < TN / 4 owns columns 4 l .. 4 l + 3 of the wavefront tile
+    const int lane = lq * 16 + lr;
+    if (lane < TN / 4) {
+      int n = tn * BN + wn * TN + 4 * lane;
+      n = n < d.N ? n : d.N - 4;
+      float4 c = make_float4(1.f, 1.f, 1.f, 1.f), l = make_float4(0.f, 0.f, 0.f, 0.f), bb = l;
+      if (col_scale) c = *reinterpret_cast<const float4*>(col_scale + n);
+      if (d.ln_stats) l = *reinterpret_cast<const float4*>(d.ln_colsum + n);
+      if (bias) bb = *reinterpret_cast<const float4*>(bias + n);
+      *reinterpret_cast<float4*>(lds_cols + 4 * lane) = c;
+      *reinterpret_cast<float4*>(lds_cols + TN + 4 * lane) = l;
+      *reinterpret_cast<float4*>(lds_cols + 2 * TN + 4 * lane) = bb;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private: order the ds_writes before the ds_reads
   }
+  auto cols = [&](const int j, float4& c, float4& l, float4& bb) {
+    if constexpr (REGCOLS) {
+      c = cs4[j]; l = lc4[j]; bb = b4[j];
+    } else if constexpr (LDSCOLS) {
+      const float* p = lds_cols + j * 16 + lq * 4;
+      c = *reinterpret_cast<const float4*>(p);
+      l = *reinterpret_cast<const float4*>(p + TN);
+      bb = *reinterpret_cast<const float4*>(p + 2 * TN);
+    } else {    // wide tile without scratch: straight from global (L2 hits), still no control flow
+      c = col_scale ? *reinterpret_cast<const float4*>(col_scale + nc[j]) : make_float4(1.f, 1.f, 1.f, 1.f);
+      l = d.ln_stats ? *reinterpret_cast<const float4*>(d.ln_colsum + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bb = bias ? *reinterpret_cast<const float4*>(bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  float amax_row[MI], st_s[MI], st_q[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) amax_row[i] = st_s[i] = st_q[i] = 0.f;
+
+  auto run = [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int i = b / NJC, jc = b % NJC;
+      if (d.R && b + 1 < NB) issue_r(b + 1, (b + 1) & 1);
+      const float acc_scale = (col_scale && row_inv) ? row_inv[i] : 1.f;
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj) {
+        const int j = jc * JC + jj;
+        float4 c4, l4, bb4;
+        cols(j, c4, l4, bb4);
+        f32x4 v = acc[i][j];
+        if (col_scale) {   // fp16 two-term operands were scaled by exact powers of two: undo (exact)
+          v[0] *= acc_scale * c4.x; v[1] *= acc_scale * c4.y; v[2] *= acc_scale * c4.z; v[3] *= acc_scale * c4.w;
+        }
+        if (d.ln_stats) {
+          v[0] = ln_rs[i] * (v[0] - ln_mu[i] * l4.x); v[1] = ln_rs[i] * (v[1] - ln_mu[i] * l4.y);
+          v[2] = ln_rs[i] * (v[2] - ln_mu[i] * l4.z); v[3] = ln_rs[i] * (v[3] - ln_mu[i] * l4.w);
+        }
+        if (bias) { v[0] += bb4.x; v[1] += bb4.y; v[2] += bb4.z; v[3] += bb4.w; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act_c<ACT>(v[e]) * d.alpha;
+        if (d.R) {
+          const float4 r = r4[b & 1][jj];
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        }
+        if (d.post_relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        acc[i][j] = v;
+        if (nok[j]) {      // statistics / |max| over the columns that exist
+          amax_row[i] = fmaxf(fmaxf(amax_row[i], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          st_s[i] += (v[0] + v[1]) + (v[2] + v[3]);
+          st_q[i] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], st_q[i]))));
+        }
+        // keep the ALU work of one column block together (memory instructions may still move across): interleaving the
+        // erf chains of 16 elements costs ~100 live registers and spills
+        __builtin_amdgcn_sched_barrier(0x00E0 | 0x0200);
+      }
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj) {
+        const int j = jc * JC + jj;
+        if (mok[i] && nok[j])
+          *reinterpret_cast<float4*>(d.C + crow[i] + nc[j]) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+  };
+  switch (d.act) {
+    case DZN_ACT_GELU: run(std::integral_constant<int, DZN_ACT_GELU>{}); break;
+    case DZN_ACT_SWISH: run(std::integral_constant<int, DZN_ACT_SWISH>{}); break;
+    case DZN_ACT_RELU: run(std::integral_constant<int, DZN_ACT_RELU>{}); break;
+    default: run(std::integral_constant<int, DZN_ACT_NONE>{}); break;
+  }
+  // ---- layer-weighted sum: WS (+)= ws_w * v, second pass, same two-deep ring ----
+  if (d.WS) {
+    float4 w4[2][JC];
+    auto issue_w = [&](const int b, const int slot) {
+      const int i = b / NJC, jc = b % NJC;
+      const float* wrow = d.WS + (int64_t)mcl[i] * d.ldws;
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj) w4[slot][jj] = *reinterpret_cast<const float4*>(wrow + nc[jc * JC + jj]);
+    };
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj) w4[s][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!d.ws_init) issue_w(0, 0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int i = b / NJC, jc = b % NJC;
+      if (!d.ws_init && b + 1 < NB) issue_w(b + 1, (b + 1) & 1);
+      float* wrow = d.WS + (int64_t)mcl[i] * d.ldws;
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj) {
+        const int j = jc * JC + jj;
+        const float4 w = w4[b & 1][jj];
+        if (mok[i] && nok[j])
+          *reinterpret_cast<float4*>(wrow + nc[j]) =
+              make_float4(w.x + d.ws_w * acc[i][j][0], w.y + d.ws_w * acc[i][j][1], w.z + d.ws_w * acc[i][j][2],
+                          w.w + d.ws_w * acc[i][j][3]);
+      }
+    }
+  }
+  // ---- row statistics for a following folded LayerNorm, |max| trackers ----
   float amax = 0.f, amax_hi = 0.f;
   const int wrow0 = tm * BM + wm * TM;
   const bool two_unit = d.c_amax && d.amax_unit >= TM;
   const int unit0 = two_unit ? (wrow0 < d.M ? wrow0 : d.M - 1) / d.amax_unit : 0;
   const int boundary = two_unit ? (unit0 + 1) * d.amax_unit : 0;
-  int64_t crow[MI];
-  bool mok[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = tm * BM + wm * TM + i * 16 + lr;
-    mok[i] = m < d.M;
-    const int mc = mok[i] ? m : d.M - 1;
-    crow[i] = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[mc] : (int64_t)mc * d.ldc);
-  }
-  // one 16-row block; the activation is a template argument so that the element loop has no control flow
-  auto row_block = [&](auto actc, const int i) {
-    constexpr int ACT = decltype(actc)::value;
-    const int m = tm * BM + wm * TM + i * 16 + lr;
-    const int mc = mok[i] ? m : d.M - 1;
-    const float acc_scale = (col_scale && row_inv) ? row_inv[i] : 1.f;
-    float ln_mu = 0.f, ln_rs = 1.f;
-    if (d.ln_stats) {
-      const float2 st = *reinterpret_cast<const float2*>(d.ln_stats + 2 * (int64_t)mc);
-      ln_mu = st.x;
-      ln_rs = st.y;
-    }
-    float4 r4[NI];
-    if (d.R) {
-#pragma unroll
-      for (int j = 0; j < NI; ++j) r4[j] = *reinterpret_cast<const float4*>(d.R + crow[i] + nc[j]);
-    }
-    float amax_row = 0.f, st_s = 0.f, st_q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      f32x4 v = acc[i][j];
-      if (col_scale) {   // fp16 two-term operands were scaled by exact powers of two: undo (exact)
-        v[0] *= acc_scale * cs4[j].x; v[1] *= acc_scale * cs4[j].y; v[2] *= acc_scale * cs4[j].z; v[3] *= acc_scale * cs4[j].w;
-      }
-      if (d.ln_stats) {
-        v[0] = ln_rs * (v[0] - ln_mu * lc4[j].x); v[1] = ln_rs * (v[1] - ln_mu * lc4[j].y);
-        v[2] = ln_rs * (v[2] - ln_mu * lc4[j].z); v[3] = ln_rs * (v[3] - ln_mu * lc4[j].w);
-      }
-      if (bias) { v[0] += b4[j].x; v[1] += b4[j].y; v[2] += b4[j].z; v[3] += b4[j].w; }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act_c<ACT>(v[e]) * d.alpha;
-      if (d.R) { v[0] += r4[j].x; v[1] += r4[j].y; v[2] += r4[j].z; v[3] += r4[j].w; }
-      if (d.post_relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      acc[i][j] = v;
-      if (nok[j]) {      // statistics / |max| over the columns that exist
-        amax_row = fmaxf(fmaxf(amax_row, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        st_s += (v[0] + v[1]) + (v[2] + v[3]);
-        st_q = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], st_q))));
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-      if (mok[i] && nok[j])
-        *reinterpret_cast<float4*>(d.C + crow[i] + nc[j]) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    if (!mok[i]) return;
+    if (!mok[i]) continue;
     if (d.stat_partial) {
-      float s1 = st_s + __shfl_xor(st_s, 16, 64), q1 = st_q + __shfl_xor(st_q, 16, 64);
+      // every wavefront leaves (sum, sum of squares) of its TN columns; stats_finalize_kernel adds the tilesN * (BN / TN)
+      // partials of a row in a fixed order (deterministic).  The row lives in lanes lr, lr + 16, lr + 32, lr + 48.
+      float s1 = st_s[i] + __shfl_xor(st_s[i], 16, 64), q1 = st_q[i] + __shfl_xor(st_q[i], 16, 64);
       s1 += __shfl_xor(s1, 32, 64);
       q1 += __shfl_xor(q1, 32, 64);
       if (lq == 0) {
@@ -266,46 +378,15 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     }
     if (d.c_amax) {
       if (two_unit) {
-        if (m < boundary) amax = fmaxf(amax, amax_row);
-        else amax_hi = fmaxf(amax_hi, amax_row);
+        if (m < boundary) amax = fmaxf(amax, amax_row[i]);
+        else amax_hi = fmaxf(amax_hi, amax_row[i]);
       } else if (d.amax_unit > 0) {
-        float r = fmaxf(amax_row, __shfl_xor(amax_row, 16, 64));
+        float r = fmaxf(amax_row[i], __shfl_xor(amax_row[i], 16, 64));
         r = fmaxf(r, __shfl_xor(r, 32, 64));
         if (lq == 0) track_amax_lane(d.c_amax + m / d.amax_unit, r);
       } else {
-        amax = fmaxf(amax, amax_row);
+        amax = fmaxf(amax, amax_row[i]);
       }
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    switch (d.act) {
-      case DZN_ACT_GELU: row_block(std::integral_constant<int, DZN_ACT_GELU>{}, i); break;
-      case DZN_ACT_SWISH: row_block(std::integral_constant<int, DZN_ACT_SWISH>{}, i); break;
-      case DZN_ACT_RELU: row_block(std::integral_constant<int, DZN_ACT_RELU>{}, i); break;
-      default: row_block(std::integral_constant<int, DZN_ACT_NONE>{}, i); break;
-    }
-  }
-  // layer-weighted sum: WS (+)= ws_w * v, a second batched read-modify-write pass over the finished values
-  if (d.WS) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = tm * BM + wm * TM + i * 16 + lr;
-      const int mc = mok[i] ? m : d.M - 1;
-      float* wrow = d.WS + (int64_t)mc * d.ldws;
-      float4 w4[NI];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) w4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!d.ws_init) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) w4[j] = *reinterpret_cast<const float4*>(wrow + nc[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        if (mok[i] && nok[j])
-          *reinterpret_cast<float4*>(wrow + nc[j]) =
-              make_float4(w4[j].x + d.ws_w * acc[i][j][0], w4[j].y + d.ws_w * acc[i][j][1], w4[j].z + d.ws_w * acc[i][j][2],
-                          w4[j].w + d.ws_w * acc[i][j][3]);
     }
   }
   if (two_unit) {

@@ -288,14 +288,255 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const dzn_gemm_desc d) {
       if (t < nk) segment(rc, std::false_type{}, t);
     });
 
-  gemm_epilogue<BM, BN, TM, BN, MI, NI>(d, acc, tm, tn, wave, 0, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr);
+  // column vectors of the epilogue: a wavefront-private scratch BEHIND the W stages (group 1 may still be multiplying)
+  float* lds_cols = reinterpret_cast<float*>(smem + S * STAGE) + wave * 3 * BN;
+  gemm_epilogue<BM, BN, TM, BN, MI, NI, true>(d, acc, tm, tn, wave, 0, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr,
+                                        lds_cols);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form ("pq"): the W fragments are STREAMED through a small register ring inside the compute segment instead of
+// being read wholesale in the load segment.  Measured on the first form (profiles/r3_gemm_pp_probe.txt): time per launch
+// = 300 us + 0.70 us x K at M = 149 k, N = 1024, i.e. the loop ran at ~52 % of the matrix pipe — its load segment
+// (16 fragment reads + DMA + A loads + wait + 50 VALU of split) was LONGER than the 768-cycle compute segment of its
+// partner.  Here the load segment keeps only the VMEM issue, the wait and the split; the compute segment multiplies
+// column-block pairs while the ds_reads of the next pair are in flight (ring of RD pairs, first RD-1 pairs read at the
+// end of the load segment).  64 registers of fragments become 16 x RD, which is what lets the tile grow to 256 x 192 /
+// 256 x 256 (128 accumulator registers): per K tile 96 MFMAs per wavefront against the same A traffic and split work.
+// Stage t % S is now read during the compute segments of tile t (I(2t+1), I(2t+2)), so it is refilled with tile t+S by
+// the load segments of tile t+2 (W runs S-2 tiles ahead) and S >= 4.
+template <int BN, int NP, int S, int AD, int RD>
+__global__ __launch_bounds__(512) void gemm_pq_kernel(const dzn_gemm_desc d) {
+  constexpr int BM = 256, TM = 32, MI = 2, NI = BN / 16, BK = 32, NPAIR = NI / 2;
+  constexpr int SP = NP == 3 ? 3 : 2;
+  constexpr int WPLANE = BN * 64, STAGE = NP * WPLANE;
+  constexpr int NPIECE = STAGE / 1024;
+  static_assert(NPIECE % 8 == 0 && NI % 2 == 0, "tile shape");
+  constexpr int PPW = NPIECE / 8;
+  constexpr int OPS = PPW + 2 * MI;
+  constexpr int INFL = (AD < S - 3 ? AD : S - 3) * OPS;
+  constexpr int AHEAD = (S - 2 > AD ? S - 2 : AD);
+  constexpr int NR = AD + 1;
+  static_assert(S >= 4 && AD >= 1 && AD <= S - 2 && INFL < 64 && RD >= 2 && RD <= NPAIR, "pipeline depths");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int tilesN = (d.N + BN - 1) / BN;
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = tile / tilesN, tn = tile % tilesN;
+  const int z = blockIdx.y;
+  const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
+  const float* __restrict__ A = d.A + z0 * d.a_z0 + z1 * d.a_z1;
+  const u16* __restrict__ W3 =
+      reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + SP * (z0 * d.w_z0 + z1 * d.w_z1);
+  const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
+  const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
+
+  float a_scale[MI], row_inv[MI], a_max[MI];
+  const float* aptr[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    int m = tm * BM + wave * TM + i * 16 + lr;
+    m = m < d.M ? m : d.M - 1;
+    a_scale[i] = row_inv[i] = 1.f;
+    a_max[i] = 0.f;
+    aptr[i] = A + (d.a_rowoff ? (int64_t)d.a_rowoff[m] : (int64_t)m * d.lda) + lq * 4;
+    asm volatile("" : "+v"(aptr[i]));
+    if constexpr (NP <= 2) {
+      const float* tp = d.a_amax + (d.amax_unit > 0 ? m / d.amax_unit : z0);
+      asm volatile("global_load_dword %0, %1, off" : "=v"(a_max[i]) : "v"(tp) : "memory");
+    }
+  }
+  const u16* wptr[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int c = wave + 8 * i, p = c / (BN / 16), g = c % (BN / 16);
+    const int row = g * 16 + (lane >> 2);
+    int n = tn * BN + row;
+    n = n < d.N ? n : d.N - 1;
+    wptr[i] = W3 + (int64_t)n * SP * d.ldw + p * 32 + (((lane & 3) ^ wswz_pp(row)) << 3);
+  }
+  const int woff0 = lr * 64 + ((lq ^ wswz_pp(lr)) << 4);
+
+  const int nk = d.K / BK;
+  int wk = 0, wst = 0;
+  int64_t a_koff = 0;
+  int a_rem = 0;
+  f32x4 araw[NR][MI][2];
+  u32x4 af[MI][NP];
+  u32x4 ring[RD][2][NP];                     // W fragments of RD column-block pairs
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto issue_w = [&]() {
+    unsigned char* dst = smem + wst * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wptr[i] + SP * wk),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, 0, 0);
+    wk += BK;
+    wst = wst + 1 == S ? 0 : wst + 1;
+  };
+  auto issue_a = [&](auto rc) {
+    constexpr int R = decltype(rc)::value;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      asm_load16<0>(araw[R][i][0], aptr[i] + a_koff);
+      asm_load16<64>(araw[R][i][1], aptr[i] + a_koff);
+    }
+    a_koff += BK;
+    a_rem += BK;
+    if (a_rem == d.kc) { a_rem = 0; a_koff += d.ldk - d.kc; }
+  };
+
+  const bool deep = nk > AHEAD;
+  if (deep) {
+#pragma unroll
+    for (int s = 0; s < S - 2; ++s) issue_w();
+    static_for<AD>([&](auto ac) { issue_a(ac); });
+    wait_vm_only<(AD - 1) * 2 * MI>();
+  } else {
+#pragma unroll
+    for (int s = 0; s < S - 2; ++s)
+      if (s < nk) issue_w();
+    static_for<AD>([&](auto ac) {
+      if (decltype(ac)::value < nk) issue_a(ac);
+    });
+    wait_vm_only<0>();
+  }
+  if constexpr (NP <= 2) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      asm volatile("" : "+v"(a_max[i]));
+      h2_scale(a_max[i], a_scale[i], row_inv[i]);
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp) __builtin_amdgcn_s_barrier();
+
+  int rst = 0;
+  auto read_pair = [&](const unsigned char* base, auto slotc, const int pr) {
+    constexpr int SL = decltype(slotc)::value;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        ring[SL][jj][p] = *reinterpret_cast<const u32x4*>(base + p * WPLANE + (2 * pr + jj) * 1024);
+  };
+  auto segment = [&](auto rc, auto fullc, int t) {
+    constexpr int R = decltype(rc)::value;
+    constexpr bool FULL = decltype(fullc)::value;
+    const unsigned char* base = smem + rst * STAGE + woff0;
+    rst = rst + 1 == S ? 0 : rst + 1;
+    // -------- load segment of tile t --------
+    if constexpr (FULL) {
+      issue_w();
+      issue_a(std::integral_constant<int, (R + AD) % NR>{});
+    } else {
+      if (t + S - 2 < nk) issue_w();
+      if (t + AD < nk) issue_a(std::integral_constant<int, (R + AD) % NR>{});
+    }
+    static_for<RD - 1>([&](auto pc) { read_pair(base, pc, decltype(pc)::value); });
+    if constexpr (FULL) wait_vm_tied<INFL>(araw[R]);
+    else wait_vm_tied<0>(araw[R]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if constexpr (NP == 3) {
+        bf16x8 h_, m_, l_;
+        split8(araw[R][i][0], araw[R][i][1], h_, m_, l_);
+        af[i][0] = __builtin_bit_cast(u32x4, h_);
+        af[i][1] = __builtin_bit_cast(u32x4, m_);
+        af[i][2] = __builtin_bit_cast(u32x4, l_);
+      } else if constexpr (NP == 2) {
+        split8_h2(araw[R][i][0], araw[R][i][1], a_scale[i], af[i][0], af[i][1]);
+      } else {
+        cvt8_h1(araw[R][i][0], araw[R][i][1], a_scale[i], af[i][0]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // -------- compute segment of tile t: MFMAs + the fragment reads of the pairs ahead --------
+    static_for<NPAIR>([&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      if constexpr (P + RD - 1 < NPAIR) read_pair(base, std::integral_constant<int, (P + RD - 1) % RD>{}, P + RD - 1);
+      constexpr int SL = P % RD;
+      constexpr int NQ = NP == 3 ? 6 : NP == 2 ? 3 : 1;
+      constexpr int PW6[6] = {2, 0, 1, 1, 0, 0}, PA6[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int PW3[3] = {1, 0, 0}, PA3[3] = {0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int pw = NP == 3 ? PW6[q] : NP == 2 ? PW3[q] : 0, pa = NP == 3 ? PA6[q] : NP == 2 ? PA3[q] : 0;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc[i][2 * P + jj] = mfma_np<NP>(ring[SL][jj][pw], af[i][pa], acc[i][2 * P + jj]);
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    if (FULL || !(grp && t + 1 == nk)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int t0 = 0;
+  if (deep)
+    for (; t0 + NR - 1 + AHEAD < nk; t0 += NR)
+      static_for<NR>([&](auto rc) { segment(rc, std::true_type{}, t0 + decltype(rc)::value); });
+  for (; t0 < nk; t0 += NR)
+    static_for<NR>([&](auto rc) {
+      const int t = t0 + decltype(rc)::value;
+      if (t < nk) segment(rc, std::false_type{}, t);
+    });
+
+  float* lds_cols = reinterpret_cast<float*>(smem + S * STAGE) + wave * 3 * BN;
+  gemm_epilogue<BM, BN, TM, BN, MI, NI, true>(d, acc, tm, tn, wave, 0, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr,
+                                              lds_cols);
+}
+
+template <int BN, int NP, int S, int AD, int RD>
+int launch_pq_cfg(const dzn_gemm_desc& d, hipStream_t s) {
+  constexpr int BM = 256;
+  const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+  const size_t lds = (size_t)S * NP * BN * 64 + 8 * 3 * BN * sizeof(float);
+  static_assert((size_t)S * NP * BN * 64 + 8 * 3 * BN * sizeof(float) <= 160 * 1024, "LDS");
+  auto kern = gemm_pq_kernel<BN, NP, S, AD, RD>;
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(attr_mask))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  dim3 grid(tilesM * tilesN, d.nz > 0 ? d.nz : 1, 1);
+  int pid = -1;
+  if (prof_enabled()) {
+    char cls[64];
+    static const bool by_shape = getenv("DZN_PROFILE_SHAPES") != nullptr;
+    const char* pn = NP == 3 ? "f32s" : NP == 2 ? "f32h" : "f16";
+    if (by_shape) snprintf(cls, sizeof(cls), "gemm_%s_pq256x%d M%d N%d K%d z%d", pn, BN, d.M, d.N, d.K, d.nz);
+    else snprintf(cls, sizeof(cls), "gemm_%s_pq256x%d", pn, BN);
+    const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
+    pid = prof_begin(s, cls, fl, gemm_alg_bytes(d, NP * 2));
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, d);
+  prof_end(pid, s);
+  if (hipGetLastError() != hipSuccess) return DZN_E_HIP;
+  if (d.stat_partial && d.stat_final)
+    return launch_stats_finalize(d.stat_partial, d.M, tilesN, d.stat_C, d.stat_eps, d.stat_final, s);
+  return DZN_OK;
 }
 
 template <int BN, int NP, int S, int AD>
 int launch_pp_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   constexpr int BM = 256;
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-  const size_t lds = (size_t)S * NP * BN * 64;
+  const size_t lds = (size_t)S * NP * BN * 64 + 8 * 3 * BN * sizeof(float);   // W stages + epilogue column scratch
   auto kern = gemm_pp_kernel<BN, NP, S, AD>;
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask))
@@ -321,17 +562,30 @@ int launch_pp_cfg(const dzn_gemm_desc& d, hipStream_t s) {
 
 }  // namespace
 
-// cfg: "pp128" / "pp64" (+ "s4" for 4 stages, "a2" for A two tiles ahead), e.g. "pp128s4a2"
+// cfg: first form "pp128" / "pp64" (+ "s4" for 4 stages, "a2" for A two tiles ahead), e.g. "pp128s4a2";
+//      streamed form "pq128" / "pq192" / "pq256" (+ "r3": ring of 3 pairs, "a2": A two tiles ahead with 5 stages)
 int launch_gemm_pp(const dzn_gemm_desc& d, hipStream_t s, int np, const char* cfg) {
+  if (cfg && !strncmp(cfg, "pq", 2)) {
+    const bool r3 = strstr(cfg, "r3"), a2 = strstr(cfg, "a2");
+    const int bn = atoi(cfg + 2);
+    if (np == 2) {
+      if (bn == 128) return a2 ? launch_pq_cfg<128, 2, 5, 2, 2>(d, s) : r3 ? launch_pq_cfg<128, 2, 4, 1, 3>(d, s) : launch_pq_cfg<128, 2, 4, 1, 2>(d, s);
+      if (bn == 192) return r3 ? launch_pq_cfg<192, 2, 4, 1, 3>(d, s) : launch_pq_cfg<192, 2, 4, 1, 2>(d, s);
+      if (bn == 256) return r3 ? launch_pq_cfg<256, 2, 4, 1, 3>(d, s) : launch_pq_cfg<256, 2, 4, 1, 2>(d, s);
+    }
+    if (np == 1 && bn == 256) return launch_pq_cfg<256, 1, 4, 1, 2>(d, s);
+    if (np == 1 && bn == 128) return launch_pq_cfg<128, 1, 4, 1, 2>(d, s);
+    if (np == 3 && bn == 128) return launch_pq_cfg<128, 3, 4, 1, 2>(d, s);
+    return DZN_E_INVALID;
+  }
   const bool n64 = cfg && !strncmp(cfg, "pp64", 4);
   const bool s4 = cfg && strstr(cfg, "s4"), a2 = cfg && strstr(cfg, "a2");
   if (np == 2) {
     if (n64) return s4 ? launch_pp_cfg<64, 2, 4, 2>(d, s) : launch_pp_cfg<64, 2, 3, 1>(d, s);
     if (s4 && a2) return launch_pp_cfg<128, 2, 4, 2>(d, s);
-    if (s4) return launch_pp_cfg<128, 2, 4, 1>(d, s);
     return launch_pp_cfg<128, 2, 3, 1>(d, s);
   }
-  if (np == 1 && !n64) return s4 ? launch_pp_cfg<128, 1, 4, 2>(d, s) : launch_pp_cfg<128, 1, 3, 1>(d, s);
+  if (np == 1 && !n64) return launch_pp_cfg<128, 1, 3, 1>(d, s);
   if (np == 3 && !n64) return launch_pp_cfg<128, 3, 3, 1>(d, s);
   return DZN_E_INVALID;
 }

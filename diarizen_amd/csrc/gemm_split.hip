@@ -299,7 +299,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
     step(kt, wfa, wfb);
     if (kt + 1 < nk) step(kt + 1, wfb, wfa);
   }
-  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr);
+  if constexpr (true) {
+    // the epilogue's column vectors live in LDS (48 registers less than holding them): the stages are dead once every
+    // wavefront left the loop
+    __syncthreads();
+    gemm_epilogue<BM, BN, TM, TN, MI, NI, true>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr,
+                                                reinterpret_cast<float*>(smem) + wave * 3 * TN);
+  } else {
+    gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr);
+  }
 }
 
 template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0>
@@ -373,11 +381,11 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   if (force) {
     if (!strncmp(force, "pp", 2)) return launch_gemm_pp(d, s, NP, force);   // gemm_pp.hip: 8-wavefront ping-pong tiles
     // production tiles by name
-    if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
-    if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2, NP>(d, s);
+    if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2, NP, NP <= 2 ? 3 : 2>(d, s);
+    if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2, NP, 2>(d, s);
     if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
     if constexpr (NP == 3) {
-      if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
+      if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2, NP, 2>(d, s);
     } else {
       if (!strcmp(force, "128x128w4")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);
     }
@@ -405,22 +413,25 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     }
 #endif
   }
+  // launch bounds pin the occupancy the tile was tuned at (r3: the pipelined epilogue gives the register allocator
+  // room to trade occupancy for more loads in flight; 128x64 tiles want 3 workgroups per CU, 128x128 two)
+  constexpr int OCC64 = NP <= 2 ? 3 : 2;
   if (d.N <= 32) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
   // 128x64 tiles run 4 wavefronts as 4x1 (32 rows x 64 columns each): the in-register operand
   // split is per A row, so wide-and-short wavefront tiles halve the VALU work per MFMA
-  if (d.N <= 64 || d.K <= 512) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
+  if (d.N <= 64 || d.K <= 512) return launch_split_cfg<128, 64, 4, 1, 2, NP, OCC64>(d, s);
   // 128-wide column tiles unless 64-wide ones save more than ~1/8 of the (padded) columns; widths that
   // are multiples of 80 but not of 64 (conv1 of the extractor: 153 -> 160) get exact 80-wide tiles
   const int cols128 = (d.N + 127) / 128 * 128, cols64 = (d.N + 63) / 64 * 64;
-  if (d.N % 80 == 0 && d.N < cols64 && d.N * 9 < cols128 * 8) return launch_split_cfg<128, 80, 4, 1, 2, NP>(d, s);
-  if (cols64 * 9 < cols128 * 8) return launch_split_cfg<128, 64, 4, 1, 2, NP>(d, s);
+  if (d.N % 80 == 0 && d.N < cols64 && d.N * 9 < cols128 * 8) return launch_split_cfg<128, 80, 4, 1, 2, NP, 2>(d, s);
+  if (cols64 * 9 < cols128 * 8) return launch_split_cfg<128, 64, 4, 1, 2, NP, OCC64>(d, s);
   // NP = 2: 4 x 1 wavefronts (32 x 128 each): every A row is split by ONE wavefront instead of two; measured +3 %
   // over 2 x 2 on the pipeline's K = 1024 shapes (scripts/bench_gemm_h2.py).  NP = 3 keeps 2 x 2 (register budget).
   // NP = 1 (DZN_PREC_F16) is bound by the global -> LDS fill, not by MFMA / VALU (ablation: profiles/r2_gemm_ablation.txt):
   // 256 x 128 tiles halve the W bytes per flop and a third stage keeps two K tiles in flight: +7..13 % (r2_gemm_cfg_probe.txt)
   if constexpr (NP == 1) return launch_split_cfg<256, 128, 8, 1, 3, NP, 2>(d, s);
   if constexpr (NP == 2) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);   // held to 2 wavefronts per SIMD
-  return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
+  return launch_split_cfg<128, 128, 2, 2, 2, NP, 2>(d, s);
 }
 
 // W [rows][K] fp32 -> W2h [rows][K/32][2][32] fp16 (k permuted as above) of w * 2^e_row, e_row chosen so that

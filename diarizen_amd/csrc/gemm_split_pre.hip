@@ -210,8 +210,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
     step(kt, wfa, wfb);
     if (kt + 1 < nk) step(kt + 1, wfb, wfa);
   }
-  gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv,
-                                        NP <= 2 ? d.col_scale + z0 * d.b_z0 + z1 * d.b_z1 : nullptr);
+  if constexpr (true) {
+    // column vectors of the epilogue in LDS (48 registers less than holding them; the stages are dead by now)
+    __syncthreads();
+    gemm_epilogue<BM, BN, TM, TN, MI, NI, true>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv,
+                                                NP <= 2 ? d.col_scale + z0 * d.b_z0 + z1 * d.b_z1 : nullptr,
+                                                reinterpret_cast<float*>(smem) + (wm * WGN + wn) * 3 * TN);
+  } else {
+    gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv,
+                                          NP <= 2 ? d.col_scale + z0 * d.b_z0 + z1 * d.b_z1 : nullptr);
+  }
 }
 
 template <int BM, int BN, int WGM, int WGN, int S, int NP>

@@ -542,8 +542,46 @@ def gen_host_ref():
     np.savez_compressed(GOLD / "host_ref.npz", **out)
 
 
+
+# ------------------------------------------------------------------ clustering: the branches host_clustering.npz does not reach
+FORCED_CASES = [
+    # name, seed, C, n_spk, threshold, min_cluster_size, call kwargs, max_num_embeddings, random.seed, constrained
+    ("min_walk", 41, 90, 3, 0.6, 5, dict(min_clusters=5, max_clusters=20), np.inf, None, True),      # n_large < min_clusters
+    ("min_walk_found", 50, 120, 6, 1.3, 5, dict(min_clusters=6, max_clusters=20), np.inf, None, True),  # walk finds an exact fit
+    ("max_walk", 42, 120, 5, 0.5, 5, dict(min_clusters=1, max_clusters=2), np.inf, None, True),      # n_large > max_clusters
+    ("num_exact", 43, 100, 4, 0.6, 4, dict(num_clusters=6), np.inf, None, True),                     # num_clusters given
+    ("num_fewer", 44, 100, 4, 0.6, 4, dict(num_clusters=2), np.inf, None, True),
+    ("num_unreachable", 45, 40, 3, 0.6, 13, dict(num_clusters=9), np.inf, None, True),               # best-candidate re-apply
+    ("subsample", 46, 150, 4, 0.6, 6, dict(min_clusters=1, max_clusters=20), 120, 1234, True),       # max_num_embeddings
+    ("subsample_forced", 47, 150, 4, 0.6, 6, dict(num_clusters=3), 90, 99, True),
+    ("argmax_assign", 48, 80, 3, 0.6, 5, dict(min_clusters=1, max_clusters=20), np.inf, None, False),  # unconstrained
+    ("one_cluster", 49, 30, 2, 0.6, 5, dict(num_clusters=1), np.inf, None, True),                    # max_clusters < 2
+]
+
+
+def gen_host_forced():
+    """tests/golden/host_clustering_forced.npz: the reference's AgglomerativeClustering (PA/pipelines/clustering.py) on
+    the branches the plain fixtures never take: the min / max / num_clusters dendrogram walk (:429-481), its
+    best-candidate re-application, `max_num_embeddings` sub-sampling (:160-166, seeded `random`), unconstrained argmax
+    assignment and the single-cluster shortcut (:296-302).  (`num_large_clusters == 0`, :483-485, cannot be reached:
+    min_clusters >= 1 always starts the walk, whose last merge holds every embedding.)"""
+    import random
+    cl = load_reference_clustering()
+    out = {"cases": np.array([c[0] for c in FORCED_CASES])}
+    for name, seed, C, nspk, thr, mcs, kw, mne, rseed, constrained in FORCED_CASES:
+        seg, emb = synth_host_case(seed, C=C, n_spk=nspk)
+        ahc = cl.AgglomerativeClustering(metric="cosine", max_num_embeddings=mne, constrained_assignment=constrained)
+        ahc.method, ahc.threshold, ahc.min_cluster_size = "centroid", thr, mcs
+        if rseed is not None:
+            random.seed(rseed)
+        hard, soft, cent = ahc(embeddings=emb.copy(), segmentations=types.SimpleNamespace(data=seg), **kw)
+        out[f"{name}_hard"], out[f"{name}_centroids"] = hard, cent
+        print(f"host_forced {name}: clusters {int(hard.max()) + 1}, centroids {cent.shape}")
+    np.savez_compressed(GOLD / "host_clustering_forced.npz", **out)
+
+
 GENERATORS = {"seg": gen_seg, "seg_tt": gen_seg_tt, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
-              "e2e": gen_e2e, "host_ref": gen_host_ref}
+              "e2e": gen_e2e, "host_ref": gen_host_ref, "host_forced": gen_host_forced}
 
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)

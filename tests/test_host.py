@@ -698,3 +698,28 @@ def test_wav_loader_24bit_extensible_float64(tmp_path):
     assert np.array_equal(load_wav(str(p))[0], y)
     with pytest.raises(ValueError):
         load_wav(riff(struct.pack("<HHIIHH", 2, 1, 8000, 8000, 1, 4), b"\x00" * 16))   # ADPCM: refused loudly
+
+
+# ---------------------------------------------------------------- clustering branches the plain fixtures do not reach
+_FORCED = np.load(os.path.join(GOLD, "host_clustering_forced.npz"))
+
+
+@pytest.mark.parametrize("name", [str(c) for c in _FORCED["cases"]])
+def test_ahc_forced_branches_equal_reference(name):
+    """min / max / num_clusters dendrogram walk (PA/pipelines/clustering.py:429-481) incl. its best-candidate
+    re-application, `max_num_embeddings` sub-sampling with the seeded `random` module (:160-166), unconstrained argmax
+    assignment, the single-cluster shortcut (:296-302): goldens made by the reference's own AgglomerativeClustering
+    (oracle/gen_golden.py host_forced)."""
+    import random
+    from diarizen_amd.clustering import AgglomerativeClustering
+    from oracle.gen_golden import FORCED_CASES, synth_host_case
+    case = {c[0]: c for c in FORCED_CASES}[name]
+    _, seed, C, nspk, thr, mcs, kw, mne, rseed, constrained = case
+    seg, emb = synth_host_case(seed, C=C, n_spk=nspk)
+    ahc = AgglomerativeClustering(metric="cosine", method="centroid", threshold=thr, min_cluster_size=mcs,
+                                  max_num_embeddings=mne, constrained_assignment=constrained)
+    if rseed is not None:
+        random.seed(rseed)
+    hard, soft, cent = ahc(embeddings=emb.copy(), segmentations=seg, **kw)
+    assert np.array_equal(hard, _FORCED[f"{name}_hard"])
+    assert np.allclose(cent, _FORCED[f"{name}_centroids"], atol=1e-6)
