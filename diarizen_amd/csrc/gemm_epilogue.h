@@ -172,19 +172,17 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     return;
   }
   // column blocks per batch: 4 keeps acc + two residual batches + the hoisted column-vector reads inside 256 registers
-  constexpr int JC = NI % 8 == 0 ? 8 : NI % 6 == 0 ? 6 : NI % 4 == 0 ? 4 : NI % 3 == 0 ? 3 : NI % 5 == 0 ? 5 : NI % 2 == 0 ? 2 : 1;
+  constexpr int JC = MI * NI > 16 ? 4 : NI % 8 == 0 ? 8 : NI % 6 == 0 ? 6 : NI % 4 == 0 ? 4 : NI % 3 == 0 ? 3 : NI % 5 == 0 ? 5 : NI % 2 == 0 ? 2 : 1;
   constexpr int NJC = NI / JC, NB = MI * NJC;            // batch b = (row block b / NJC, column chunk b % NJC)
   constexpr bool REGCOLS = !LDSCOLS && NI <= 4;          // register column vectors need 12 NI registers
   const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
   const int ncol0 = tn * BN + wn * TN + lq * 4;          // column of block j: ncol0 + 16 j
-  int nc[NI];                                            // ... clamped for the loads
-  bool nok[NI];
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
+  // recomputed at every use rather than kept in 2 NI registers: N % 4 == 0, so a float4 is inside or outside as a whole
+  auto nok_ = [&](const int j) { return ncol0 + j * 16 < d.N; };
+  auto nc_ = [&](const int j) {                          // ... clamped for the loads
     const int n0 = ncol0 + j * 16;
-    nok[j] = n0 < d.N;                                   // N % 4 == 0: a float4 is inside or outside as a whole
-    nc[j] = nok[j] ? n0 : d.N - 4;
-  }
+    return n0 < d.N ? n0 : d.N - 4;
+  };
   int64_t crow[MI];
   bool mok[MI];
   int mcl[MI];
@@ -200,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
   auto issue_r = [&](const int b, const int slot) {
     const int i = b / NJC, jc = b % NJC;
 #pragma unroll
-    for (int jj = 0; jj < JC; ++jj) r4[slot][jj] = *reinterpret_cast<const float4*>(d.R + crow[i] + nc[jc * JC + jj]);
+    for (int jj = 0; jj < JC; ++jj) r4[slot][jj] = *reinterpret_cast<const float4*>(d.R + crow[i] + nc_(jc * JC + jj));
   };
   if (d.R) issue_r(0, 0);
   float ln_mu[MI], ln_rs[MI];
@@ -226,15 +224,15 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     }
     if (col_scale) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) cs4[j] = *reinterpret_cast<const float4*>(col_scale + nc[j]);
+      for (int j = 0; j < NI; ++j) cs4[j] = *reinterpret_cast<const float4*>(col_scale + nc_(j));
     }
     if (d.ln_stats) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) lc4[j] = *reinterpret_cast<const float4*>(d.ln_colsum + nc[j]);
+      for (int j = 0; j < NI; ++j) lc4[j] = *reinterpret_cast<const float4*>(d.ln_colsum + nc_(j));
     }
     if (bias) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) b4[j] = *reinterpret_cast<const float4*>(bias + nc[j]);
+      for (int j = 0; j < NI; ++j) b4[j] = *reinterpret_cast<const float4*>(bias + nc_(j));
     }
   } else if constexpr (LDSCOLS) {
     // lane l < TN / 4 owns columns 4 l .. 4 l + 3 of the wavefront tile
@@ -261,9 +259,9 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
       l = *reinterpret_cast<const float4*>(p + TN);
       bb = *reinterpret_cast<const float4*>(p + 2 * TN);
     } else {    // wide tile without scratch: straight from global (L2 hits), still no control flow
-      c = col_scale ? *reinterpret_cast<const float4*>(col_scale + nc[j]) : make_float4(1.f, 1.f, 1.f, 1.f);
-      l = d.ln_stats ? *reinterpret_cast<const float4*>(d.ln_colsum + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
-      bb = bias ? *reinterpret_cast<const float4*>(bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      c = col_scale ? *reinterpret_cast<const float4*>(col_scale + nc_(j)) : make_float4(1.f, 1.f, 1.f, 1.f);
+      l = d.ln_stats ? *reinterpret_cast<const float4*>(d.ln_colsum + nc_(j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bb = bias ? *reinterpret_cast<const float4*>(bias + nc_(j)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   float amax_row[MI], st_s[MI], st_q[MI];
@@ -302,7 +300,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         acc[i][j] = v;
-        if (nok[j]) {      // statistics / |max| over the columns that exist
+        if (nok_(j)) {      // statistics / |max| over the columns that exist
           amax_row[i] = fmaxf(fmaxf(amax_row[i], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
           st_s[i] += (v[0] + v[1]) + (v[2] + v[3]);
           st_q[i] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], st_q[i]))));
@@ -314,8 +312,8 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
 #pragma unroll
       for (int jj = 0; jj < JC; ++jj) {
         const int j = jc * JC + jj;
-        if (mok[i] && nok[j])
-          *reinterpret_cast<float4*>(d.C + crow[i] + nc[j]) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (mok[i] && nok_(j))
+          *reinterpret_cast<float4*>(d.C + crow[i] + nc_(j)) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     }
   };
@@ -332,7 +330,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
       const int i = b / NJC, jc = b % NJC;
       const float* wrow = d.WS + (int64_t)mcl[i] * d.ldws;
 #pragma unroll
-      for (int jj = 0; jj < JC; ++jj) w4[slot][jj] = *reinterpret_cast<const float4*>(wrow + nc[jc * JC + jj]);
+      for (int jj = 0; jj < JC; ++jj) w4[slot][jj] = *reinterpret_cast<const float4*>(wrow + nc_(jc * JC + jj));
     };
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -348,8 +346,8 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
       for (int jj = 0; jj < JC; ++jj) {
         const int j = jc * JC + jj;
         const float4 w = w4[b & 1][jj];
-        if (mok[i] && nok[j])
-          *reinterpret_cast<float4*>(wrow + nc[j]) =
+        if (mok[i] && nok_(j))
+          *reinterpret_cast<float4*>(wrow + nc_(j)) =
               make_float4(w.x + d.ws_w * acc[i][j][0], w.y + d.ws_w * acc[i][j][1], w.z + d.ws_w * acc[i][j][2],
                           w.w + d.ws_w * acc[i][j][3]);
       }

@@ -313,11 +313,11 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(const dzn_gemm_desc d) {
   constexpr int NPIECE = STAGE / 1024;
   static_assert(NPIECE % 8 == 0 && NI % 2 == 0, "tile shape");
   constexpr int PPW = NPIECE / 8;
-  constexpr int OPS = PPW + 2 * MI;
-  constexpr int INFL = (AD < S - 3 ? AD : S - 3) * OPS;
-  constexpr int AHEAD = (S - 2 > AD ? S - 2 : AD);
-  constexpr int NR = AD + 1;
-  static_assert(S >= 4 && AD >= 1 && AD <= S - 2 && INFL < 64 && RD >= 2 && RD <= NPAIR, "pipeline depths");
+  // A is loaded ONE tile ahead into a single register set: a load segment first waits for its own tile (issued by the
+  // previous segment, after that segment's W pieces: so only the PPW pieces it issues itself stay in flight), splits it
+  // into the fp16 fragments, and only then issues the next tile's loads into the same registers.
+  constexpr int AHEAD = S - 2;
+  static_assert(S >= 4 && AD == 1 && RD >= 2 && RD <= NPAIR, "pipeline depths");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(const dzn_gemm_desc d) {
   int wk = 0, wst = 0;
   int64_t a_koff = 0;
   int a_rem = 0;
-  f32x4 araw[NR][MI][2];
+  f32x4 araw[MI][2];
   u32x4 af[MI][NP];
   u32x4 ring[RD][2][NP];                     // W fragments of RD column-block pairs
   f32x4 acc[MI][NI];
@@ -388,12 +388,11 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(const dzn_gemm_desc d) {
     wk += BK;
     wst = wst + 1 == S ? 0 : wst + 1;
   };
-  auto issue_a = [&](auto rc) {
-    constexpr int R = decltype(rc)::value;
+  auto issue_a = [&]() {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      asm_load16<0>(araw[R][i][0], aptr[i] + a_koff);
-      asm_load16<64>(araw[R][i][1], aptr[i] + a_koff);
+      asm_load16<0>(araw[i][0], aptr[i] + a_koff);
+      asm_load16<64>(araw[i][1], aptr[i] + a_koff);
     }
     a_koff += BK;
     a_rem += BK;
@@ -401,20 +400,17 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(const dzn_gemm_desc d) {
   };
 
   const bool deep = nk > AHEAD;
+  // prologue: W tiles 0 .. S-3, then A tile 0; W tile 0 must be visible to everybody before the first segment
   if (deep) {
 #pragma unroll
     for (int s = 0; s < S - 2; ++s) issue_w();
-    static_for<AD>([&](auto ac) { issue_a(ac); });
-    wait_vm_only<(AD - 1) * 2 * MI>();
   } else {
 #pragma unroll
     for (int s = 0; s < S - 2; ++s)
       if (s < nk) issue_w();
-    static_for<AD>([&](auto ac) {
-      if (decltype(ac)::value < nk) issue_a(ac);
-    });
-    wait_vm_only<0>();
   }
+  issue_a();
+  wait_vm_only<2 * MI>();                    // everything but A tile 0 (the first segment waits for that itself)
   if constexpr (NP <= 2) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -434,36 +430,43 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(const dzn_gemm_desc d) {
       for (int p = 0; p < NP; ++p)
         ring[SL][jj][p] = *reinterpret_cast<const u32x4*>(base + p * WPLANE + (2 * pr + jj) * 1024);
   };
-  auto segment = [&](auto rc, auto fullc, int t) {
-    constexpr int R = decltype(rc)::value;
+  auto segment = [&](int, auto fullc, int t) {
     constexpr bool FULL = decltype(fullc)::value;
     const unsigned char* base = smem + rst * STAGE + woff0;
     rst = rst + 1 == S ? 0 : rst + 1;
     // -------- load segment of tile t --------
-    if constexpr (FULL) {
-      issue_w();
-      issue_a(std::integral_constant<int, (R + AD) % NR>{});
-    } else {
-      if (t + S - 2 < nk) issue_w();
-      if (t + AD < nk) issue_a(std::integral_constant<int, (R + AD) % NR>{});
-    }
-    static_for<RD - 1>([&](auto pc) { read_pair(base, pc, decltype(pc)::value); });
-    if constexpr (FULL) wait_vm_tied<INFL>(araw[R]);
-    else wait_vm_tied<0>(araw[R]);
+    // (1) A tile t: issued last by the previous segment -> nothing of ours is younger
+    wait_vm_tied<0>(araw);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       if constexpr (NP == 3) {
         bf16x8 h_, m_, l_;
-        split8(araw[R][i][0], araw[R][i][1], h_, m_, l_);
+        split8(araw[i][0], araw[i][1], h_, m_, l_);
         af[i][0] = __builtin_bit_cast(u32x4, h_);
         af[i][1] = __builtin_bit_cast(u32x4, m_);
         af[i][2] = __builtin_bit_cast(u32x4, l_);
       } else if constexpr (NP == 2) {
-        split8_h2(araw[R][i][0], araw[R][i][1], a_scale[i], af[i][0], af[i][1]);
+        split8_h2(araw[i][0], araw[i][1], a_scale[i], af[i][0], af[i][1]);
       } else {
-        cvt8_h1(araw[R][i][0], araw[R][i][1], a_scale[i], af[i][0]);
+        cvt8_h1(araw[i][0], araw[i][1], a_scale[i], af[i][0]);
       }
     }
+    // the split must have consumed the raw registers before the next loads are issued into them
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(af[i][p]));
+    // (2) W tile t+S-2 and A tile t+1; everything the previous segments issued has landed (in-order return), and the
+    //     barrier below publishes this wavefront's pieces of tile t+1 to the other group
+    if constexpr (FULL) {
+      issue_w();
+      issue_a();
+    } else {
+      if (t + S - 2 < nk) issue_w();
+      if (t + 1 < nk) issue_a();
+    }
+    // (3) first fragment pairs of tile t
+    static_for<RD - 1>([&](auto pc) { read_pair(base, pc, decltype(pc)::value); });
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -490,13 +493,8 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(const dzn_gemm_desc d) {
   };
   int t0 = 0;
   if (deep)
-    for (; t0 + NR - 1 + AHEAD < nk; t0 += NR)
-      static_for<NR>([&](auto rc) { segment(rc, std::true_type{}, t0 + decltype(rc)::value); });
-  for (; t0 < nk; t0 += NR)
-    static_for<NR>([&](auto rc) {
-      const int t = t0 + decltype(rc)::value;
-      if (t < nk) segment(rc, std::false_type{}, t);
-    });
+    for (; t0 + AHEAD < nk; ++t0) segment(0, std::true_type{}, t0);
+  for (; t0 < nk; ++t0) segment(0, std::false_type{}, t0);
 
   float* lds_cols = reinterpret_cast<float*>(smem + S * STAGE) + wave * 3 * BN;
   gemm_epilogue<BM, BN, TM, BN, MI, NI, true>(d, acc, tm, tn, wave, 0, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr,
@@ -566,14 +564,13 @@ int launch_pp_cfg(const dzn_gemm_desc& d, hipStream_t s) {
 //      streamed form "pq128" / "pq192" / "pq256" (+ "r3": ring of 3 pairs, "a2": A two tiles ahead with 5 stages)
 int launch_gemm_pp(const dzn_gemm_desc& d, hipStream_t s, int np, const char* cfg) {
   if (cfg && !strncmp(cfg, "pq", 2)) {
-    const bool r3 = strstr(cfg, "r3"), a2 = strstr(cfg, "a2");
+    const bool r3 = strstr(cfg, "r3");
     const int bn = atoi(cfg + 2);
     if (np == 2) {
-      if (bn == 128) return a2 ? launch_pq_cfg<128, 2, 5, 2, 2>(d, s) : r3 ? launch_pq_cfg<128, 2, 4, 1, 3>(d, s) : launch_pq_cfg<128, 2, 4, 1, 2>(d, s);
+      if (bn == 128) return r3 ? launch_pq_cfg<128, 2, 4, 1, 3>(d, s) : launch_pq_cfg<128, 2, 4, 1, 2>(d, s);
       if (bn == 192) return r3 ? launch_pq_cfg<192, 2, 4, 1, 3>(d, s) : launch_pq_cfg<192, 2, 4, 1, 2>(d, s);
-      if (bn == 256) return r3 ? launch_pq_cfg<256, 2, 4, 1, 3>(d, s) : launch_pq_cfg<256, 2, 4, 1, 2>(d, s);
+      // (256 x 256: 128 accumulator registers + ring + fragments do not fit 256 VGPRs without spilling)
     }
-    if (np == 1 && bn == 256) return launch_pq_cfg<256, 1, 4, 1, 2>(d, s);
     if (np == 1 && bn == 128) return launch_pq_cfg<128, 1, 4, 1, 2>(d, s);
     if (np == 3 && bn == 128) return launch_pq_cfg<128, 3, 4, 1, 2>(d, s);
     return DZN_E_INVALID;
