@@ -47,7 +47,7 @@ DTYPE_NOTE = {"f32": "f32 (fp32 MFMA v_mfma_f32_16x16x4_f32)",
 PEAK_HBM_GBS = 8000.0
 
 
-from diarizen_amd.synth import synth_recording  # noqa: E402
+from testkit.synth import synth_recording  # noqa: E402
 
 
 # in-situ profiler class -> kernel symbol in the rocprofv3 tables (scripts/pmc_summary.py writes profiles/*.json)
@@ -154,7 +154,7 @@ def e2e_leg(args, dev, wave_host):
     import numpy as np
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.pipeline import DiariZenPipeline
-    from diarizen_amd.weights import emb_state_dict, turn_taking_state_dict
+    from testkit.weights import emb_state_dict, turn_taking_state_dict
     cfg = get_seg_config(args.model)
     conf = {"model": {"path": "diarizen.models.eend.model_wavlm_conformer.Model",
                       "args": {"wavlm_src": args.model, "wavlm_layer_num": cfg.wavlm_layer_num,
@@ -238,8 +238,8 @@ def main():
     from diarizen_amd.dist import gather_windows
     from diarizen_amd.engine import Engine
     from diarizen_amd.inference import WindowRunner
-    from diarizen_amd.synth import synth_recording_range
-    from diarizen_amd.weights import emb_state_dict, seg_state_dict   # seeded random init
+    from testkit.synth import synth_recording_range
+    from testkit.weights import emb_state_dict, seg_state_dict   # seeded random init
 
     cfg = get_seg_config(args.model)
     sd = seg_state_dict(cfg, 0)

@@ -44,7 +44,10 @@ def centroid_linkage(emb: np.ndarray, backend: str = "auto", device: int = -1) -
     memory at hours of audio.  "auto": hip from HIP_LINKAGE_MIN embeddings up when a device is present."""
     if backend not in ("auto", "scipy", "hip"):
         raise ValueError(f"unknown linkage backend {backend!r}")
-    use_hip = backend == "hip" or (backend == "auto" and len(emb) >= HIP_LINKAGE_MIN and _hip_ready())
+    # the device kernel computes its float64 distances from FLOAT32 coordinates: only float32 embeddings (what the
+    # engine produces) may take it in auto mode — float64 input would be rounded first and could merge in another order
+    use_hip = backend == "hip" or (backend == "auto" and len(emb) >= HIP_LINKAGE_MIN and emb.dtype == np.float32
+                                   and _hip_ready())
     if use_hip and backend == "auto" and _has_duplicate_rows(emb):
         # exact distance ties: scipy's neighbour-heap order and the device's lowest-index argmin may merge tied
         # pairs in a different order -> keep the reference's own call whenever ties are certain

@@ -236,5 +236,24 @@ struct ProfScope {
   ProfScope& operator=(const ProfScope&) = delete;
 };
 
+// Makes `dev` the calling thread's current HIP device for the lifetime of the object and RESTORES the previous one
+// (every C-ABI entry point that takes a device ordinal or a handle owning one: engine.cpp, linkage.hip, vbx.hip).
+// dev < 0 = leave the current device alone.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (dev < 0) return;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -44,17 +44,6 @@ struct EngineError : std::runtime_error {
 // Makes the handle's device current for the duration of a C-ABI call and restores the caller's
 // (lazy allocations, table uploads and kernel launches must not land on whatever device the calling
 // thread happens to have current — e.g. DiariZenPipeline(device="cuda:1") in a process at device 0).
-struct DeviceGuard {
-  int prev = -1;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    if (prev != dev) (void)hipSetDevice(dev);
-    else prev = -1;
-  }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
 
 struct HostT {
   std::vector<float> v;
@@ -392,9 +381,47 @@ void finalize_seg(H* h) {
         for (int i = 0; i < k0; ++i)
           for (int j = 0; j < k0; ++j)
             Q[i * 10 + j] += (w.v[(size_t)ch * k0 + i] - wb[i]) * (w.v[(size_t)ch * k0 + j] - wb[j]) / C0;
+      // var = x^T Q x as a plain sum of products cancels when the frame lies near Q's small-eigenvalue directions (trained
+      // DC-blocking / band-pass conv0 taps on low-frequency or quiet audio: ADVICE r2).  Q is PSD: factor it once, in
+      // double, as Q = sum_e lambda_e v_e v_e^T (cyclic Jacobi) and ship F[e][j] = sqrt(lambda_e) v_e[j]; the kernels
+      // evaluate var = sum_e (F[e] . x)^2 — a sum of squares, nothing to cancel.
+      std::vector<double> Aj(Q), V(100, 0.0);
+      for (int i = 0; i < 10; ++i) V[i * 10 + i] = 1.0;
+      for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 10; ++p)
+          for (int q = p + 1; q < 10; ++q) off += Aj[p * 10 + q] * Aj[p * 10 + q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 10; ++p)
+          for (int q = p + 1; q < 10; ++q) {
+            const double apq = Aj[p * 10 + q];
+            if (apq == 0.0) continue;
+            const double theta = (Aj[q * 10 + q] - Aj[p * 10 + p]) / (2.0 * apq);
+            const double tt = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            const double cs = 1.0 / std::sqrt(tt * tt + 1.0), sn = tt * cs;
+            for (int r = 0; r < 10; ++r) {        // A <- A J (columns p, q)
+              const double arp = Aj[r * 10 + p], arq = Aj[r * 10 + q];
+              Aj[r * 10 + p] = cs * arp - sn * arq;
+              Aj[r * 10 + q] = sn * arp + cs * arq;
+            }
+            for (int r = 0; r < 10; ++r) {        // A <- J^T A (rows p, q)
+              const double apr = Aj[p * 10 + r], aqr = Aj[q * 10 + r];
+              Aj[p * 10 + r] = cs * apr - sn * aqr;
+              Aj[q * 10 + r] = sn * apr + cs * aqr;
+            }
+            for (int r = 0; r < 10; ++r) {        // V <- V J
+              const double vrp = V[r * 10 + p], vrq = V[r * 10 + q];
+              V[r * 10 + p] = cs * vrp - sn * vrq;
+              V[r * 10 + q] = sn * vrp + cs * vrq;
+            }
+          }
+      }
       std::vector<float> lq(110);
       for (int i = 0; i < 10; ++i) lq[i] = (float)wb[i];
-      for (int i = 0; i < 100; ++i) lq[10 + i] = (float)Q[i];
+      for (int e = 0; e < 10; ++e) {
+        const double lam = std::max(Aj[e * 10 + e], 0.0);
+        for (int j = 0; j < 10; ++j) lq[10 + e * 10 + j] = (float)(std::sqrt(lam) * V[j * 10 + e]);
+      }
       h->conv0_lnq = upload(h, lq);
     }
     if (c.extractor_layer_norm) {   // |LN(x)_c| <= sqrt(C - 1), |GELU(t)| <= |t|

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
   }
   __syncthreads();
   // LayerNorm statistics of a frame WITHOUT touching its C0 outputs: y_c = w_c . x (x = the frame's k samples), so
-  //   mean_c y = wbar . x   and   var_c y = x^T Q x   with wbar = mean_c w_c, Q = cov_c(w_c) (k x k, PSD, built in
+  //   mean_c y = wbar . x   and   var_c y = x^T Q x = |F x|^2   with wbar = mean_c w_c, Q = cov_c(w_c) = F^T F (k x k, PSD, factored in
   // double at weight-load time).  One thread per frame here; the frame loop below has no cross-lane reductions left.
   const bool qstats = LN && lnq != nullptr;
   if (qstats && tid < nfr) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
       float q = 0.f;
 #pragma unroll
       for (int j = 0; j < 10; ++j) q = fmaf(lnq[10 + i * 10 + j], xv[j], q);
-      var = fmaf(q, xv[i], var);
+      var = fmaf(q, q, var);     // lnq rows are the factor F of Q = F^T F: a sum of squares
     }
     sst[tid] = make_float2(mu, 1.0f / sqrtf(fmaxf(var, 0.f) + eps));
   }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a)
       float q = 0.f;
 #pragma unroll
       for (int j = 0; j < 10; ++j) q = fmaf(a.lnq[10 + i * 10 + j], xv[j], q);
-      var = fmaf(q, xv[i], var);
+      var = fmaf(q, q, var);     // lnq rows are the factor F of Q = F^T F: a sum of squares
     }
     sst[f] = make_float2(mu, 1.0f / sqrtf(fmaxf(var, 0.f) + a.eps));
   }

@@ -140,6 +140,14 @@ __device__ __forceinline__ void gemm_epilogue_general(const dzn_gemm_desc& d, f3
   }
 }
 
+// largest divisor of ni that is <= cap: column blocks per epilogue batch
+constexpr int epi_chunk(int ni, int cap) {
+  int best = 1;
+  for (int c = 1; c <= cap; ++c)
+    if (ni % c == 0) best = c;
+  return best;
+}
+
 template <int ACT>
 __device__ __forceinline__ float apply_act_c(float v) {
   if constexpr (ACT == DZN_ACT_GELU) return gelu_erf(v);
@@ -172,7 +180,9 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     return;
   }
   // column blocks per batch: 4 keeps acc + two residual batches + the hoisted column-vector reads inside 256 registers
-  constexpr int JC = MI * NI > 16 ? 4 : NI % 8 == 0 ? 8 : NI % 6 == 0 ? 6 : NI % 4 == 0 ? 4 : NI % 3 == 0 ? 3 : NI % 5 == 0 ? 5 : NI % 2 == 0 ? 2 : 1;
+  constexpr int JCMAX = MI * NI > 16 ? 4 : 8;          // wide tiles: 128 accumulator registers leave room for 2 x 4 float4s
+  constexpr int JC = epi_chunk(NI, JCMAX);
+  static_assert(NI % JC == 0, "column chunks tile the wavefront tile");
   constexpr int NJC = NI / JC, NB = MI * NJC;            // batch b = (row block b / NJC, column chunk b % NJC)
   constexpr bool REGCOLS = !LDSCOLS && NI <= 4;          // register column vectors need 12 NI registers
   const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;

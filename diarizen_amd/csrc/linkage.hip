@@ -324,7 +324,8 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   std::vector<int> ones(n, 1), ids(n);
   for (int i = 0; i < n; ++i) ids[i] = i;
   MergeState st0{};
-  if (device >= 0) LCHK(hipSetDevice(device));
+  DeviceGuard dg(device);      // restores the caller's device on every return path
+  if (!dg.ok) return DZN_E_HIP;
   if (hipMalloc(&D, (size_t)n * n * sizeof(double)) != hipSuccess) { rc = DZN_E_NOMEM; goto done; }
   LCHK(hipMalloc(&E, (size_t)n * dim * sizeof(float)));
   LCHK(hipMalloc(&lb, (size_t)n * sizeof(double)));
@@ -432,7 +433,8 @@ extern "C" int dzn_cdist_cosine(const float* h_emb, int32_t n, int32_t dim, cons
   int rc = DZN_OK;
   float* E = nullptr;
   double *Cn = nullptr, *ne = nullptr, *nc = nullptr, *D = nullptr;
-  if (device >= 0) LCHK(hipSetDevice(device));
+  DeviceGuard dg(device);      // restores the caller's device on every return path
+  if (!dg.ok) return DZN_E_HIP;
   if (hipMalloc(&E, (size_t)n * dim * sizeof(float)) != hipSuccess) { rc = DZN_E_NOMEM; goto done; }
   LCHK(hipMalloc(&Cn, (size_t)k * dim * sizeof(double)));
   LCHK(hipMalloc(&ne, (size_t)n * sizeof(double)));

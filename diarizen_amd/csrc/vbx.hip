@@ -144,7 +144,8 @@ extern "C" int dzn_vbx_create(const double* h_X, const double* h_Phi, const doub
   double *X = nullptr, *Phi = nullptr;
   s->E = E; s->D = D; s->K = K; s->device = device;
   s->nchunk = (E + VB_CHUNK - 1) / VB_CHUNK;
-  if (device >= 0) VCHK(hipSetDevice(device));
+  DeviceGuard dg(device);
+  if (!dg.ok) return DZN_E_HIP;
   if (hipMalloc(&X, (size_t)E * D * 8) != hipSuccess) { rc = DZN_E_NOMEM; goto done; }
   VCHK(hipMalloc(&Phi, (size_t)D * 8));
   VCHK(hipMalloc(&s->rho, (size_t)E * D * 8));
@@ -176,7 +177,8 @@ extern "C" int dzn_vbx_stats(void* state, double* h_stats) {
   if (!s || !h_stats) return DZN_E_INVALID;
   int rc = DZN_OK;
   const int n = s->K * (s->D + 1);
-  if (s->device >= 0) VCHK(hipSetDevice(s->device));
+  DeviceGuard dg(s->device);
+  if (!dg.ok) return DZN_E_HIP;
   hipLaunchKernelGGL(vb_accum_kernel, dim3(s->nchunk), dim3(256), 0, 0, s->gamma, s->rho, s->E, s->D, s->K, s->partial);
   hipLaunchKernelGGL(vb_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, s->partial, s->nchunk, n, s->stats);
   VCHK(hipGetLastError());
@@ -193,7 +195,8 @@ extern "C" int dzn_vbx_estep(void* state, const double* h_alpha, const double* h
   if (!s || !h_alpha || !h_ck || !h_lpi || !h_total) return DZN_E_INVALID;
   int rc = DZN_OK;
   double total = 0.0;
-  if (s->device >= 0) VCHK(hipSetDevice(s->device));
+  DeviceGuard dg(s->device);
+  if (!dg.ok) return DZN_E_HIP;
   VCHK(hipMemcpy(s->alpha, h_alpha, (size_t)s->K * s->D * 8, hipMemcpyHostToDevice));
   VCHK(hipMemcpy(s->ck, h_ck, (size_t)s->K * 8, hipMemcpyHostToDevice));
   VCHK(hipMemcpy(s->lpi, h_lpi, (size_t)s->K * 8, hipMemcpyHostToDevice));
@@ -212,11 +215,14 @@ done:
 extern "C" int dzn_vbx_gamma(void* state, double* h_gamma) {
   VbState* s = static_cast<VbState*>(state);
   if (!s || !h_gamma) return DZN_E_INVALID;
-  if (s->device >= 0 && hipSetDevice(s->device) != hipSuccess) return DZN_E_HIP;
+  DeviceGuard dg(s->device);
+  if (!dg.ok) return DZN_E_HIP;
   return hipMemcpy(h_gamma, s->gamma, (size_t)s->E * s->K * 8, hipMemcpyDeviceToHost) == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
 extern "C" int dzn_vbx_destroy(void* state) {
+  if (!state) return DZN_OK;
+  DeviceGuard dg(static_cast<VbState*>(state)->device);
   vb_free(static_cast<VbState*>(state));
   return DZN_OK;
 }

@@ -39,9 +39,16 @@ EMBEDDING_REPO = "pyannote/wespeaker-voxceleb-resnet34-LM"
 def _load_checkpoint(path: str) -> Dict[str, torch.Tensor]:
     """plain state_dict (DiariZen hub `pytorch_model.bin`) or Lightning checkpoint (WeSpeaker).  Tensors-only
     unpickling first; the permissive loader only for checkpoints that carry other python objects (Lightning)."""
+    import pickle
     try:
         ckpt = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
+    except pickle.UnpicklingError:
+        # the safe loader refused a non-tensor global.  Only the WeSpeaker checkpoint is a Lightning pickle with such
+        # objects (PA/core/model.py:459-473); executing arbitrary pickles is opt-in, never a silent fallback.
+        if os.environ.get("DZN_TRUST_CHECKPOINTS") != "1":
+            raise RuntimeError(f"{path}: not a tensors-only checkpoint.  If this file comes from a source you trust (e.g. the "
+                               f"pyannote/wespeaker-voxceleb-resnet34-LM Lightning checkpoint), set DZN_TRUST_CHECKPOINTS=1 to "
+                               f"load it with the full unpickler.") from None
         ckpt = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(ckpt, dict) and "state_dict" in ckpt and isinstance(ckpt["state_dict"], dict):
         ckpt = ckpt["state_dict"]          # Lightning checkpoint (PA/core/model.py:459-473)

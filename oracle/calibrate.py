@@ -1,6 +1,6 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY.
 
-Fits the classifier of the seeded "turn taking" weights (diarizen_amd/weights.py:turn_taking_state_dict)
+Fits the classifier of the seeded "turn taking" weights (testkit/weights.py:turn_taking_state_dict)
 so that the seeded model's hard decisions are NOT degenerate.  VERDICT r1 weak #1: with plain random
 weights every frame of every fixture is one powerset class, so "bit-exact decisions" compared
 constants and the overlap-exclusion rule only ever took its fallback branch.
@@ -14,7 +14,7 @@ criteria hold on the calibration audio: >= 6 classes with >= 5 % of the frames e
 transitions in every window, smallest top-2 logit margin >= 3e-4 (so fp32 re-association noise of
 ~1e-5 cannot flip a decision of the fixture itself).
 
-    python oracle/calibrate.py                 # all configs -> diarizen_amd/data/cal_<config>_seed0.npz
+    python oracle/calibrate.py                 # all configs -> testkit/data/cal_<config>_seed0.npz
 
 Calibration audio: tests/golden/EN2002a_30s.wav (the reference's example file) plus a few windows of
 the synthetic bench recording, cut into windows of the config's fixture length.
@@ -30,10 +30,10 @@ import torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
-from diarizen_amd.audio import first_channel_16k  # noqa: E402
-from diarizen_amd.configs import get_seg_config  # noqa: E402
-from diarizen_amd.synth import synth_recording  # noqa: E402
-from diarizen_amd.weights import CAL_DIR, seg_state_dict, turn_taking_head  # noqa: E402
+from oracle.wav import first_channel_pcm16 as first_channel_16k  # noqa: E402
+from oracle.configs import get_seg_config  # noqa: E402
+from testkit.synth import synth_recording  # noqa: E402
+from testkit.weights import CAL_DIR, seg_state_dict, turn_taking_head  # noqa: E402
 from oracle import seg_model  # noqa: E402
 from oracle.pipeline import slide_windows  # noqa: E402
 

@@ -27,7 +27,7 @@ EPS = torch.finfo(torch.float32).eps   # torchaudio _get_epsilon
 
 
 # --------------------------------------------------------------------------- weights
-from diarizen_amd.weights import emb_state_dict  # noqa: E402,F401
+from testkit.weights import emb_state_dict  # noqa: E402,F401
 
 
 # --------------------------------------------------------------------------- kaldi fbank

@@ -29,7 +29,7 @@ REF = Path("/root/reference")
 GOLD = ROOT / "tests" / "golden"
 sys.path.insert(0, str(ROOT))
 
-from diarizen_amd.configs import get_seg_config  # noqa: E402
+from oracle.configs import get_seg_config  # noqa: E402
 from oracle import seg_model  # noqa: E402
 
 
@@ -140,7 +140,7 @@ def gen_seg():
 
 def tt_windows(starts, N: int) -> torch.Tensor:
     """windows of tests/golden/EN2002a_30s.wav starting at `starts` (samples)"""
-    from diarizen_amd.audio import first_channel_16k
+    from oracle.wav import first_channel_pcm16 as first_channel_16k
     wave = torch.from_numpy(first_channel_16k(str(GOLD / "EN2002a_30s.wav")))
     return torch.stack([wave[s:s + N] for s in starts])
 
@@ -158,7 +158,7 @@ TT_CASES = {
 def gen_seg_tt():
     """Reference modules (strict state_dict load) with the seeded turn-taking weights on real audio: logp
     goldens whose argmax is NOT constant (asserted), at the sizes BASELINE.json names."""
-    from diarizen_amd.weights import turn_taking_state_dict
+    from testkit.weights import turn_taking_state_dict
     for name, (N, starts) in TT_CASES.items():
         cfg = get_seg_config(name)
         sd = turn_taking_state_dict(cfg, 0)
@@ -308,7 +308,7 @@ def load_reference_clustering():
         def __init__(self, *a, **k):
             pass
 
-    from diarizen_amd import core as mycore
+    from oracle import pyannote_core_stub as mycore
     stub("pyannote")
     stub("pyannote.core", SlidingWindow=mycore.SlidingWindow, SlidingWindowFeature=mycore.SlidingWindowFeature,
          Segment=mycore.Segment, Annotation=mycore.Annotation)
@@ -405,15 +405,15 @@ E2E_VBX = {"ahc_threshold": 0.1, "Fa": 0.07, "Fb": 0.8, "lda_dim": 128, "max_ite
 
 def gen_e2e():
     """example/EN2002a_30s.wav through the oracle device stage (reference execution order) with the
-    seeded TURN-TAKING weights (diarizen_amd/weights.py:turn_taking_state_dict — plain random weights emit one
+    seeded TURN-TAKING weights (testkit/weights.py:turn_taking_state_dict — plain random weights emit one
     class for every frame) -> per-window decisions + embeddings; then the host stage: the REFERENCE's own
     clustering module on those outputs + the loop-for-loop restatement oracle/host_stage.py -> golden RTTM.
     The wav itself (a data fixture of the reference, not source) sits next to the goldens so the GPU box
     can read it."""
     import copy
     import shutil
-    from diarizen_amd.audio import first_channel_16k
-    from diarizen_amd.weights import emb_state_dict, turn_taking_state_dict
+    from oracle.wav import first_channel_pcm16 as first_channel_16k
+    from testkit.weights import emb_state_dict, turn_taking_state_dict
     from oracle import host_stage
     from oracle.pipeline import device_stage_reference
     _ref_path()
@@ -580,7 +580,20 @@ def gen_host_forced():
     np.savez_compressed(GOLD / "host_clustering_forced.npz", **out)
 
 
-GENERATORS = {"seg": gen_seg, "seg_tt": gen_seg_tt, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
+
+# ------------------------------------------------------------------ the reference's architecture tables
+def gen_configs():
+    """tests/golden/wavlm_configs.json: `get_config(name)` of diarizen/models/module/wavlm_config.py, verbatim, for its four
+    names — the source of oracle/configs.py (the product's diarizen_amd/configs.py is checked against it in tests)."""
+    import json
+    _ref_path()
+    from diarizen.models.module.wavlm_config import get_config
+    out = {n: get_config(n) for n in ("wavlm_base", "wavlm_large", "wavlm_base_s80_md", "wavlm_large_s80_md")}
+    (GOLD / "wavlm_configs.json").write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+    print("wavlm_configs:", {n: len(v["encoder_ff_interm_features"]) for n, v in out.items()})
+
+
+GENERATORS = {"configs": gen_configs, "seg": gen_seg, "seg_tt": gen_seg_tt, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
               "e2e": gen_e2e, "host_ref": gen_host_ref, "host_forced": gen_host_forced}
 
 if __name__ == "__main__":

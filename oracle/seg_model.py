@@ -15,13 +15,13 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn.functional as F
 
-from diarizen_amd.configs import SegConfig
+from oracle.configs import OracleSegConfig as SegConfig   # typing only: any object with these attributes works
 
 P = "wavlm_model."
 
 
 # --------------------------------------------------------------------------- weights
-from diarizen_amd.weights import seg_state_dict  # noqa: E402,F401  (seeded random init lives in the product)
+from testkit.weights import seg_state_dict  # noqa: E402,F401  (seeded random init lives in the product)
 
 
 # --------------------------------------------------------------------------- pieces

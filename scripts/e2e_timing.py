@@ -6,7 +6,7 @@ import numpy as np, torch
 from bench import synth_recording
 from diarizen_amd.configs import get_seg_config
 from diarizen_amd.pipeline import DiariZenPipeline
-from diarizen_amd.weights import emb_state_dict, turn_taking_state_dict
+from testkit.weights import emb_state_dict, turn_taking_state_dict
 
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 128

@@ -8,7 +8,7 @@ from bench import synth_recording
 from diarizen_amd.configs import RESNET34, get_seg_config
 from diarizen_amd.engine import Engine
 from diarizen_amd.inference import WindowRunner
-from diarizen_amd.weights import emb_state_dict, seg_state_dict
+from testkit.weights import emb_state_dict, seg_state_dict
 dev = torch.device("cuda:0")
 cfg = get_seg_config("wavlm_large_s80_md"); sd = seg_state_dict(cfg, 0); esd = emb_state_dict(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128

@@ -11,7 +11,7 @@ from typing import Dict
 
 import torch
 
-from .configs import SegConfig
+SegConfig = object      # any object with the attributes of diarizen_amd.configs.SegConfig / oracle.configs.OracleSegConfig
 
 P = "wavlm_model."
 
@@ -150,7 +150,7 @@ def emb_state_dict(seed: int = 0, m: int = 32, feat_dim: int = 80, embed_dim: in
 #     seeded gain) whose branch dominates the residual (pointwise_conv2 x 10) while the half-FFN / MHSA
 #     branches are damped (x 0.1) -> the head features vary smoothly (lag-5 autocorrelation ~0.9);
 #   * classifier: a calibration fitted ONCE by oracle/calibrate.py (within-window PCA of the oracle's head
-#     features on tests/golden/EN2002a_30s.wav) and stored in diarizen_amd/data/cal_<config>.npz, so that
+#     features on tests/golden/EN2002a_30s.wav) and stored in testkit/data/cal_<config>.npz, so that
 #     >= 6 powerset classes each take >= 5 % of the frames with ~15 transitions per 8 s window.
 # Same keys / shapes as the reference checkpoint; everything else is `seg_state_dict(cfg, seed)`.
 CAL_DIR = __import__("pathlib").Path(__file__).resolve().parent / "data"

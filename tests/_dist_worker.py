@@ -13,8 +13,8 @@ from diarizen_amd import dist as dz
 from diarizen_amd.configs import RESNET34, get_seg_config
 from diarizen_amd.engine import Engine
 from diarizen_amd.inference import WindowRunner
-from diarizen_amd.synth import synth_recording
-from diarizen_amd.weights import emb_state_dict, turn_taking_state_dict
+from testkit.synth import synth_recording
+from testkit.weights import emb_state_dict, turn_taking_state_dict
 
 backend = os.environ.get("DZN_TEST_BACKEND", "nccl")
 dev = torch.device("cuda", 0)

@@ -32,7 +32,7 @@ def decision_parity(gpu, n_windows: int, batch: int = 32):
     from diarizen_amd.audio import first_channel_16k
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.engine import Engine
-    from diarizen_amd.weights import turn_taking_state_dict
+    from testkit.weights import turn_taking_state_dict
     from oracle import seg_model
     cfg = get_seg_config("wavlm_large_s80_md")
     sd = turn_taking_state_dict(cfg, 0)

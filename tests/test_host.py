@@ -592,7 +592,7 @@ def test_reference_inference_accepts_and_drives_the_plugin_class(monkeypatch):
     `segment()` with the oracle forward — this test is about the INTERFACE, the HIP engine has its own parity tests."""
     import diarizen_amd.compat as compat
     from diarizen_amd.configs import get_seg_config
-    from diarizen_amd.weights import turn_taking_state_dict
+    from testkit.weights import turn_taking_state_dict
     from oracle import seg_model
     from oracle.gen_golden import tt_windows
     from oracle.pipeline import slide_windows

@@ -130,7 +130,7 @@ def test_seg_oracle_matches_reference_modules_turn_taking(name):
     turn-taking weights on real audio, incl. BASELINE configs[1] at full size (base-s80, 5 s x 32) and the
     bench geometry (large-s80, 8 s): >= 5 classes occur, and the oracle reproduces logp AND every argmax."""
     from diarizen_amd.configs import get_seg_config
-    from diarizen_amd.weights import turn_taking_state_dict
+    from testkit.weights import turn_taking_state_dict
     from oracle import seg_model
     from oracle.gen_golden import tt_windows
     cfg = get_seg_config(name)
@@ -142,3 +142,57 @@ def test_seg_oracle_matches_reference_modules_turn_taking(name):
     # log-probs reach -50 with these weights: 5e-4 absolute is 1e-5 relative (fp32 re-association on the CPU)
     assert np.abs(logp.numpy() - g["logp"]).max() < 5e-4
     assert np.array_equal(logp.numpy().argmax(-1), g["logp"].argmax(-1))
+
+
+# ---------------------------------------------------------------- architecture tables: product vs the reference-derived oracle table
+@pytest.mark.parametrize("name", ["wavlm_base", "wavlm_large", "wavlm_base_s80_md", "wavlm_large_s80_md", "tiny_ln", "tiny_gn"])
+def test_product_config_table_equals_reference_derived_table(name):
+    """diarizen_amd/configs.py (hand-written) against oracle/configs.py, which is built from tests/golden/wavlm_configs.json — a
+    verbatim dump of the reference's diarizen/models/module/wavlm_config.py:get_config made by `oracle/gen_golden.py configs`."""
+    from diarizen_amd.configs import get_seg_config as product
+    from diarizen_amd.configs import seg_config_from_wavlm_kwargs
+    from oracle.configs import OracleSegConfig, get_seg_config as oracle_cfg
+    o, p = oracle_cfg(name), product(name)
+    for f in OracleSegConfig.FIELDS:
+        assert getattr(o, f) == getattr(p, f), (name, f)
+    assert o.n_classes == p.n_classes and o.n_layers == p.n_layers and o.use_attention == p.use_attention
+    for n in (400, 16000, 80000, 128000):
+        assert o.num_frames(n) == p.num_frames(n)
+    # the product's checkpoint-kwargs ingest (f4 row) reads the same dictionaries to the same table
+    q = seg_config_from_wavlm_kwargs(o.kwargs, name=name)
+    for f in ("conv_channels", "conv_kernels", "conv_strides", "embed_dim", "total_heads", "layer_norm_first", "remaining_heads",
+              "ffn_dims", "pos_conv_kernel", "pos_conv_groups", "extractor_layer_norm", "normalize_waveform"):
+        assert getattr(q, f) == getattr(p, f), (name, f)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs /root/reference (build container only)")
+def test_config_json_is_the_references_table():
+    import json
+    import sys
+    sys.path.insert(0, "/root/reference")
+    try:
+        from diarizen.models.module.wavlm_config import get_config
+        tables = json.load(open(os.path.join(GOLD, "wavlm_configs.json")))
+        for name, kw in tables.items():
+            assert json.loads(json.dumps(get_config(name))) == kw, name
+    finally:
+        sys.path.remove("/root/reference")
+
+
+def test_oracle_wav_reader_equals_product_loader():
+    from diarizen_amd.audio import first_channel_16k
+    from oracle.wav import first_channel_pcm16
+    p = os.path.join(GOLD, "EN2002a_30s.wav")
+    assert np.array_equal(first_channel_pcm16(p), first_channel_16k(p))
+
+
+def test_oracle_does_not_import_the_product():
+    """dependency direction: oracle/ is test infrastructure and reads nothing from diarizen_amd/ (nor the other way round)"""
+    import re
+    root = os.path.dirname(os.path.dirname(__file__))
+    for d, forbidden in (("oracle", r"^\s*(from|import)\s+diarizen_amd"), ("diarizen_amd", r"^\s*(from|import)\s+(oracle|testkit)"),
+                         ("testkit", r"^\s*(from|import)\s+(oracle|diarizen_amd)")):
+        for fn in os.listdir(os.path.join(root, d)):
+            if fn.endswith(".py"):
+                src = open(os.path.join(root, d, fn)).read()
+                assert not re.search(forbidden, src, flags=re.M), (d, fn)

@@ -3,7 +3,7 @@ vs the oracle's execution of the reference device stage on CPU (tests/golden/e2e
 per-window hard decisions after the median filter + per-(window, speaker) embeddings) and the golden
 RTTM tests/golden/e2e_EN2002a_30s.rttm, which was produced INDEPENDENTLY of the product's host stage: the
 reference's own clustering module + oracle/host_stage.py (the reference's loops restated loop for loop).
-Weights: the seeded TURN-TAKING weights (diarizen_amd/weights.py) — no hub weights exist offline, and plain
+Weights: the seeded TURN-TAKING weights (testkit/weights.py) — no hub weights exist offline, and plain
 random weights emit one class for every frame; with these the fixture has 11 powerset classes (7 of them
 >= 5 % of the frames), >= 8 transitions in every window, 31 % overlapped frames, both mask branches of
 get_embeddings (89 clean / 25 fallback) and 3 speakers in the RTTM (asserted in tests/test_host.py).
@@ -25,7 +25,7 @@ WAV = os.path.join(GOLD, "EN2002a_30s.wav")
 def pipeline(built_lib, gpu, request):
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.pipeline import DiariZenPipeline
-    from diarizen_amd.weights import emb_state_dict, turn_taking_state_dict
+    from testkit.weights import emb_state_dict, turn_taking_state_dict
     from oracle.gen_golden import E2E_CONFIG
     import copy
     cfg = get_seg_config("wavlm_large_s80_md")
@@ -99,7 +99,7 @@ def test_from_pretrained_local_hub_dir_vbx(built_lib, gpu, tmp_path):
     import torch as T
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.pipeline import DiariZenPipeline
-    from diarizen_amd.weights import emb_state_dict, turn_taking_state_dict
+    from testkit.weights import emb_state_dict, turn_taking_state_dict
     hub = tmp_path / "hub"
     (hub / "plda").mkdir(parents=True)
     (hub / "wespeaker").mkdir()
@@ -159,7 +159,7 @@ def test_der_between_arithmetic_modes(built_lib, gpu):
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.der import der_rttm
     from diarizen_amd.pipeline import DiariZenPipeline
-    from diarizen_amd.weights import emb_state_dict, turn_taking_state_dict
+    from testkit.weights import emb_state_dict, turn_taking_state_dict
     from oracle.gen_golden import E2E_CONFIG
     cfg = get_seg_config("wavlm_large_s80_md")
     rttm = {}

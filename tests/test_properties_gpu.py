@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def engine(built_lib, gpu, request):
     from diarizen_amd.configs import RESNET34, get_seg_config
     from diarizen_amd.engine import Engine
-    from diarizen_amd.weights import emb_state_dict, seg_state_dict
+    from testkit.weights import emb_state_dict, seg_state_dict
     cfg = get_seg_config("wavlm_large_s80_md")
     return Engine(cfg, seg_state_dict(cfg, 0), RESNET34, emb_state_dict(0), max_batch=48,
                   max_samples=128000, precision=request.param, device=gpu)
@@ -62,7 +62,7 @@ def test_outputs_are_well_formed_at_full_size(engine, gpu):
     assert torch.isfinite(logp).all()
     assert torch.allclose(logp.exp().sum(-1), torch.ones_like(logp[..., 0]), atol=1e-4)
     assert ml.sum(-1).max().item() <= 2                     # powerset: at most 2 speakers per frame
-    from diarizen_amd.weights import emb_state_dict
+    from testkit.weights import emb_state_dict
     filt, masks = engine.prepare_masks(ml, 11, True, 2)
     filt2, _ = engine.prepare_masks(filt, 11, True, 2)
     emb = engine.embed(views[:32].contiguous(), masks)
@@ -105,7 +105,7 @@ def test_degenerate_waveforms_match_oracle(engine, gpu):
     """digital silence, a DC offset and a full-scale clipped square wave: finite outputs, strict parity with the
     oracle (the waveform LayerNorm divides by sqrt(var + eps) with var == 0 on the first two)."""
     from diarizen_amd.configs import get_seg_config
-    from diarizen_amd.weights import seg_state_dict
+    from testkit.weights import seg_state_dict
     from oracle import seg_model
     cfg = get_seg_config("wavlm_large_s80_md")
     sd = seg_state_dict(cfg, 0)
@@ -134,7 +134,7 @@ def test_c_abi_without_python(built_lib, gpu, tmp_path):
     from diarizen_amd import build as b
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.engine import make_dzn_config
-    from diarizen_amd.weights import turn_taking_state_dict
+    from testkit.weights import turn_taking_state_dict
     from oracle import seg_model
     from oracle.gen_golden import tt_windows
     exe = b.build_c_harness()

@@ -90,7 +90,7 @@ def test_seg_fp32_matches_reference_golden_turn_taking(built_lib, gpu, name, pre
     geometry for large-s80 (8 s).  Strict bar: max |dlogp| <= 1e-3 AND every argmax / u8 decision identical."""
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.engine import Engine
-    from diarizen_amd.weights import turn_taking_state_dict
+    from testkit.weights import turn_taking_state_dict
     from oracle import seg_model
     from oracle.gen_golden import tt_windows
     cfg = get_seg_config(name)
@@ -218,7 +218,7 @@ def test_conv01_fusion_matches_unfused(built_lib, gpu, monkeypatch):
     lengths exercise the ragged last tile (T1 % 128 != 0) and conv0 frames past the end of the strip."""
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.engine import Engine
-    from diarizen_amd.weights import turn_taking_state_dict
+    from testkit.weights import turn_taking_state_dict
     from oracle import seg_model
     from oracle.gen_golden import tt_windows
     cfg = get_seg_config("wavlm_large_s80_md")
