@@ -379,7 +379,7 @@ template <int NP>
 int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   const char* force = g_force_cfg();                    // tuning knob: force one tile shape
   if (force) {
-    if (!strncmp(force, "pp", 2)) return launch_gemm_pp(d, s, NP, force);   // gemm_pp.hip: 8-wavefront ping-pong tiles
+    if (!strncmp(force, "pp", 2) || !strncmp(force, "pq", 2)) return launch_gemm_pp(d, s, NP, force);   // gemm_pp.hip: 8-wavefront ping-pong tiles
     // production tiles by name
     if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2, NP, NP <= 2 ? 3 : 2>(d, s);
     if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2, NP, 2>(d, s);

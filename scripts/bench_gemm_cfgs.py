@@ -32,13 +32,14 @@ for spec in sys.argv[2:]:
             except Exception as e:     # a configuration that cannot launch (LDS / registers)
                 print(f"cfg={cfg:12s} {name} M={M} N={N} K={K}: FAILED {e}", flush=True)
                 continue
-            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            it = 8
-            st.record()
-            for _ in range(it):
-                ops.gemm(A, W, C_out=out, R=R, precision=prec, **kw)
-            en.record(); torch.cuda.synchronize()
-            dt = st.elapsed_time(en) / it * 1e-3
+            it, dt = 8, 1e9
+            for rep in range(2):          # best of two batches: the first batch after a configuration switch runs colder
+                st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                st.record()
+                for _ in range(it):
+                    ops.gemm(A, W, C_out=out, R=R, precision=prec, **kw)
+                en.record(); torch.cuda.synchronize()
+                dt = min(dt, st.elapsed_time(en) / it * 1e-3)
             if cfg == "auto":
                 base[name] = out.clone()
                 err = 0.0

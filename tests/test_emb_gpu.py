@@ -130,3 +130,36 @@ def test_embedding_reduced_precision_engines(built_lib, gpu, precision):
     cos = torch.nn.functional.cosine_similarity(emb.cpu().reshape(-1, 256), ref.reshape(-1, 256), dim=-1)
     assert cos.min().item() > 0.999
     assert torch.equal(emb.cpu()[0, 2], emb_model.emb_state_dict(0)["resnet.seg_1.bias"])
+
+
+def test_fbank_linear_mel_error_on_real_audio_vs_float64(built_lib, gpu):
+    """How close is the device fbank (fp32 MFMA direct DFT + mel contraction) to the kaldi restatement evaluated in FLOAT64,
+    on real speech (tests/golden/EN2002a_30s.wav, 4 windows of 8 s)?  Reported in log-mel units (what the ResNet sees,
+    after the mean subtraction) and as linear mel energy relative to the frame's largest bin (VERDICT r2 #1d).  The
+    float32 restatement itself sits at 4e-5 / 1.1e-5 (tests/test_oracle.py::test_fbank_cross_check_transformers)."""
+    import json
+    from oracle import emb_model
+    from oracle.gen_golden import tt_windows
+    B, N = 4, 128000
+    wave = tt_windows([0, 90000, 200000, 352000], N)
+    eng = _engine(gpu, B, N, precision="f32h", taps=True)
+    masks = torch.ones(B, 4, 399)
+    eng.embed(wave.to(gpu), masks.to(gpu))
+    torch.cuda.synchronize()
+    torch.set_default_dtype(torch.float64)
+    try:
+        raw64 = torch.stack([emb_model.kaldi_fbank(w.double() * (1 << 15)) for w in wave])       # log-mel before CMN
+    finally:
+        torch.set_default_dtype(torch.float32)
+    ref64 = (raw64 - raw64.mean(dim=1, keepdim=True)).numpy()
+    fb = eng.debug_fetch("fbank").reshape(ref64.shape).astype(np.float64)
+    d = fb - ref64
+    e = np.exp(raw64.numpy())
+    weight = e / e.max(axis=2, keepdims=True)
+    lin = np.abs(np.expm1(d)) * weight
+    out = {"log_mel_max_abs": float(np.abs(d).max()), "log_mel_rms": float(np.sqrt((d ** 2).mean())),
+           "linear_mel_rel_to_frame_max": float(lin.max()), "frames": int(ref64.shape[1]) * B}
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open("gpurun_out/fbank_vs_float64.json", "w"), indent=1)
+    print(out)
+    assert out["log_mel_max_abs"] < 2e-3 and out["linear_mel_rel_to_frame_max"] < 1e-4, out
