@@ -413,6 +413,12 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     }
 #endif
   }
+  if constexpr (NP == 2) {
+    // trial (DZN_GEMM_PQ=1): the streamed ping-pong form with 256 x 192 tiles for the big plain contractions
+    static const bool pq = getenv("DZN_GEMM_PQ") != nullptr;
+    if (pq && d.nz <= 1 && d.M >= 16384 && d.K >= 640 && (d.N % 192 == 0 || d.N == 1024) && !d.a_rowoff)
+      return launch_gemm_pp(d, s, NP, "pq192r3");
+  }
   // launch bounds pin the occupancy the tile was tuned at (r3: the pipelined epilogue gives the register allocator
   // room to trade occupancy for more loads in flight; 128x64 tiles want 3 workgroups per CU, 128x128 two)
   constexpr int OCC64 = NP <= 2 ? 3 : 2;

@@ -83,9 +83,15 @@ class WindowRunner:
         hook: the progress callback of `Inference.slide` (PA/core/inference.py:308-340), called as
         hook(completed=<windows done>, total=<windows>) before the first and after every batch; a hook makes the
         call wait for each batch (otherwise "completed" would only mean "enqueued")."""
-        eng = self.engine
         views = self.windows_view(wave)
         c0, c1 = window_range if window_range is not None else (0, views.shape[0])
+        return self.run_views(views, c0, c1, with_embeddings=with_embeddings, hook=hook)
+
+    def run_views(self, views: torch.Tensor, c0: int, c1: int, with_embeddings: bool = True, hook=None) -> SlideResult:
+        """the batch loop of run() over rows c0 .. c1 of a [C, window] (strided) view of device samples — the streaming
+        session hands in a view of its pre-zeroed device ring, so nothing is re-concatenated as audio arrives"""
+        eng = self.engine
+        wave = views
         C = max(c1 - c0, 0)
         S = eng.seg.max_speakers_per_chunk
         seg = torch.empty((C, self.num_frames, S), device=wave.device, dtype=torch.uint8)

@@ -216,6 +216,14 @@ class DiariZenPipeline:
                               sample_rate=self.segmentation_model.sample_rate, sess_name=sess_name,
                               device=self.device if self.device_postprocess else None, hook=hook)
 
+    # ------------------------------------------------------------------ online use
+    def stream(self, chunks, sess_name: Optional[str] = None, **kw):
+        """windows scheduled as the audio arrives (pinned ring + copy stream): yields (seconds received, provisional
+        Annotation) at every refresh and finally (total seconds, final Annotation == __call__ on the whole file).
+        See streaming.StreamingSession for the push form (feed / finish)."""
+        from .streaming import stream as _stream
+        return _stream(self, chunks, sess_name, **kw)
+
     # ------------------------------------------------------------------ __call__
     def __call__(self, in_wav, sess_name: Optional[str] = None, hook=None) -> Annotation:
         """`hook` (optional, not in the reference's DiariZenPipeline signature but in the pyannote pipeline it

@@ -241,3 +241,47 @@ def test_conv01_fusion_matches_unfused(built_lib, gpu, monkeypatch):
             assert (lf.cpu() - ref).abs().max().item() <= 1e-3
         fused.close()
         plain.close()
+
+
+def test_conv0_layernorm_statistics_survive_band_pass_taps_on_low_frequency_audio(built_lib, gpu, monkeypatch):
+    """conv0's LayerNorm statistics come from the frame's 10 input samples (mean = wbar . x, var = x^T Q x with
+    Q = cov_c(w_c)).  With TRAINED-looking taps — every channel a zero-DC band-pass filter — and low-frequency / quiet audio
+    the frame lies near Q's small-eigenvalue directions; a plain sum of products cancels there.  The kernels evaluate
+    |F x|^2 with Q = F^T F factored in double at load time (engine.cpp): compare with the two-pass statistics over the C0
+    outputs themselves (DZN_CONV0_WAVE_STATS=1) and with the oracle."""
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from oracle import seg_model
+    cfg = get_seg_config("tiny_ln")
+    sd = dict(seg_model.seg_state_dict(cfg, 3))
+    key = "wavlm_model.feature_extractor.conv_layers.0.conv.weight"
+    C0, k = sd[key].shape[0], sd[key].shape[-1]
+    g = torch.Generator().manual_seed(5)
+    t = torch.arange(k, dtype=torch.float32)
+    taps = []
+    for c in range(C0):      # windowed sinusoids between 1.5 and 7 kHz, DC removed exactly
+        f = 1500.0 + 5500.0 * torch.rand(1, generator=g).item()
+        w = torch.hann_window(k + 2, periodic=False)[1:-1] * torch.cos(2 * np.pi * f / 16000.0 * t + 6.28 * torch.rand(1, generator=g).item())
+        taps.append(w - w.mean())
+    sd[key] = (torch.stack(taps) * 0.5).reshape(sd[key].shape).contiguous()
+    N = 16000
+    n = torch.arange(N) / 16000.0
+    wave = torch.stack([0.5 * torch.sin(2 * np.pi * 60.0 * n) + 1e-4 * torch.randn(N, generator=g),      # loud hum, faint noise
+                        1e-3 * torch.sin(2 * np.pi * 35.0 * n + 1.0) + 1e-6 * torch.randn(N, generator=g),   # quiet, low frequency
+                        0.2 * torch.sin(2 * np.pi * 110.0 * n) * (n > 0.5)])                                   # half silence
+    ref = seg_model.seg_forward(sd, cfg, wave)
+    outs = {}
+    for mode in ("quadratic", "two_pass"):
+        if mode == "two_pass":
+            monkeypatch.setenv("DZN_CONV0_WAVE_STATS", "1")
+        eng = Engine(cfg, sd, max_batch=3, max_samples=N, precision="f32", device=gpu)
+        monkeypatch.delenv("DZN_CONV0_WAVE_STATS", raising=False)
+        logp, ml = eng.segment(wave.to(gpu))
+        torch.cuda.synchronize()
+        outs[mode] = logp.cpu()
+        eng.close()
+    dq = (outs["quadratic"] - ref).abs().max().item()
+    dt = (outs["two_pass"] - ref).abs().max().item()
+    print(f"max |dlogp| vs oracle: factored quadratic form {dq:.2e}, two-pass {dt:.2e}")
+    assert dq <= 1e-3 and dt <= 1e-3
+    assert dq <= 3.0 * dt + 1e-5
