@@ -45,6 +45,7 @@ DTYPE_NOTE = {"f32": "f32 (fp32 MFMA v_mfma_f32_16x16x4_f32)",
                      "power-of-two scaling); attention, the fused conv frontend and the 32-channel 3x3 convs keep 2 terms; "
                      "data, norms, softmax, residual stream fp32"}
 PEAK_HBM_GBS = 8000.0
+ALT_STEPS = 5          # timed steps of every comparison leg (other fp32 modes, reduced precision)
 
 
 from testkit.synth import synth_recording  # noqa: E402
@@ -128,20 +129,23 @@ def batches_note(n_windows: int, batch: int) -> str:
 
 
 def run_mode(cfg, sd, esd, wave, args, window, precision, full, dev):
-    """one untimed + one timed step of the same workload in another arithmetic mode (reported beside the headline)"""
+    """one untimed + ALT_STEPS timed steps of the same workload in another arithmetic mode (reported beside the headline)"""
     from diarizen_amd.configs import RESNET34
     from diarizen_amd.engine import Engine
     from diarizen_amd.inference import WindowRunner
     eng = Engine(cfg, sd, RESNET34, esd, max_batch=args.batch, max_samples=window, precision=precision, device=dev)
     r = WindowRunner(eng, args.window, 0.1, args.batch)
-    dt = 0.0
-    for _ in range(2):
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
+
+    def one():
         res = r.run(wave, with_embeddings=full)
         _ = (res.segmentations.cpu(), res.embeddings.cpu()) if full else res.segmentations.cpu()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
+    one()                                   # warm-up (allocations, tables)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(ALT_STEPS):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / ALT_STEPS
     eng.close()
     return dt
 
@@ -186,6 +190,73 @@ def e2e_leg(args, dev, wave_host):
                     "turn-taking weights"}
 
 
+class SynthSource:
+    """lazy recording for DiariZenPipeline.device_stage: a rank synthesises only the samples it asks for"""
+
+    def __init__(self, num_samples: int, seed: int = 3407):
+        self.num_samples, self.seed = num_samples, seed
+
+    def read(self, start: int, n: int):
+        from testkit.synth import synth_recording_range
+        n = max(0, min(n, self.num_samples - start))
+        return synth_recording_range(start, n, total=self.num_samples, seed=self.seed).numpy()
+
+
+def strong_leg(args, dev, rank, world, minutes):
+    """BASELINE configs[3]: ONE recording of `minutes` whose windows are sharded over the ranks, END TO END — each rank
+    reads + uploads only its slice, runs segmentation + embeddings on its windows, one RCCL all-gather per tensor, then
+    rank 0 runs the host stage (counting, AHC, assignment, reconstruction, RTTM).  The serial part (gather + host) is
+    reported next to the sharded part so that Amdahl's bound on the end-to-end speed-up is visible in the line."""
+    import copy
+    import torch.distributed as dist
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.pipeline import DiariZenPipeline
+    from testkit.weights import emb_state_dict, turn_taking_state_dict
+    cfg = get_seg_config(args.model)
+    conf = {"model": {"path": "diarizen.models.eend.model_wavlm_conformer.Model",
+                      "args": {"wavlm_src": args.model, "wavlm_layer_num": cfg.wavlm_layer_num,
+                               "wavlm_feat_dim": cfg.embed_dim, "chunk_size": int(args.window)}},
+            "inference": {"args": {"seg_duration": args.window, "segmentation_step": 0.1, "batch_size": args.batch,
+                                   "apply_median_filtering": True}},
+            "clustering": {"args": {"method": "AgglomerativeClustering", "min_speakers": 1, "max_speakers": 20,
+                                    "ahc_criterion": "distance", "ahc_threshold": 0.1, "min_cluster_size": 13}}}
+    pipe = DiariZenPipeline(None, None, config=copy.deepcopy(conf), device=dev, precision=args.precision,
+                            seg_state=turn_taking_state_dict(cfg, 0), emb_state=emb_state_dict(0))
+    src = SynthSource(int(minutes * 60 * 16000))
+    best = None
+    for _ in range(2):                       # first pass warms allocations / tables / RCCL channels
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        seg, emb = pipe.device_stage(src)    # slice read + upload + device stage + all-gather (+ D2H)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        ann = pipe.host_stage(seg, emb, "bench") if rank == 0 else None
+        t2 = time.perf_counter()
+        best = (t1 - t0, t2 - t1, ann)
+    dev_s, host_s, ann = best
+    if world > 1:
+        tt = torch.tensor([dev_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dev_s = tt.item()
+    if rank != 0:
+        return None
+    audio_s = src.num_samples / 16000.0
+    return {"workload": f"{args.model} full pipeline, ONE {minutes:g} min synthetic recording, {seg.shape[0]} windows sharded over "
+                        f"{world} rank(s) (contiguous blocks), all-gather, host stage on rank 0",
+            "scaling": "strong", "n_gpus": world, "audio_s": audio_s,
+            "sharded_s": round(dev_s, 3), "serial_host_s": round(host_s, 3),
+            "e2e_audio_seconds_per_s": round(audio_s / (dev_s + host_s), 1),
+            "device_only_audio_seconds_per_s": round(audio_s / dev_s, 1),
+            "amdahl_serial_frac": round(host_s / (dev_s + host_s), 4),
+            "speakers": len(ann.labels()), "rttm_lines": len(ann.to_rttm().splitlines()),
+            "note": "sharded_s = max over ranks of [slice synthesis + upload + segmentation + embeddings + RCCL all-gather + D2H]; "
+                    "serial_host_s = rank 0's counting + AHC + assignment + reconstruction + RTTM; seeded turn-taking weights"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +283,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra steps in the other fp32 modes")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (device + host AHC) leg")
+    ap.add_argument("--strong-minutes", type=float, default=None,
+                    help="length of the ONE recording of the strong-scaling end-to-end leg (BASELINE configs[3]: 240); "
+                         "default: 240 when --gpus > 1, off at 1 GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -315,6 +389,14 @@ def main():
     torch.cuda.synchronize()
     unprofiled_ms = (time.perf_counter() - t1) * 1e3
 
+    strong_min = args.strong_minutes if args.strong_minutes is not None else (240.0 if world > 1 else 0.0)
+    strong_res = None
+    if strong_min > 0 and full and not args.no_e2e and world > 1:     # collective: every rank takes part
+        del eng, runner, wave
+        torch.cuda.empty_cache()
+        strong_res = strong_leg(args, dev, rank, world, strong_min)
+        eng = None
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         total_audio = audio_s if strong else world * audio_s
@@ -416,21 +498,27 @@ def main():
                     continue
                 dt2 = run_mode(cfg, sd, esd, wave, args, window, prec, full, dev)
                 alt[prec] = {"value": round(audio_s / dt2, 2), "unit": "audio-seconds/s",
-                             "ms_per_step": round(dt2 * 1e3, 2), "steps": 1, "dtype": DTYPE_NOTE[prec]}
+                             "ms_per_step": round(dt2 * 1e3, 2), "steps": ALT_STEPS, "dtype": DTYPE_NOTE[prec]}
             out["other_fp32_modes"] = alt
             out["fp32_mfma_mode"] = alt["f32"]
             # REDUCED precision (BASELINE configs[4] "fp16"): reported beside the headline, never as `value`
             dt2 = run_mode(cfg, sd, esd, wave, args, window, "f16", full, dev)
             out["reduced_precision_mode"] = {"f16": {"value": round(audio_s / dt2, 2), "unit": "audio-seconds/s",
-                                                     "ms_per_step": round(dt2 * 1e3, 2), "steps": 1,
+                                                     "ms_per_step": round(dt2 * 1e3, 2), "steps": ALT_STEPS,
                                                      "dtype": DTYPE_NOTE["f16"],
                                                      "parity": "reduced-precision bar (tests/test_seg_gpu.py::"
                                                                "test_seg_f16_within_tolerance: max |dlogp| <= 5e-2, "
                                                                "argmax >= 99.5 %; embeddings cos >= 0.999)"}}
         if world == 1 and full and not args.no_e2e and args.minutes <= 60:
-            del eng
+            eng = None
             torch.cuda.empty_cache()
             out["e2e"] = e2e_leg(args, dev, wave_host)
+        if strong_min > 0 and full and not args.no_e2e and world == 1:     # one GPU: the same leg as the N > 1 runs, for the curve
+            eng = None
+            torch.cuda.empty_cache()
+            strong_res = strong_leg(args, dev, rank, world, strong_min)
+        if strong_res is not None:
+            out["strong_scaling_e2e"] = strong_res
         if not args.no_cpu_baseline and world == 1 and full:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, esd, window, 0.1 * args.window)
         print(json.dumps(out))

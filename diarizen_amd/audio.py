@@ -85,6 +85,79 @@ def load_wav(src: Union[str, bytes, BinaryIO, io.BytesIO]) -> Tuple[np.ndarray, 
     return x.reshape(-1, nch).T.copy(), sr
 
 
+class WavSource:
+    """Lazy reader of ONE channel of a RIFF/WAVE file: parses the header, then decodes only the byte range a caller
+    asks for — with N ranks sharding one recording (pipeline.device_stage) every rank reads 1/N of the file (+ one
+    window of halo) instead of decoding all of it.  Same formats and the same float conversion as
+    load_wav(); `needs_resampling` sources fall back to the full decode (the polyphase resampler needs context)."""
+
+    def __init__(self, path, channel: int = 0):
+        self.path = str(path)
+        with open(self.path, "rb") as f:
+            head = f.read(12)
+            if head[:4] not in (b"RIFF", b"RF64") or head[8:12] != b"WAVE":
+                raise ValueError("not a RIFF/WAVE file")
+            fmt = None
+            while True:
+                ck = f.read(8)
+                if len(ck) < 8:
+                    raise ValueError("malformed WAVE file")
+                cid, size = ck[:4], int.from_bytes(ck[4:8], "little")
+                if cid == b"fmt ":
+                    fmt = f.read(size)
+                    if size & 1:
+                        f.seek(1, 1)
+                elif cid == b"data":
+                    self._data_off = f.tell()
+                    f.seek(0, 2)
+                    avail = f.tell() - self._data_off
+                    self._data_len = avail if size in (0, 0xFFFFFFFF) else min(size, avail)
+                    break
+                else:
+                    f.seek(size + (size & 1), 1)
+        if fmt is None or len(fmt) < 16:
+            raise ValueError("malformed WAVE file")
+        tag = int.from_bytes(fmt[0:2], "little")
+        self.channels = int.from_bytes(fmt[2:4], "little")
+        self.sample_rate = int.from_bytes(fmt[4:8], "little")
+        block = int.from_bytes(fmt[12:14], "little")
+        bits = int.from_bytes(fmt[14:16], "little")
+        if tag == 0xFFFE:
+            if len(fmt) < 40 or fmt[26:40] != _PCM_GUID_TAIL:
+                raise ValueError("unsupported WAVE_FORMAT_EXTENSIBLE sub-format")
+            tag = int.from_bytes(fmt[24:26], "little")
+        if self.channels < 1 or self.sample_rate < 1 or channel >= self.channels:
+            raise ValueError("malformed WAVE fmt chunk")
+        self._width = block // self.channels if block else (bits + 7) // 8
+        self._tag, self._channel = tag, channel
+        if (tag, self._width) not in ((1, 1), (1, 2), (1, 3), (1, 4), (3, 4), (3, 8)):
+            raise ValueError(f"unsupported WAVE format tag {tag} ({bits} bit)")
+        self._frame = self._width * self.channels
+        self.num_samples = self._data_len // self._frame
+
+    def read(self, start: int, n: int) -> np.ndarray:
+        """float32 [m] = samples start .. start + n of the channel (m < n at the end of the file)"""
+        start = max(0, min(int(start), self.num_samples))
+        n = max(0, min(int(n), self.num_samples - start))
+        with open(self.path, "rb") as f:
+            f.seek(self._data_off + start * self._frame)
+            body = f.read(n * self._frame)
+        w, c, nch = self._width, self._channel, self.channels
+        if self._tag == 1:
+            if w == 1:
+                return (np.frombuffer(body, dtype=np.uint8).reshape(-1, nch)[:, c].astype(np.float32) - 128.0) / 128.0
+            if w == 2:
+                return np.frombuffer(body, dtype="<i2").reshape(-1, nch)[:, c].astype(np.float32) / 32768.0
+            if w == 3:
+                b3 = np.frombuffer(body, dtype=np.uint8).reshape(-1, nch, 3)[:, c].astype(np.int32)
+                v = b3[:, 0] | (b3[:, 1] << 8) | (b3[:, 2] << 16)
+                v = np.where(v & 0x800000, v - 0x1000000, v)
+                return v.astype(np.float32) / 8388608.0
+            return np.frombuffer(body, dtype="<i4").reshape(-1, nch)[:, c].astype(np.float32) / 2147483648.0
+        dt = "<f4" if w == 4 else "<f8"
+        return np.ascontiguousarray(np.frombuffer(body, dtype=dt).reshape(-1, nch)[:, c].astype(np.float32))
+
+
 def resample(x: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
              rolloff: float = 0.99) -> np.ndarray:
     """float32 [..., T] -> [..., ceil(T * new / orig)]: band-limited sinc interpolation with a Hann

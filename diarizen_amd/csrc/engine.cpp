@@ -666,7 +666,7 @@ void finalize_seg(H* h) {
   if (n < 1) throw EngineError(DZN_E_INVALID, "max_samples too short");
   const int64_t ML = B * n;
   h->stats = dalloc<float>(h, B * 2);
-  if (!c.extractor_layer_norm) h->gn_stats = dalloc<float>(h, B * h->C[0] * 2);
+  if (!c.extractor_layer_norm) h->gn_stats = dalloc<float>(h, gn_stats_floats((int)B, h->maxT[0], h->C[0], h->Cp[0]));
   h->bufA = dalloc<float>(h, maxbuf);
   {
     // bufB holds every odd conv output (and the feature-projection LN output)

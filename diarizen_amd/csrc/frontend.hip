@@ -11,6 +11,8 @@
 // conv is a plain contraction over overlapping rows.  A workgroup stages a run of normalised
 // samples in LDS (coalesced), every lane keeps its channels' 10 taps in registers, a wavefront
 // produces one frame per iteration and stores 256 contiguous bytes per channel group.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -127,57 +129,113 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
   }
 }
 
-// per (b, channel) mean / rstd over the T rows of x [B, T, ld]  (GroupNorm(C, C) statistics)
-__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, int T, int C,
-                                                        int64_t ld, float eps,
-                                                        float* __restrict__ stats /* [B, C, 2] */) {
-  // block = 64 channels x 4 row-phases
-  __shared__ float red[4][64];
-  const int b = blockIdx.y;
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int ph = threadIdx.x >> 6;
-  const float* xp = x + (int64_t)b * T * ld;
-  float s = 0.f;
-  if (c < C)
-    for (int t = ph; t < T; t += 4) s += xp[(int64_t)t * ld + c];
-  red[ph][threadIdx.x & 63] = s;
-  __syncthreads();
-  const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] +
-                      red[3][threadIdx.x & 63]) / (float)T;
-  __syncthreads();
-  float q = 0.f;
-  if (c < C)
-    for (int t = ph; t < T; t += 4) {
-      const float d = xp[(int64_t)t * ld + c] - mean;
-      q += d * d;
+// ---- GroupNorm(C, C) = per (window, channel) normalisation over TIME (components.py:1248-1253) ----
+// r2's statistics kernel ran (C / 64) x B workgroups, each walking all T rows twice with one 4-byte load per thread and
+// row: 64 workgroups on 256 CUs, 2.6 ms for 390 MB at BASELINE configs[1] (0.15 TB/s, 29 % of that step).  Now:
+//   gn_partial_kernel : grid (T / GN_ROWS, B); a workgroup owns GN_ROWS consecutive rows of one window, threads own a
+//                       channel QUAD (float4 loads, coalesced along the channel axis) and a row phase; pass 1 = chunk mean,
+//                       pass 2 = centred sum of squares over the same rows (second read comes from L2) -> (mean, M2) per
+//                       (window, chunk, channel): the two-pass arithmetic of the reference inside a chunk;
+//   gn_finalize_kernel: one thread per (window, channel) merges the chunks in order with Chan's update (deterministic)
+//                       -> (mean, rstd);
+//   gn_gelu_kernel    : the element pass, float4 wide.
+constexpr int GN_ROWS = 128;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int T, int C, int Cp, int64_t ld,
+                                                         float* __restrict__ part /* [B, nchunk, Cp, 2] */) {
+  __shared__ float4 red[256];
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int Q = Cp >> 2;                        // channel quads (Cp % 4 == 0, Q <= 256)
+  const int nph = 256 / Q;                      // row phases
+  const int q = threadIdx.x % Q, ph = threadIdx.x / Q;
+  const bool on = ph < nph;
+  const int r0 = chunk * GN_ROWS, r1 = min(T, r0 + GN_ROWS), n = r1 - r0;
+  const float* xp = x + ((int64_t)b * T + r0) * ld + 4 * q;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on)
+    for (int t = ph; t < n; t += nph) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ld);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-  red[ph][threadIdx.x & 63] = q;
+  red[threadIdx.x] = s;
   __syncthreads();
-  if (ph == 0 && c < C) {
-    const float var = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
-                       red[3][threadIdx.x]) / (float)T;
-    stats[((int64_t)b * C + c) * 2] = mean;
-    stats[((int64_t)b * C + c) * 2 + 1] = 1.0f / sqrtf(var + eps);
+  float4 mean = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < nph; ++p) {               // fixed order: deterministic
+    const float4 v = red[p * Q + q];
+    mean.x += v.x; mean.y += v.y; mean.z += v.z; mean.w += v.w;
+  }
+  const float inv = 1.0f / (float)n;
+  mean.x *= inv; mean.y *= inv; mean.z *= inv; mean.w *= inv;
+  __syncthreads();
+  float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on)
+    for (int t = ph; t < n; t += nph) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ld);
+      const float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
+      m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
+    }
+  red[threadIdx.x] = m2;
+  __syncthreads();
+  if (ph == 0) {
+    float4 t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < nph; ++p) {
+      const float4 v = red[p * Q + q];
+      t2.x += v.x; t2.y += v.y; t2.z += v.z; t2.w += v.w;
+    }
+    float* o = part + (((int64_t)b * nchunk + chunk) * Cp + 4 * q) * 2;
+    o[0] = mean.x; o[1] = t2.x; o[2] = mean.y; o[3] = t2.y; o[4] = mean.z; o[5] = t2.z; o[6] = mean.w; o[7] = t2.w;
   }
 }
 
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int B, int T, int C, int Cp, int nchunk,
+                                                          float eps, float* __restrict__ stats /* [B, C, 2] */) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  float mean = 0.f, m2 = 0.f, cnt = 0.f;
+  for (int k = 0; k < nchunk; ++k) {            // Chan et al.: merge (cnt, mean, M2) with the chunk's (n, mu, m)
+    const float* p = part + (((int64_t)b * nchunk + k) * Cp + c) * 2;
+    const float n = (float)min(GN_ROWS, T - k * GN_ROWS);
+    const float delta = p[0] - mean, tot = cnt + n;
+    mean += delta * (n / tot);
+    m2 += p[1] + delta * delta * (cnt * n / tot);
+    cnt = tot;
+  }
+  stats[2 * (int64_t)i] = mean;
+  stats[2 * (int64_t)i + 1] = 1.0f / sqrtf(m2 / (float)T + eps);
+}
+
 // y[b,t,c] = gelu((x - mean[b,c]) * rstd[b,c] * gamma[c] + beta[c]); y may alias x when TO = float;
-// columns [C, Cp) of y are zeroed
+// columns [C, Cp) of y are zeroed.  One float4 of channels per thread and step (Cp % 4 == 0, ld % 4 == 0).
 template <typename TO>
 __global__ __launch_bounds__(256) void gn_gelu_kernel(const float* x, TO* y, int T, int C, int Cp,
                                                       int64_t ld, const float* __restrict__ stats,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta) {
   const int b = blockIdx.y;
-  const int64_t n = (int64_t)T * Cp;
+  const int Q = Cp >> 2;
+  const int64_t n = (int64_t)T * Q;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int t = (int)(i / Cp), c = (int)(i - (int64_t)t * Cp);
-    const int64_t off = ((int64_t)b * T + t) * ld + c;
-    if (c < C) {
-      const float mu = stats[((int64_t)b * C + c) * 2], rs = stats[((int64_t)b * C + c) * 2 + 1];
-      st_act(y, off, gelu_erf((x[off] - mu) * rs * gamma[c] + beta[c]));
+    const int t = (int)(i / Q), c0 = 4 * (int)(i - (int64_t)t * Q);
+    const int64_t off = ((int64_t)b * T + t) * ld + c0;
+    const float4 v = *reinterpret_cast<const float4*>(x + off);
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      if (c < C) {
+        const float mu = stats[((int64_t)b * C + c) * 2], rs = stats[((int64_t)b * C + c) * 2 + 1];
+        o[e] = gelu_erf((in[e] - mu) * rs * gamma[c] + beta[c]);
+      } else {
+        o[e] = 0.f;
+      }
+    }
+    if constexpr (std::is_same<TO, float>::value) {
+      *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
-      st_act(y, off, 0.f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st_act(y, off + e, o[e]);
     }
   }
 }
@@ -276,15 +334,26 @@ int launch_conv0(const float* wave, int B, int N, const float* stats, const floa
 
 int launch_groupnorm_gelu(const float* x, void* y, int y_bf16, int B, int T, int C, int Cp, int64_t ld,
                           const float* gamma, const float* beta, float eps, float* stats, hipStream_t st) {
-  ProfScope prof_scope_(st, "groupnorm_gelu");
-  hipLaunchKernelGGL(col_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, T, C, ld, eps, stats);
+  // algorithmic bytes: x read once for the statistics, once for the element pass, y written once
+  ProfScope prof_scope_(st, "groupnorm_gelu", 0.0, (double)B * T * C * (y_bf16 ? 10.0 : 12.0));
+  if ((Cp & 3) || (ld & 3) || Cp > 1024) return DZN_E_INVALID;
+  const int nchunk = (T + GN_ROWS - 1) / GN_ROWS;
+  // scratch for the chunk partials: behind the [B, C, 2] statistics (the engine sizes `stats` for it: gn_stats_floats())
+  float* part = stats + (int64_t)B * C * 2;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, T, C, Cp, ld, part);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, T, C, Cp, nchunk, eps, stats);
   if (y_bf16)
-    hipLaunchKernelGGL(gn_gelu_kernel<u16>, dim3(grid_for((int64_t)T * Cp), B), dim3(256), 0, st, x,
+    hipLaunchKernelGGL(gn_gelu_kernel<u16>, dim3(grid_for((int64_t)T * (Cp / 4)), B), dim3(256), 0, st, x,
                        static_cast<u16*>(y), T, C, Cp, ld, stats, gamma, beta);
   else
-    hipLaunchKernelGGL(gn_gelu_kernel<float>, dim3(grid_for((int64_t)T * Cp), B), dim3(256), 0, st, x,
+    hipLaunchKernelGGL(gn_gelu_kernel<float>, dim3(grid_for((int64_t)T * (Cp / 4)), B), dim3(256), 0, st, x,
                        static_cast<float*>(y), T, C, Cp, ld, stats, gamma, beta);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+// floats the `stats` argument of launch_groupnorm_gelu must hold: [B, C, 2] statistics + [B, nchunk, Cp, 2] partials
+int64_t gn_stats_floats(int B, int T, int C, int Cp) {
+  return (int64_t)B * C * 2 + (int64_t)B * ((T + GN_ROWS - 1) / GN_ROWS) * Cp * 2;
 }
 
 int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int Lp, int pad, int D,

@@ -413,12 +413,6 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     }
 #endif
   }
-  if constexpr (NP == 2) {
-    // trial (DZN_GEMM_PQ=1): the streamed ping-pong form with 256 x 192 tiles for the big plain contractions
-    static const bool pq = getenv("DZN_GEMM_PQ") != nullptr;
-    if (pq && d.nz <= 1 && d.M >= 16384 && d.K >= 640 && (d.N % 192 == 0 || d.N == 1024) && !d.a_rowoff)
-      return launch_gemm_pp(d, s, NP, "pq192r3");
-  }
   // launch bounds pin the occupancy the tile was tuned at (r3: the pipelined epilogue gives the register allocator
   // room to trade occupancy for more loads in flight; 128x64 tiles want 3 workgroups per CU, 128x128 two)
   constexpr int OCC64 = NP <= 2 ? 3 : 2;
@@ -429,6 +423,10 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   // 128-wide column tiles unless 64-wide ones save more than ~1/8 of the (padded) columns; widths that
   // are multiples of 80 but not of 64 (conv1 of the extractor: 153 -> 160) get exact 80-wide tiles
   const int cols128 = (d.N + 127) / 128 * 128, cols64 = (d.N + 63) / 64 * 64;
+  // small launches (BASELINE configs[1]: 32 windows of 5 s = 7968 rows): 128 x 128 tiles would leave most of the 512
+  // workgroup slots (256 CUs x 2) empty — halve the tile so that twice as many workgroups exist
+  if ((int64_t)((d.M + 127) / 128) * (cols128 / 128) * (d.nz > 0 ? d.nz : 1) < 448)
+    return launch_split_cfg<128, 64, 4, 1, 2, NP, OCC64>(d, s);
   if (d.N % 80 == 0 && d.N < cols64 && d.N * 9 < cols128 * 8) return launch_split_cfg<128, 80, 4, 1, 2, NP, 2>(d, s);
   if (cols64 * 9 < cols128 * 8) return launch_split_cfg<128, 64, 4, 1, 2, NP, OCC64>(d, s);
   // NP = 2: 4 x 1 wavefronts (32 x 128 each): every A row is split by ONE wavefront instead of two; measured +3 %

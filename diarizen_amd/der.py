@@ -30,12 +30,49 @@ def parse_rttm(text: str, uri: str = None) -> List[Turn]:
     return turns
 
 
-def der(ref: List[Turn], hyp: List[Turn]) -> Dict[str, float]:
-    bounds = sorted({t for s, e, _ in ref + hyp for t in (s, e)})
+def parse_uem(text: str) -> Dict[str, List[Tuple[float, float]]]:
+    """NIST UEM: `<uri> <channel> <start> <end>` per line -> {uri: [(start, end), ...]} (the scored regions)"""
+    out: Dict[str, List[Tuple[float, float]]] = defaultdict(list)
+    for line in text.splitlines():
+        f = line.split()
+        if len(f) >= 4 and not f[0].startswith(";"):
+            out[f[0]].append((float(f[2]), float(f[3])))
+    return dict(out)
+
+
+def rttm_uris(text: str) -> List[str]:
+    seen = []
+    for line in text.splitlines():
+        f = line.split()
+        if len(f) >= 8 and f[0] == "SPEAKER" and f[1] not in seen:
+            seen.append(f[1])
+    return seen
+
+
+def der(ref: List[Turn], hyp: List[Turn], uem: List[Tuple[float, float]] = None, collar: float = 0.0) -> Dict[str, float]:
+    """md-eval / dscore semantics (`score.py --collar C`, overlaps scored): time outside the UEM regions is not scored
+    (default: everything — dscore then uses the extent of reference and system turns), nor is +-collar around every
+    REFERENCE turn boundary; ONE optimal speaker mapping on the scored time."""
+    bset = {t for s, e, _ in ref + hyp for t in (s, e)}
+    if uem:
+        bset |= {t for s, e in uem for t in (s, e)}
+    if collar > 0:
+        bset |= {t + d for s, e, _ in ref for t in (s, e) for d in (-collar, collar)}
+    bounds = sorted(bset)
     if len(bounds) < 2:
         return {"der": 0.0, "miss": 0.0, "false_alarm": 0.0, "confusion": 0.0, "total": 0.0, "mapping": {}}
     mids = 0.5 * (np.array(bounds[:-1]) + np.array(bounds[1:]))
     durs = np.diff(np.array(bounds))
+    scored = np.ones(len(mids), dtype=bool)
+    if uem:
+        scored[:] = False
+        for s, e in uem:
+            scored |= (mids > s) & (mids < e)
+    if collar > 0:
+        for s, e, _ in ref:
+            for t in (s, e):
+                scored &= ~((mids > t - collar) & (mids < t + collar))
+    durs = durs * scored
 
     def active(turns):
         spk = sorted({s for _, _, s in turns})
@@ -66,5 +103,19 @@ def der(ref: List[Turn], hyp: List[Turn]) -> Dict[str, float]:
     return out
 
 
-def der_rttm(ref_text: str, hyp_text: str, uri: str = None) -> Dict[str, float]:
-    return der(parse_rttm(ref_text, uri), parse_rttm(hyp_text, uri))
+def der_rttm(ref_text: str, hyp_text: str, uri: str = None, uem: List[Tuple[float, float]] = None,
+             collar: float = 0.0) -> Dict[str, float]:
+    return der(parse_rttm(ref_text, uri), parse_rttm(hyp_text, uri), uem=uem, collar=collar)
+
+
+def score_set(ref_text: str, hyp_texts: Dict[str, str], uem_text: str = None, collar: float = 0.0) -> Dict:
+    """A test set the way the recipe scores it (recipes/diar_ssl/run_stage.sh:84-91: dscore `score.py -r <set>/rttm
+    -s <out>/*.rttm --collar 0`): one reference RTTM holding every recording, one system RTTM per recording, optional UEM.
+    -> {"files": {uri: per-file result}, "overall": errors summed over the files / summed reference time}."""
+    uem = parse_uem(uem_text) if uem_text else {}
+    files = {}
+    for uri, hyp in hyp_texts.items():
+        files[uri] = der_rttm(ref_text, hyp, uri=uri, uem=uem.get(uri), collar=collar)
+    tot = {k: sum(f[k] for f in files.values()) for k in ("miss", "false_alarm", "confusion", "total")}
+    tot["der"] = (tot["miss"] + tot["false_alarm"] + tot["confusion"]) / tot["total"] if tot["total"] > 0 else 0.0
+    return {"files": files, "overall": tot, "collar": collar, "missing_in_reference": [u for u in hyp_texts if u not in rttm_uris(ref_text)]}

@@ -46,22 +46,34 @@ def my_window_range(num_windows: int) -> Optional[Tuple[int, int]]:
     return shard_range(num_windows, rank(), g)
 
 
-def gather_windows(seg: torch.Tensor, emb: Optional[torch.Tensor]):
-    """all-gather per-window results of every rank (padded to equal counts), in window order."""
+def gather_windows(seg: torch.Tensor, emb: Optional[torch.Tensor], expected_total: Optional[int] = None):
+    """all-gather per-window results of every rank (padded to equal counts), in window order.
+    expected_total: the number of windows of the whole recording — every one of the world_size ranks must have
+    contributed its block and the blocks must add up (a rank that silently ran alone, e.g. a collective that fell back
+    to a 1-rank group, is an error, not a short result)."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
+        if expected_total is not None and seg.shape[0] != expected_total:
+            raise RuntimeError(f"{seg.shape[0]} windows computed, {expected_total} expected")
         return seg, emb
     g = d.get_world_size()
     if d.get_backend() == "gloo" and seg.is_cuda:
         # gloo has no device all_gather: stage through the host (debug / single-GPU rehearsal of the N > 1 path;
         # production runs use the "nccl" backend = RCCL over xGMI, device to device)
         dev = seg.device
-        s2, e2 = gather_windows(seg.cpu(), emb.cpu() if emb is not None else None)
+        s2, e2 = gather_windows(seg.cpu(), emb.cpu() if emb is not None else None, expected_total)
         return s2.to(dev), (e2.to(dev) if e2 is not None else None)
     n = torch.tensor([seg.shape[0]], device=seg.device, dtype=torch.int64)
     counts = [torch.zeros_like(n) for _ in range(g)]
     d.all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
+    if len(counts) != g or counts[d.get_rank()] != seg.shape[0]:
+        raise RuntimeError(f"all_gather of the window counts returned {counts} on rank {d.get_rank()} of {g}")
+    if expected_total is not None:
+        blocks = [shard_range(expected_total, r, g) for r in range(g)]
+        if counts != [hi - lo for lo, hi in blocks]:
+            raise RuntimeError(f"ranks contributed {counts} windows, the block partition of {expected_total} windows over {g} "
+                               f"ranks is {[hi - lo for lo, hi in blocks]}")
     cap = max(max(counts), 1)
 
     def gather(t: torch.Tensor) -> torch.Tensor:

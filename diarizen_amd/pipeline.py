@@ -181,22 +181,28 @@ class DiariZenPipeline:
         return SlidingWindow(start=0.0, duration=self.seg_duration,
                              step=self.segmentation_step * self.seg_duration)
 
-    def device_stage(self, waveform: np.ndarray, hook=None):
-        """host float32 [N] -> (segmentations u8 [C, L, 4], embeddings f32 [C, 4, 256]) on the host.
-        With torch.distributed initialised, this rank uploads ONLY the samples its contiguous window range touches
+    def device_stage(self, waveform, hook=None):
+        """host float32 [N] (or a lazy source with `.num_samples` and `.read(start, n)`, e.g. audio.WavSource) ->
+        (segmentations u8 [C, L, 4], embeddings f32 [C, 4, 256]) on the host.
+        With torch.distributed initialised, this rank reads / uploads ONLY the samples its contiguous window range touches
         (its slice + one window of halo), runs them, and the per-window results are all-gathered."""
         from . import dist as dz_dist
         r = self._runner
-        C = r.num_windows(len(waveform))
+        lazy = hasattr(waveform, "read") and hasattr(waveform, "num_samples")
+        total = int(waveform.num_samples) if lazy else len(waveform)
+        C = r.num_windows(total)
         rng = dz_dist.my_window_range(C)
-        x = np.ascontiguousarray(waveform, dtype=np.float32)
         if rng is not None:
             c0, c1 = rng
             lo, n = c0 * r.step, ((c1 - c0 - 1) * r.step + r.window if c1 > c0 else 0)
-            sl = np.zeros(n, dtype=np.float32)                     # zero-extended like the last window (inference.py:293-299)
-            have = x[lo:lo + n]
-            sl[:len(have)] = have
-            x = sl
+        else:
+            lo, n = 0, total
+        have = waveform.read(lo, n) if lazy else np.asarray(waveform[lo:lo + n], dtype=np.float32)
+        if rng is not None:
+            x = np.zeros(n, dtype=np.float32)                      # zero-extended like the last window (inference.py:293-299)
+            x[:len(have)] = have
+        else:
+            x = np.ascontiguousarray(have, dtype=np.float32)
         if len(x):
             wave = torch.from_numpy(x).to(self.device)
             res = r.run(wave, with_embeddings=True, hook=hook)
@@ -205,7 +211,7 @@ class DiariZenPipeline:
             S = self.engine.seg.max_speakers_per_chunk
             seg_l = torch.empty((0, r.num_frames, S), device=self.device, dtype=torch.uint8)
             emb_l = torch.empty((0, S, self.engine.emb.embed_dim), device=self.device, dtype=torch.float32)
-        seg, emb = dz_dist.gather_windows(seg_l, emb_l)
+        seg, emb = dz_dist.gather_windows(seg_l, emb_l, expected_total=C)
         torch.cuda.synchronize(self.device)
         return seg.cpu().numpy(), emb.cpu().numpy()
 
@@ -242,7 +248,20 @@ class DiariZenPipeline:
         assert isinstance(in_wav, (str, os.PathLike, BytesIO, bytes)), \
             f"input must be either a str, BytesIO or a ProtocolFile; there was {type(in_wav)}"
         t0 = time.perf_counter()
-        waveform = audio_io.first_channel_16k(in_wav, self.segmentation_model.sample_rate)
+        from . import dist as dz_dist
+        waveform = None
+        if dz_dist.world_size() > 1 and isinstance(in_wav, (str, os.PathLike)):
+            # sharded run: every rank decodes only the byte range of its windows (files at the model's rate; others need
+            # the resampler's context and are decoded whole)
+            try:
+                src = audio_io.WavSource(in_wav)
+                if src.sample_rate == self.segmentation_model.sample_rate:
+                    waveform = src
+            except ValueError:
+                waveform = None
+        if waveform is None:
+            waveform = audio_io.first_channel_16k(in_wav, self.segmentation_model.sample_rate)
+        num_samples = int(waveform.num_samples) if hasattr(waveform, "num_samples") else len(waveform)
         t1 = time.perf_counter()
         seg, emb = self.device_stage(
             waveform, hook=functools.partial(hook, "segmentation", None) if hook is not None else None)
@@ -251,7 +270,6 @@ class DiariZenPipeline:
             hook("segmentation", SlidingWindowFeature(seg, self.chunks_window()))
             hook("embeddings", emb)
         t2 = time.perf_counter()
-        from . import dist as dz_dist
         result = None
         if dz_dist.rank() == 0:
             result = self.host_stage(seg, emb, sess_name, hook=hook)
@@ -261,5 +279,5 @@ class DiariZenPipeline:
                     f.write(result.to_rttm())
         t3 = time.perf_counter()
         self.timings = {"load_s": t1 - t0, "device_s": t2 - t1, "host_s": t3 - t2,
-                        "audio_s": len(waveform) / self.segmentation_model.sample_rate}
+                        "audio_s": num_samples / self.segmentation_model.sample_rate}
         return result

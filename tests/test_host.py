@@ -245,8 +245,16 @@ def _worker(rank, world, port, C, out_dir):
     # every rank "computes" its own windows: value = global window index
     seg = (torch.arange(lo, hi).view(-1, 1, 1) % 251).to(torch.uint8).expand(hi - lo, 5, 4).contiguous()
     emb = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(hi - lo, 4, 8).contiguous()
-    gs, ge = dz.gather_windows(seg, emb)
-    torch.save((gs, ge), os.path.join(out_dir, f"r{rank}.pt"))
+    gs, ge = dz.gather_windows(seg, emb, expected_total=C)
+    # a rank that contributes a block of the wrong size must be noticed by EVERY rank ("assert that
+    # world_size ranks contributed to the gather")
+    try:
+        dz.gather_windows(seg[: max(hi - lo - 1, 0)] if rank == 0 else seg, emb[: max(hi - lo - 1, 0)] if rank == 0 else emb,
+                          expected_total=C)
+        raised = False
+    except RuntimeError:
+        raised = True
+    torch.save((gs, ge, raised), os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -262,7 +270,8 @@ def test_window_sharding_and_gather_gloo_world2(C, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, C, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
-        gs, ge = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        gs, ge, raised = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        assert raised                                           # the short block of rank 0 was refused on both ranks
         assert gs.shape == (C, 5, 4) and ge.shape == (C, 4, 8)
         assert torch.equal(ge[:, 0, 0], torch.arange(C, dtype=torch.float32))   # window order kept
         assert torch.equal(gs[:, 0, 0].long(), torch.arange(C) % 251)
@@ -700,6 +709,46 @@ def test_wav_loader_24bit_extensible_float64(tmp_path):
         load_wav(riff(struct.pack("<HHIIHH", 2, 1, 8000, 8000, 1, 4), b"\x00" * 16))   # ADPCM: refused loudly
 
 
+def test_wav_source_reads_ranges_like_the_full_decoder(tmp_path):
+    """audio.WavSource (each rank of a sharded run decodes only its byte range) against load_wav() on every format
+    load_wav reads: 16-bit stereo, 24-bit, WAVE_FORMAT_EXTENSIBLE, float64, 8-bit; ranges at the start, inside, across the
+    end and past it."""
+    import struct
+    import wave
+    from diarizen_amd.audio import WavSource, load_wav
+    g = np.random.default_rng(3)
+    x = np.clip(g.normal(size=(2, 5000)) * 0.3, -0.99, 0.99)
+
+    def riff(fmt, body, extra=b""):
+        chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt + extra + b"data" + struct.pack("<I", len(body)) + body
+        return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+    q24 = np.round(x.T * 8388607).astype(np.int32)
+    b24 = b"".join(int(v).to_bytes(3, "little", signed=True) for v in q24.reshape(-1))
+    guid = struct.pack("<H", 1) + bytes.fromhex("000000001000800000aa00389b71")
+    files = {
+        "pcm16": riff(struct.pack("<HHIIHH", 1, 2, 16000, 64000, 4, 16), np.round(x.T * 32767).astype("<i2").tobytes(),
+                      extra=b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\x00"),            # an odd-sized chunk before data
+        "pcm24": riff(struct.pack("<HHIIHH", 1, 2, 44100, 44100 * 6, 6, 24), b24),
+        "ext24": riff(struct.pack("<HHIIHH", 0xFFFE, 2, 16000, 96000, 6, 24) + struct.pack("<HHI", 22, 24, 3) + guid, b24),
+        "f64": riff(struct.pack("<HHIIHH", 3, 2, 8000, 128000, 16, 64), x.T.astype("<f8").tobytes()),
+        "u8": riff(struct.pack("<HHIIHH", 1, 2, 8000, 16000, 2, 8), np.round(x.T * 127 + 128).astype(np.uint8).tobytes()),
+    }
+    for name, blob in files.items():
+        p = tmp_path / f"{name}.wav"
+        p.write_bytes(blob)
+        full, sr = load_wav(str(p))
+        for ch in (0, 1):
+            src = WavSource(p, channel=ch)
+            assert src.sample_rate == sr and src.num_samples == full.shape[1] and src.channels == 2
+            for start, n in ((0, 5000), (0, 17), (1234, 2000), (4990, 100), (5000, 10), (7000, 5)):
+                got = src.read(start, n)
+                assert np.array_equal(got, full[ch, start:start + n]), (name, ch, start, n)
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.wav").write_bytes(b"RIFFxxxxWAVEjunk")
+        WavSource(tmp_path / "bad.wav")
+
+
 # ---------------------------------------------------------------- clustering branches the plain fixtures do not reach
 _FORCED = np.load(os.path.join(GOLD, "host_clustering_forced.npz"))
 
@@ -723,3 +772,28 @@ def test_ahc_forced_branches_equal_reference(name):
     hard, soft, cent = ahc(embeddings=emb.copy(), segmentations=seg, **kw)
     assert np.array_equal(hard, _FORCED[f"{name}_hard"])
     assert np.allclose(cent, _FORCED[f"{name}_centroids"], atol=1e-6)
+
+
+def test_der_uem_collar_and_set_scoring():
+    """md-eval / dscore semantics of diarizen_amd/der.py beyond the plain case: UEM-restricted scoring, +-collar around the
+    reference boundaries, and the recipe's set-level aggregation (errors summed over recordings / summed reference time)."""
+    from diarizen_amd.der import der, parse_uem, score_set
+    ref = [(0.0, 10.0, "A"), (10.0, 20.0, "B")]
+    hyp = [(0.0, 12.0, "x"), (12.0, 20.0, "y"), (25.0, 30.0, "y")]          # 2 s of confusion, 5 s of false alarm
+    r = der(ref, hyp)
+    assert abs(r["confusion"] - 2.0) < 1e-9 and abs(r["false_alarm"] - 5.0) < 1e-9 and abs(r["der"] - 7.0 / 20.0) < 1e-9
+    r = der(ref, hyp, uem=[(0.0, 20.0)])                                     # the false alarm lies outside the UEM
+    assert r["false_alarm"] == 0.0 and abs(r["der"] - 2.0 / 20.0) < 1e-9
+    r = der(ref, hyp, uem=[(0.0, 20.0)], collar=0.25)                        # boundaries at 0, 10, 10, 20: 0.25 s each side
+    assert abs(r["total"] - (20.0 - 0.25 - 0.5 - 0.25)) < 1e-9 and abs(r["confusion"] - 1.75) < 1e-9
+    r = der(ref, hyp, uem=[(0.0, 20.0)], collar=2.0)                         # the whole confusion hides in the collar
+    assert r["confusion"] == 0.0 and r["der"] == 0.0
+    assert parse_uem("EN2002a 1 0.000 2142.709375\n;; comment\nEN2002b 1 0.0 10.5\n") == {"EN2002a": [(0.0, 2142.709375)],
+                                                                                            "EN2002b": [(0.0, 10.5)]}
+    ref_text = ("SPEAKER f1 1 0.0 10.0 <NA> <NA> A <NA> <NA>\nSPEAKER f1 1 10.0 10.0 <NA> <NA> B <NA> <NA>\n"
+                "SPEAKER f2 1 0.0 5.0 <NA> <NA> C <NA> <NA>\n")
+    hyp = {"f1": "SPEAKER f1 1 0.0 12.0 <NA> <NA> 0 <NA> <NA>\nSPEAKER f1 1 12.0 8.0 <NA> <NA> 1 <NA> <NA>\n",
+           "f2": "SPEAKER f2 1 1.0 4.0 <NA> <NA> 0 <NA> <NA>\n"}
+    s = score_set(ref_text, hyp, "f1 1 0 20\nf2 1 0 5\n")
+    assert abs(s["files"]["f1"]["der"] - 0.1) < 1e-9 and abs(s["files"]["f2"]["der"] - 0.2) < 1e-9
+    assert abs(s["overall"]["der"] - 3.0 / 25.0) < 1e-9 and s["missing_in_reference"] == []

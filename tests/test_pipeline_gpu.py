@@ -183,3 +183,41 @@ def test_der_between_arithmetic_modes(built_lib, gpu):
         with open("gpurun_out/der_reduced_modes.json", "w") as f:
             json.dump({"reference": "fp32-mode RTTM (== golden)", "bf16": {k: v for k, v in d.items() if k != "mapping"},
                        "f16": {k: v for k, v in d16.items() if k != "mapping"}}, f, indent=1)
+
+
+def test_streaming_session_equals_offline(pipeline, tmp_path):
+    """Row f3: windows scheduled as the audio arrives (pinned ring + copy stream, diarizen_amd/streaming.py).  Feeding the
+    fixture in ragged chunks (0.01 s ... 2.9 s, one longer than a ring slot) gives the SAME decisions, embeddings and final
+    RTTM as the offline call; provisional annotations appear while audio is still arriving and never run ahead of it."""
+    from diarizen_amd.audio import first_channel_16k
+    from diarizen_amd.streaming import StreamingSession, complete_windows
+    wave = first_channel_16k(WAV)
+    ref = open(os.path.join(GOLD, "e2e_EN2002a_30s.rttm")).read()
+    rng = np.random.default_rng(5)
+    cuts = [0]
+    while cuts[-1] < len(wave):
+        cuts.append(min(len(wave), cuts[-1] + int(rng.choice([160, 5000, 16000, 46400, 30001]))))
+    chunks = [wave[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    provisional = []
+    final = None
+    for t, ann in pipeline.stream(chunks, sess_name="EN2002a", refresh_s=4.0, slot_seconds=2.5, slots=3):
+        provisional.append((t, ann))
+        final = ann
+    assert provisional[-1][0] == 30.0 and final.to_rttm() == ref
+    assert len(provisional) >= 4                                            # refreshes before the end
+    for t, ann in provisional[:-1]:
+        assert t < 30.0
+        turns = [seg for seg, _ in ann.itertracks()]
+        assert turns and max(s.end for s in turns) <= t + 1e-6              # nothing beyond the audio received
+    # push form, and the per-window results themselves
+    g = np.load(os.path.join(GOLD, "e2e_EN2002a_30s.npz"))
+    sess = StreamingSession(pipeline, "EN2002a", refresh_s=None, max_seconds=60.0)
+    for c in chunks:
+        assert sess.feed(c) is None
+        assert sess.done == complete_windows(sess.n, 128000, 12800)
+    assert sess.done == 28                                                  # the zero-padded 29th window waits for finish()
+    assert sess.finish().to_rttm() == ref
+    assert np.array_equal(np.concatenate(sess.seg), g["seg"])
+    assert sess.stats["uploads"] >= len(chunks)
+    with pytest.raises(RuntimeError):
+        sess.feed(chunks[0])
