@@ -45,6 +45,8 @@ DTYPE_NOTE = {"f32": "f32 (fp32 MFMA v_mfma_f32_16x16x4_f32)",
                      "power-of-two scaling); attention, the fused conv frontend and the 32-channel 3x3 convs keep 2 terms; "
                      "data, norms, softmax, residual stream fp32"}
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_SOURCE = ("committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x 2 "
+                  "correction; scripts/final_measure.sh -> profiles/) — not measured in this run")
 ALT_STEPS = 5          # timed steps of every comparison leg (other fp32 modes, reduced precision)
 
 
@@ -425,6 +427,7 @@ def main():
                             "peak": round(PEAK_TFLOPS[prec], 1), "unit": "TFLOP/s",
                             "frac": round(ach / PEAK_TFLOPS[prec], 4),
                             "traffic": pmc_lookup(traffic, top["name"], "hbm_bytes_per_launch"),
+                            "traffic_source": TRAFFIC_SOURCE if traffic else None,
                             "launches": top["launches"],
                             "avg_launch_ms": round(top["ms"] / top["launches"], 4),
                             "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 3),

@@ -367,7 +367,8 @@ int launch_attention_t(const float* qkv, void* out, int out_bf16, const float* g
   dim3 grid((L + 63) / 64, h, B);
   // algorithmic flops: QK^T and PV, 2*L*L*64 each per (batch, head)
   const int pid = prof_begin(s, bias ? "attention_relpos_f32" : "attention_f32",
-                             4.0 * B * h * (double)L * L * 64.0, 0.0);
+                             4.0 * B * h * (double)L * L * 64.0,
+                             (double)B * L * h * 64.0 * 4.0 * 4.0 + (gate ? (double)B * L * Htot * 4.0 : 0.0));
 #define DZN_ATT(BIASV, T)                                                                          \
   hipLaunchKernelGGL((attn_kernel<BIASV, T>), grid, dim3(256), lds, s, qkv, static_cast<T*>(out), gate, \
                      table, head_idx, B, L, h, Htot, ldqkv, ldo, scale)
@@ -391,7 +392,7 @@ int launch_attention(const float* qkv, float* out, const float* gate, const floa
 
 int launch_gate_t(const void* y, int y_bf16, int64_t ldy, const float* Wg, const float* bg,
                   const float* cst, float* gate, int64_t rows, int Htot, hipStream_t s) {
-  ProfScope prof_scope_(s, "gate");
+  ProfScope prof_scope_(s, "gate", 0.0, (double)rows * Htot * (64.0 + 1.0) * 4.0);
   if (rows <= 0) return DZN_OK;
   if (y_bf16)
     hipLaunchKernelGGL(gate_kernel<u16>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s,

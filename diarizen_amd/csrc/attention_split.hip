@@ -285,7 +285,8 @@ int launch_attention_split(const float* qkv, float* out, const float* gate, cons
   }
   dim3 grid((L + 63) / 64, h, B);
   const int pid = prof_begin(s, bias ? (amax ? "attention_relpos_f32h" : "attention_relpos_f32s") : (amax ? "attention_f32h" : "attention_f32s"),
-                             4.0 * B * h * (double)L * L * 64.0, 0.0);
+                             4.0 * B * h * (double)L * L * 64.0,
+                             (double)B * L * h * 64.0 * 4.0 * 4.0 + (gate ? (double)B * L * Htot * 4.0 : 0.0));   // q, k, v in + out, once
 #define DZN_ATT(BV, NPV)                                                                                            \
   hipLaunchKernelGGL((attn_split_kernel<BV, NPV>), grid, dim3(256), lds, s, qkv, out, gate, table, head_idx, B, L, h, \
                      Htot, ldqkv, ldo, scale, amax)

@@ -160,7 +160,7 @@ int launch_conv0(const float* wave, int B, int N, const float* stats, const floa
                  const float* gamma, const float* beta, int C0, int Cp, int k, int s, int T0,
                  int layer_norm, float eps, void* out, int out_bf16, hipStream_t st, const float* lnq = nullptr);
 int launch_groupnorm_gelu(const float* x, void* y, int y_bf16, int B, int T, int C, int Cp, int64_t ld,
-                          const float* gamma, const float* beta, float eps, float* stats, hipStream_t st);
+                          const float* gamma, const float* beta, float eps, float* stats, hipStream_t st, float* amax = nullptr);
 int64_t gn_stats_floats(int B, int T, int C, int Cp);   // size of launch_groupnorm_gelu's `stats` (statistics + chunk partials)
 int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int Lp, int pad, int D,
                     hipStream_t st);

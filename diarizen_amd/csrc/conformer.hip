@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const float* __restrict__
 
 int launch_glu_dwconv(const float* u, int64_t ldu, const float* w, const float* bias, void* out,
                       int out_bf16, int64_t ldo, int B, int L, int A, int ks, hipStream_t st) {
-  ProfScope prof_scope_(st, "glu_dwconv");
+  ProfScope prof_scope_(st, "glu_dwconv", 0.0, (double)B * L * A * (8.0 + (out_bf16 ? 2.0 : 4.0)));   // 2 A in, A out
   dim3 grid((L + DW_TT - 1) / DW_TT, B);
   const int threads = A >= 256 ? 256 : (A >= 128 ? 128 : 64);
 #define DZN_DW(KSV)                                                                                   \
@@ -124,7 +124,7 @@ int launch_glu_dwconv(const float* u, int64_t ldu, const float* w, const float* 
 int launch_classify(const float* z, int64_t ldz, const float* W, const float* bias,
                     const uint8_t* mapping, int64_t rows, int A, int NC, int S, float* logp,
                     uint8_t* multilabel, hipStream_t st) {
-  ProfScope prof_scope_(st, "classify");
+  ProfScope prof_scope_(st, "classify", 2.0 * (double)rows * A * NC, (double)rows * (A * 4.0 + NC * 4.0 + S));
   if (NC > 16 || S > 64) return DZN_E_INVALID;
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, st, z, ldz, W,
                      bias, mapping, rows, A, NC, S, logp, multilabel);

@@ -224,7 +224,8 @@ int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias,
   }
   ConvArgs a{in, static_cast<const u16*>(h2 ? W2h : W3), bias, R, out, B, Hs, Ws, relu, post_relu, amax, amax_in, col_scale};
   const int grid = 512;   // persistent: 2 workgroups per CU; XCD-major work distribution inside the kernel
-  const int pid = prof_begin(s, h2 ? "conv3x3_c32_f32h" : "conv3x3_c32_f32s", 2.0 * B * Hs * (double)Ws * 32.0 * 288.0, 0.0);
+  const int pid = prof_begin(s, h2 ? "conv3x3_c32_f32h" : "conv3x3_c32_f32s", 2.0 * B * Hs * (double)Ws * 32.0 * 288.0,
+                             (double)B * Hs * Ws * 32.0 * 4.0 * (R ? 3.0 : 2.0));   // image in + out (+ residual), once
   if (h2) hipLaunchKernelGGL(conv3x3_c32_split_kernel<2>, dim3(grid), dim3(256), lds, s, a);
   else hipLaunchKernelGGL(conv3x3_c32_split_kernel<3>, dim3(grid), dim3(256), lds, s, a);
   prof_end(pid, s);

@@ -195,7 +195,7 @@ inline unsigned grid_for(int64_t n, int per = 256, int cap = 8192) {
 
 int launch_frame_prep(const float* wave, int B, int N, int T, int flen, int fshift, int Kp,
                       const float* window, float preemph, float* frames, hipStream_t st) {
-  ProfScope prof_scope_(st, "frame_prep");
+  ProfScope prof_scope_(st, "frame_prep", 0.0, (double)B * N * 4.0 + (double)B * T * Kp * 4.0);
   if (flen > 512 || T <= 0) return DZN_E_INVALID;
   hipLaunchKernelGGL(frame_prep_kernel, dim3((T + 3) / 4, B), dim3(256), 0, st, wave, N, T, flen,
                      fshift, Kp, window, preemph, frames);
@@ -203,20 +203,21 @@ int launch_frame_prep(const float* wave, int B, int N, int T, int flen, int fshi
 }
 
 int launch_power(const float* spec, int64_t rows, int nb, float* pw, hipStream_t st) {
-  ProfScope prof_scope_(st, "power");
+  ProfScope prof_scope_(st, "power", 0.0, (double)rows * nb * 12.0);
   hipLaunchKernelGGL(power_kernel, dim3(grid_for(rows * nb)), dim3(256), 0, st, spec, rows, nb, pw);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
 int launch_log_cmn(float* mel, int B, int T, int NB, float eps, hipStream_t st) {
-  ProfScope prof_scope_(st, "log_cmn");
+  ProfScope prof_scope_(st, "log_cmn", 0.0, (double)B * T * NB * 12.0);   // read for the mean, read + write
   hipLaunchKernelGGL(log_cmn_kernel, dim3((NB + 15) / 16, B), dim3(256), 0, st, mel, T, NB, eps);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
 int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* w, const float* bias,
                      void* img, int out_bf16, hipStream_t st, float* amax) {
-  ProfScope prof_scope_(st, "stem_conv");
+  ProfScope prof_scope_(st, "stem_conv", 2.0 * B * NB * (double)T * C * 9.0,
+                        (double)B * NB * T * 4.0 + (double)B * NB * T * C * (out_bf16 ? 2.0 : 4.0));   // fbank in, C-channel image out
   const dim3 grid(grid_for((int64_t)B * NB * T * (C / 4)));
   if (out_bf16)
     hipLaunchKernelGGL(stem_conv_kernel<u16>, grid, dim3(256), 0, st, fb, B, T, NB, C, w, bias,
@@ -229,7 +230,7 @@ int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* 
 
 int launch_stats_pool(const void* img, int in_bf16, int B, int H, int W, int C, const float* masks, int S,
                       int L, float* stats, hipStream_t st) {
-  ProfScope prof_scope_(st, "stats_pool");
+  ProfScope prof_scope_(st, "stats_pool", 0.0, (double)B * H * W * C * (in_bf16 ? 2.0 : 4.0) + (double)B * S * L * 4.0);
   const size_t lds = (size_t)S * W * sizeof(float);
   if (in_bf16)
     hipLaunchKernelGGL(stats_pool_kernel<u16>, dim3(H, B), dim3(256), lds, st, static_cast<const u16*>(img),

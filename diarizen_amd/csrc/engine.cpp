@@ -1032,7 +1032,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
                      c.conv_s[0], T[0], 0, 1e-5f, raw, 0, st),
         "conv0");
     chk(launch_groupnorm_gelu(raw, h->bufA, lp, B, T[0], h->C[0], h->Cp[0], h->Cp[0], h->conv_ln[0].g,
-                              h->conv_ln[0].b, 1e-5f, h->gn_stats, st),
+                              h->conv_ln[0].b, 1e-5f, h->gn_stats, st, am(conv_slot(h->bufA))),
         "groupnorm");
   }
   tap(h, "conv0", h->bufA, (int64_t)B * T[0], h->C[0], h->Cp[0], st, lp);
@@ -1047,7 +1047,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     d.a_z0 = (int64_t)T[i - 1] * h->Cp[i - 1];
     d.c_z0 = (int64_t)T[i] * h->Cp[i];
     if (!lnx) d.act = DZN_ACT_GELU;
-    if (i > 1 || lnx) d.a_amax = am(conv_slot(cur));   // (group-norm conv0 has neither tracker nor bound: bf16 split)
+    d.a_amax = am(conv_slot(cur));   // (r3: the group-norm element pass tracks its |max| too, so conv1 takes the fp16 split)
     if (!lnx) d.c_amax = am(conv_slot(nxt));
     if (i == 1 && fuse01)
       chk(launch_conv01_fused(wave, B, N, stats, h->conv0_w, h->conv_ln[0].g, h->conv_ln[0].b, h->conv0_lnq, h->C[0],

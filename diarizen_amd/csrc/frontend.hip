@@ -211,10 +211,11 @@ template <typename TO>
 __global__ __launch_bounds__(256) void gn_gelu_kernel(const float* x, TO* y, int T, int C, int Cp,
                                                       int64_t ld, const float* __restrict__ stats,
                                                       const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta) {
+                                                      const float* __restrict__ beta, float* __restrict__ amax /* [B] or null */) {
   const int b = blockIdx.y;
   const int Q = Cp >> 2;
   const int64_t n = (int64_t)T * Q;
+  float mx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int t = (int)(i / Q), c0 = 4 * (int)(i - (int64_t)t * Q);
     const int64_t off = ((int64_t)b * T + t) * ld + c0;
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void gn_gelu_kernel(const float* x, TO* y, int
       if (c < C) {
         const float mu = stats[((int64_t)b * C + c) * 2], rs = stats[((int64_t)b * C + c) * 2 + 1];
         o[e] = gelu_erf((in[e] - mu) * rs * gamma[c] + beta[c]);
+        mx = fmaxf(mx, fabsf(o[e]));
       } else {
         o[e] = 0.f;
       }
@@ -238,6 +240,8 @@ __global__ __launch_bounds__(256) void gn_gelu_kernel(const float* x, TO* y, int
       for (int e = 0; e < 4; ++e) st_act(y, off + e, o[e]);
     }
   }
+  // per-window |max| of the output: the scale of conv1's fp16 two-term split (DZN_PREC_F32_H2)
+  if (amax) track_amax(amax + b, mx);
 }
 
 // xpad[b, t + pad, :] = x[b, t, :], zero borders (input of the positional conv)
@@ -333,7 +337,7 @@ int launch_conv0(const float* wave, int B, int N, const float* stats, const floa
 }
 
 int launch_groupnorm_gelu(const float* x, void* y, int y_bf16, int B, int T, int C, int Cp, int64_t ld,
-                          const float* gamma, const float* beta, float eps, float* stats, hipStream_t st) {
+                          const float* gamma, const float* beta, float eps, float* stats, hipStream_t st, float* amax) {
   // algorithmic bytes: x read once for the statistics, once for the element pass, y written once
   ProfScope prof_scope_(st, "groupnorm_gelu", 0.0, (double)B * T * C * (y_bf16 ? 10.0 : 12.0));
   if ((Cp & 3) || (ld & 3) || Cp > 1024) return DZN_E_INVALID;
@@ -344,10 +348,10 @@ int launch_groupnorm_gelu(const float* x, void* y, int y_bf16, int B, int T, int
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, T, C, Cp, nchunk, eps, stats);
   if (y_bf16)
     hipLaunchKernelGGL(gn_gelu_kernel<u16>, dim3(grid_for((int64_t)T * (Cp / 4)), B), dim3(256), 0, st, x,
-                       static_cast<u16*>(y), T, C, Cp, ld, stats, gamma, beta);
+                       static_cast<u16*>(y), T, C, Cp, ld, stats, gamma, beta, amax);
   else
     hipLaunchKernelGGL(gn_gelu_kernel<float>, dim3(grid_for((int64_t)T * (Cp / 4)), B), dim3(256), 0, st, x,
-                       static_cast<float*>(y), T, C, Cp, ld, stats, gamma, beta);
+                       static_cast<float*>(y), T, C, Cp, ld, stats, gamma, beta, amax);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
@@ -358,7 +362,7 @@ int64_t gn_stats_floats(int B, int T, int C, int Cp) {
 
 int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int Lp, int pad, int D,
                     hipStream_t st) {
-  ProfScope prof_scope_(st, "pad_rows");
+  ProfScope prof_scope_(st, "pad_rows", 0.0, (double)B * (L + Lp) * D * 4.0);
   if (out_bf16)
     hipLaunchKernelGGL(pad_rows_kernel<u16>, dim3(grid_for((int64_t)Lp * (D / 4)), B), dim3(256), 0, st,
                        x, static_cast<u16*>(xpad), L, Lp, pad, D / 4);
@@ -369,14 +373,14 @@ int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int 
 }
 
 int launch_ws_accum(const float* x, float* ws, float w, int init, int64_t n, hipStream_t st) {
-  ProfScope prof_scope_(st, "ws_accum");
+  ProfScope prof_scope_(st, "ws_accum", 0.0, (double)n * (init ? 8.0 : 12.0));
   hipLaunchKernelGGL(ws_accum_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, ws, w, init, n / 4);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
 int launch_col_scale(void* x, int x_bf16, int64_t rows, int C, int64_t ld, const float* scale,
                      hipStream_t st) {
-  ProfScope prof_scope_(st, "col_scale");
+  ProfScope prof_scope_(st, "col_scale", 0.0, (double)rows * C * 8.0);
   if (x_bf16)
     hipLaunchKernelGGL(col_scale_kernel<u16>, dim3(grid_for(rows * C)), dim3(256), 0, st,
                        static_cast<u16*>(x), rows, C, ld, scale);

@@ -375,7 +375,7 @@ int launch_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     else
       snprintf(cls, sizeof(cls), "gemm_%s_%dx%d", LOWP ? "bf16" : "f32", BM, BN);
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
-    pid = prof_begin(s, cls, fl, 0.0);
+    pid = prof_begin(s, cls, fl, gemm_alg_bytes(d, LOWP ? 2 : 4));
   }
   if constexpr (!LOWP) {
     if (use_glds)

@@ -336,7 +336,7 @@ int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s) {
 
 int launch_pad_rows_split2(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
                            const float* amax, float* snapshot, hipStream_t st) {
-  ProfScope prof_scope_(st, "pad_rows_split2");
+  ProfScope prof_scope_(st, "pad_rows_split2", 0.0, (double)B * D * (L * 4.0 + Lp * 4.0));   // fp32 in, two fp16 planes out
   if (D % 32 || !amax || !snapshot) return DZN_E_INVALID;
   int64_t g = cdiv64((int64_t)Lp * (D / 8), 256);
   g = g > 4096 ? 4096 : g;
@@ -350,7 +350,7 @@ extern "C" int dzn_op_split_rows(const float* x, void* planes, int64_t plane_str
 
 int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
                            hipStream_t st) {
-  ProfScope prof_scope_(st, "pad_rows_split3");
+  ProfScope prof_scope_(st, "pad_rows_split3", 0.0, (double)B * D * (L * 4.0 + Lp * 6.0));
   if (D % 32) return DZN_E_INVALID;
   int64_t g = cdiv64((int64_t)Lp * (D / 8), 256);
   g = g > 4096 ? 4096 : g;

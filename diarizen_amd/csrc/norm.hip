@@ -270,7 +270,7 @@ int launch_cast_bf16(const float* x, void* y, int64_t n, hipStream_t s) {
 }
 
 int launch_wave_stats(const float* w, int B, int N, float eps, float* stats, hipStream_t s) {
-  ProfScope prof_scope_(s, "wave_stats");
+  ProfScope prof_scope_(s, "wave_stats", 0.0, (double)B * N * 4.0);
   if (B <= 0) return DZN_OK;
   hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(1024), 0, s, w, N, eps, stats);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;

@@ -157,7 +157,7 @@ extern "C" int dzn_cluster_activations(const uint8_t* d_seg, const int8_t* d_har
 
 int launch_prepare_masks(const uint8_t* ml, int B, int L, int S, int median, int exclude_overlap,
                          int min_num_frames, uint8_t* filtered, float* masks, hipStream_t st) {
-  ProfScope prof_scope_(st, "prepare_masks");
+  ProfScope prof_scope_(st, "prepare_masks", 0.0, (double)B * L * S * (2.0 + 4.0));
   if (B <= 0) return DZN_OK;
   if (S < 1 || S > 8 || L < 1 || (median > 1 && !(median & 1))) return DZN_E_INVALID;
   const size_t lds = 2 * (((size_t)L * S + 3) & ~(size_t)3) + 8 * sizeof(int);
