@@ -121,9 +121,9 @@ int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s); // gemm_split.hip:
 int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s);  // gemm_split_pre.hip: A pre-split planes
 int launch_gemm_pp(const dzn_gemm_desc& d, hipStream_t s, int np, const char* cfg);  // gemm_pp.hip: 8-wavefront ping-pong
 int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
-                           hipStream_t st);
+                           hipStream_t st, int cg = 0, int cgp = 0);   // D = plane row width (groups padded from cg to cgp channels)
 int launch_pad_rows_split2(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
-                           const float* amax, float* snapshot, hipStream_t st);
+                           const float* amax, float* snapshot, hipStream_t st, int cg = 0, int cgp = 0);
 int launch_split_weights(const float* W, int64_t rows, int K, int64_t ldw, void* W3, hipStream_t s);
 int launch_split_weights_h2(const float* W, int64_t rows, int K, int64_t ldw, void* W2, float* col_scale, hipStream_t s);
 int launch_amax(const float* x, int64_t n, float* amax, hipStream_t s);

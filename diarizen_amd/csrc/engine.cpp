@@ -123,6 +123,8 @@ struct dzn_handle {
   float* dummy_w = nullptr;
   LNp fp_ln, enc_ln;
   Lin fp, posconv;
+  int pos_rowD = 0;               // row width the row-offset table of the positional conv was built for
+  int pos_cgp = 0;                // channels per positional-conv group in the pre-split planes (cg rounded up to 32)
   std::vector<EncLayer> layers;
   std::vector<float> rel_embed;  // [num_buckets, H] host
   std::vector<float> wsum_w;
@@ -485,14 +487,20 @@ void finalize_seg(H* h) {
           const double t = v.v[((size_t)o * cg + ii) * K + j];
           nrm[j] += t * t;
         }
-    std::vector<float> wp((size_t)D * K * cg);
+    // split modes: groups whose width is not a multiple of 32 (base: 768 / 16 = 48) are zero-padded to the next one
+    // (64) in the weights AND in the pre-split padded copy of x, so the contraction keeps whole 32-k tiles per tap and
+    // runs on the fp16 / bf16 planes instead of the fp32 MFMA fallback (r2: 15 % of BASELINE configs[1])
+    const int cgp = prec_is_split(c.precision) ? round_up(cg, 32) : cg;
+    h->pos_cgp = cgp;
+    std::vector<float> wp((size_t)D * K * cgp, 0.f);
     for (int o = 0; o < D; ++o)
       for (int ii = 0; ii < cg; ++ii)
         for (int j = 0; j < K; ++j) {
           const float nj = (float)std::sqrt(nrm[j]);
-          wp[((size_t)o * K + j) * cg + ii] = g.v[j] * v.v[((size_t)o * cg + ii) * K + j] / nj;
+          wp[((size_t)o * K + j) * cgp + ii] = g.v[j] * v.v[((size_t)o * cg + ii) * K + j] / nj;
         }
-    h->posconv = make_lin(h, wp, b.v.data(), D, K * cg, D, K * cg);
+    h->posconv = make_lin(h, wp, b.v.data(), D, K * cgp, D, K * cgp);
+    h->posconv.Kt = K * cg;
   }
   if (!c.layer_norm_first) h->enc_ln = ln_from_sd(h, P + "encoder.transformer.layer_norm", D);
   h->layers.resize(c.n_layers);
@@ -681,8 +689,8 @@ void finalize_seg(H* h) {
   }
   h->x = dalloc<float>(h, ML * D);
   h->xpad = dalloc<float>(h, B * (n + c.pos_conv_kernel) * D);
-  if (prec_is_split(c.precision) && (D / c.pos_conv_groups) % 32 == 0) {
-    h->xpad3_plane = B * (n + c.pos_conv_kernel) * D;
+  if (prec_is_split(c.precision)) {
+    h->xpad3_plane = B * (n + c.pos_conv_kernel) * (int64_t)(c.pos_conv_groups * round_up(D / c.pos_conv_groups, 32));
     h->xpad3 = dalloc<u16>(h, 3 * h->xpad3_plane);
   }
   h->y = dalloc<float>(h, ML * D);
@@ -943,13 +951,14 @@ void ln_t(const float* x, bool x16, int64_t ldx, float* y, bool y16, int64_t ldy
 }
 
 // positional conv rows: m = b*L + t reads xpad[b][t .. t+Kc) — one table for all batch sizes
-void ensure_pos_rowoff(H* h, int L, int Lp, hipStream_t st) {
-  if (L == h->pos_L) return;
+void ensure_pos_rowoff(H* h, int L, int Lp, int rowD, hipStream_t st) {
+  if (L == h->pos_L && rowD == h->pos_rowD) return;
+  h->pos_rowD = rowD;
   HIPCHK(hipStreamSynchronize(st));
   const int Bm = h->cfg.max_batch;
   std::vector<int32_t> t((size_t)Bm * L);
   for (int b = 0; b < Bm; ++b)
-    for (int i = 0; i < L; ++i) t[(size_t)b * L + i] = (int32_t)(((int64_t)b * Lp + i) * h->D);
+    for (int i = 0; i < L; ++i) t[(size_t)b * L + i] = (int32_t)(((int64_t)b * Lp + i) * h->pos_rowD);
   if (!h->pos_rowoff) h->pos_rowoff = dalloc<int32_t>(h, (int64_t)Bm * h->maxL, false);
   HIPCHK(hipMemcpy(h->pos_rowoff, t.data(), t.size() * 4, hipMemcpyHostToDevice));
   h->pos_L = L;
@@ -1095,27 +1104,31 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     const bool pc16 = lp && (cg % 32 == 0);
     // f32s: every element of the padded copy feeds 128 taps — split it ONCE here (three bf16 planes) and
     // let the contraction read the planes (gemm_split_pre.hip) instead of re-splitting it per K tile
-    const bool pre3 = h->xpad3 != nullptr && (int64_t)c.max_batch * Lp * D < (int64_t)1 << 31;
+    const int cgp = h->pos_cgp > 0 ? h->pos_cgp : cg, Dp = G * cgp;     // plane rows: G groups of cgp channels
+    const bool pre3 = h->xpad3 != nullptr && (int64_t)c.max_batch * Lp * Dp < (int64_t)1 << 31;
     const bool pre2 = pre3 && h2 && h->posconv.W2h;   // two fp16 planes, scaled by the |max| of x (snapshotted)
     if (pre2)
-      chk(launch_pad_rows_split2(h->x, h->xpad3, h->xpad3_plane, B, L, Lp, Kc / 2, D, am(dzn_handle::AM_X),
-                                 am(dzn_handle::AM_XPAD), st),
+      chk(launch_pad_rows_split2(h->x, h->xpad3, h->xpad3_plane, B, L, Lp, Kc / 2, Dp, am(dzn_handle::AM_X),
+                                 am(dzn_handle::AM_XPAD), st, cg, cgp),
           "pad_rows_split2");
     else if (pre3)
-      chk(launch_pad_rows_split3(h->x, h->xpad3, h->xpad3_plane, B, L, Lp, Kc / 2, D, st), "pad_rows_split3");
+      chk(launch_pad_rows_split3(h->x, h->xpad3, h->xpad3_plane, B, L, Lp, Kc / 2, Dp, st, cg, cgp), "pad_rows_split3");
     else
       chk(launch_pad_rows(h->x, h->xpad, pc16, B, L, Lp, Kc / 2, D, st), "pad_rows");
+    // the un-split copy (fp32 / bf16 modes) keeps cg channels per group; the planes have cgp
+    const int ca = pre3 ? cgp : cg, Da = pre3 ? Dp : D;
+    if (!pre3 && cgp != cg) throw EngineError(DZN_E_INVALID, "padded positional-conv groups need the pre-split planes");
     // one contraction per channel group over ALL B*L rows (row-offset table into the padded copy), so
     // the 128-row tiles are not padded per window (L = 399 would waste 22 % of every window's last tile)
-    const bool tabled = (int64_t)c.max_batch * Lp * D < (int64_t)1 << 31;
-    if (tabled) ensure_pos_rowoff(h, L, Lp, st);
-    dzn_gemm_desc d = gd(h, h->xpad, h->posconv, h->x, tabled ? ML : L, D, D);
+    const bool tabled = (int64_t)c.max_batch * Lp * Da < (int64_t)1 << 31;
+    if (tabled) ensure_pos_rowoff(h, L, Lp, Da, st);
+    dzn_gemm_desc d = gd(h, h->xpad, h->posconv, h->x, tabled ? ML : L, Da, D);
     d.N = cg;
-    d.kc = cg;
-    d.ldk = D;
+    d.kc = ca;
+    d.ldk = Da;
     d.act = DZN_ACT_GELU;
     d.R = h->x;
-    d.a_z1 = cg;
+    d.a_z1 = ca;
     d.w_z1 = (int64_t)cg * h->posconv.K;
     d.c_z1 = cg;
     d.b_z1 = cg;
@@ -1127,7 +1140,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     } else {
       d.nz = B * G;
       d.zdiv = G;
-      d.a_z0 = (int64_t)Lp * D;
+      d.a_z0 = (int64_t)Lp * Da;
       d.c_z0 = (int64_t)L * D;
       d.alg_flops = 2.0 * (double)L * cg * h->posconv.Kt;
     }

@@ -240,8 +240,15 @@ __global__ __launch_bounds__(256) void gn_gelu_kernel(const float* x, TO* y, int
       for (int e = 0; e < 4; ++e) st_act(y, off + e, o[e]);
     }
   }
-  // per-window |max| of the output: the scale of conv1's fp16 two-term split (DZN_PREC_F32_H2)
-  if (amax) track_amax(amax + b, mx);
+  // per-window |max| of the output: the scale of conv1's fp16 two-term split (DZN_PREC_F32_H2).  One atomic per
+  // WORKGROUP (wave maxima through LDS): per-wavefront atomics on 32 addresses cost 0.3 ms at BASELINE configs[1].
+  if (amax) {
+    __shared__ float wmax[4];
+    const float m = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) track_amax_lane(amax + b, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+  }
 }
 
 // xpad[b, t + pad, :] = x[b, t, :], zero borders (input of the positional conv)
@@ -347,10 +354,10 @@ int launch_groupnorm_gelu(const float* x, void* y, int y_bf16, int B, int T, int
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, T, C, Cp, ld, part);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, T, C, Cp, nchunk, eps, stats);
   if (y_bf16)
-    hipLaunchKernelGGL(gn_gelu_kernel<u16>, dim3(grid_for((int64_t)T * (Cp / 4)), B), dim3(256), 0, st, x,
+    hipLaunchKernelGGL(gn_gelu_kernel<u16>, dim3(grid_for((int64_t)T * (Cp / 4), 256, 512), B), dim3(256), 0, st, x,
                        static_cast<u16*>(y), T, C, Cp, ld, stats, gamma, beta, amax);
   else
-    hipLaunchKernelGGL(gn_gelu_kernel<float>, dim3(grid_for((int64_t)T * (Cp / 4)), B), dim3(256), 0, st, x,
+    hipLaunchKernelGGL(gn_gelu_kernel<float>, dim3(grid_for((int64_t)T * (Cp / 4), 256, 512), B), dim3(256), 0, st, x,
                        static_cast<float*>(y), T, C, Cp, ld, stats, gamma, beta, amax);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }

@@ -21,6 +21,8 @@
 //     [MFMA] 2 x 2 wavefronts, 64 x 80 outputs each, 6 k-steps (3 taps x 2 blocks), W fragments straight from L2 into
 //     registers (the slab's W would not fit LDS next to the planes).  Two workgroups per CU (74 KB of LDS each), so one
 //     multiplies while the other computes activations.
+#include <cstdlib>
+
 #include "common.h"
 #include "split.h"
 
@@ -43,6 +45,7 @@ struct FusedArgs {
   float* out;             // [B, T1, N1p] raw conv1 output
   int N, T0, T1, C0, N1p;
   float eps, a_scale, a_inv;   // power-of-two scale of the conv0 activations (from their static bound) and inverse
+  int abl;                     // timing probe only (DZN_CONV01_ABL): 1 = skip the VALU phase, 2 = skip the MFMA phase (wrong results)
 };
 
 __global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a) {
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a)
       const float g0 = a.gamma0[ch], b0 = a.beta0[ch];
       const int cslot = lane >> 3, cbyte = (lane & 7) * 2;
       constexpr int UF = 4;
-      for (int fb = wave; fb < FF_FR; fb += 4 * UF) {
+      for (int fb = wave; fb < (a.abl == 1 ? 0 : FF_FR); fb += 4 * UF) {
         float o[UF];
 #pragma unroll
         for (int u = 0; u < UF; ++u) {
@@ -164,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a)
       }
     };
     u32x4 wfa[NI][2], wfb[NI][2];
+    if (a.abl == 2) continue;
     load_w(0, wfa);
 #pragma unroll
     for (int ks = 0; ks < 6; ks += 2) {
@@ -234,6 +238,8 @@ int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, co
   a.wave = wave; a.wstats = wstats; a.w0 = w0; a.gamma0 = gamma0; a.beta0 = beta0; a.lnq = lnq;
   a.W2h = static_cast<const u16*>(W2h); a.col_scale = col_scale; a.out = out;
   a.N = N; a.T0 = T0; a.T1 = T1; a.C0 = C0; a.N1p = N1p; a.eps = eps;
+  static const int abl = getenv("DZN_CONV01_ABL") ? atoi(getenv("DZN_CONV01_ABL")) : 0;
+  a.abl = abl;
   {   // exact power-of-two scale that puts the bound into [2^14, 2^15)
     int e;
     (void)frexpf(act_bound, &e);          // act_bound = m * 2^e, m in [0.5, 1)

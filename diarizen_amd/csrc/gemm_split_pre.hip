@@ -252,9 +252,13 @@ int launch_pre_cfg(const dzn_gemm_desc& d, hipStream_t s) {
 
 // x fp32 [B, L, D] -> three bf16 planes of the zero-padded copy [B, Lp, D] (rows shifted by `pad`), the 32
 // channels of every block stored in fragment order (position 8q+e <-> channel 4q+e, 16+4q+(e-4))
+// cg / cgp: channels per group of the source / of the planes (cgp = cg rounded up to 32; channels cg .. cgp-1 of a group
+// are written as zeros — the base models' 48-channel groups become 64, so that the contraction's K tiles never straddle
+// a tap; D is the PLANE row width G * cgp, the source rows are G * cg wide)
 __global__ __launch_bounds__(256) void pad_rows_split3_kernel(const float* __restrict__ x, u16* __restrict__ planes,
-                                                              int64_t plane_stride, int L, int Lp, int pad, int D) {
+                                                              int64_t plane_stride, int L, int Lp, int pad, int D, int cg, int cgp) {
   const int b = blockIdx.y;
+  const int Ds = D / cgp * cg;                                // source row width
   const int chunks = D / 8;                                   // 16-byte output chunks per row
   const int64_t n = (int64_t)Lp * chunks;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -263,11 +267,17 @@ __global__ __launch_bounds__(256) void pad_rows_split3_kernel(const float* __res
     const int t = r - pad;
     f32x4 u = (f32x4){0.f, 0.f, 0.f, 0.f}, v = u;
     if (t >= 0 && t < L) {
-      const float* src = x + ((int64_t)b * L + t) * D + blk * 32 + 4 * q;
-      const float4 a = *reinterpret_cast<const float4*>(src);
-      const float4 e = *reinterpret_cast<const float4*>(src + 16);
-      u = (f32x4){a.x, a.y, a.z, a.w};
-      v = (f32x4){e.x, e.y, e.z, e.w};
+      const float* row = x + ((int64_t)b * L + t) * Ds;
+      const int c0 = blk * 32 + 4 * q, c1 = c0 + 16;          // plane channels of the two float4s
+      const int g0 = c0 / cgp, i0 = c0 - g0 * cgp, g1 = c1 / cgp, i1 = c1 - g1 * cgp;
+      if (i0 < cg) {
+        const float4 a = *reinterpret_cast<const float4*>(row + g0 * cg + i0);
+        u = (f32x4){a.x, a.y, a.z, a.w};
+      }
+      if (i1 < cg) {
+        const float4 e = *reinterpret_cast<const float4*>(row + g1 * cg + i1);
+        v = (f32x4){e.x, e.y, e.z, e.w};
+      }
     }
     bf16x8 ph, pm, pl;
     split8(u, v, ph, pm, pl);
@@ -282,8 +292,9 @@ __global__ __launch_bounds__(256) void pad_rows_split3_kernel(const float* __res
 // snapshotted for the consuming contraction (see gemm_split_pre_kernel)
 __global__ __launch_bounds__(256) void pad_rows_split2_kernel(const float* __restrict__ x, u16* __restrict__ planes,
                                                               int64_t plane_stride, int L, int Lp, int pad, int D,
-                                                              const float* __restrict__ amax, float* __restrict__ snapshot) {
+                                                              const float* __restrict__ amax, float* __restrict__ snapshot, int cg, int cgp) {
   const int b = blockIdx.y;
+  const int Ds = D / cgp * cg;
   const float am = amax[b];              // per-window tracker
   float sc, inv;
   h2_scale(am, sc, inv);
@@ -296,11 +307,17 @@ __global__ __launch_bounds__(256) void pad_rows_split2_kernel(const float* __res
     const int t = r - pad;
     f32x4 u = (f32x4){0.f, 0.f, 0.f, 0.f}, v = u;
     if (t >= 0 && t < L) {
-      const float* src = x + ((int64_t)b * L + t) * D + blk * 32 + 4 * q;
-      const float4 a = *reinterpret_cast<const float4*>(src);
-      const float4 e = *reinterpret_cast<const float4*>(src + 16);
-      u = (f32x4){a.x, a.y, a.z, a.w};
-      v = (f32x4){e.x, e.y, e.z, e.w};
+      const float* row = x + ((int64_t)b * L + t) * Ds;
+      const int c0 = blk * 32 + 4 * q, c1 = c0 + 16;          // plane channels of the two float4s
+      const int g0 = c0 / cgp, i0 = c0 - g0 * cgp, g1 = c1 / cgp, i1 = c1 - g1 * cgp;
+      if (i0 < cg) {
+        const float4 a = *reinterpret_cast<const float4*>(row + g0 * cg + i0);
+        u = (f32x4){a.x, a.y, a.z, a.w};
+      }
+      if (i1 < cg) {
+        const float4 e = *reinterpret_cast<const float4*>(row + g1 * cg + i1);
+        v = (f32x4){e.x, e.y, e.z, e.w};
+      }
     }
     u32x4 ph, pl;
     split8_h2(u, v, sc, ph, pl);
@@ -335,13 +352,15 @@ int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s) {
 }
 
 int launch_pad_rows_split2(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
-                           const float* amax, float* snapshot, hipStream_t st) {
+                           const float* amax, float* snapshot, hipStream_t st, int cg, int cgp) {
+  if (cg <= 0) cg = cgp = 32;
+  if (cg % 4 || cgp % 32 || cg > cgp || D % cgp) return DZN_E_INVALID;
   ProfScope prof_scope_(st, "pad_rows_split2", 0.0, (double)B * D * (L * 4.0 + Lp * 4.0));   // fp32 in, two fp16 planes out
   if (D % 32 || !amax || !snapshot) return DZN_E_INVALID;
   int64_t g = cdiv64((int64_t)Lp * (D / 8), 256);
   g = g > 4096 ? 4096 : g;
   hipLaunchKernelGGL(pad_rows_split2_kernel, dim3((unsigned)g, B), dim3(256), 0, st, x, static_cast<u16*>(planes),
-                     plane_stride, L, Lp, pad, D, amax, snapshot);
+                     plane_stride, L, Lp, pad, D, amax, snapshot, cg, cgp);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
@@ -349,13 +368,15 @@ extern "C" int dzn_op_split_rows(const float* x, void* planes, int64_t plane_str
                                  void* stream);
 
 int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
-                           hipStream_t st) {
+                           hipStream_t st, int cg, int cgp) {
+  if (cg <= 0) cg = cgp = 32;
+  if (cg % 4 || cgp % 32 || cg > cgp || D % cgp) return DZN_E_INVALID;
   ProfScope prof_scope_(st, "pad_rows_split3", 0.0, (double)B * D * (L * 4.0 + Lp * 6.0));
   if (D % 32) return DZN_E_INVALID;
   int64_t g = cdiv64((int64_t)Lp * (D / 8), 256);
   g = g > 4096 ? 4096 : g;
   hipLaunchKernelGGL(pad_rows_split3_kernel, dim3((unsigned)g, B), dim3(256), 0, st, x, static_cast<u16*>(planes),
-                     plane_stride, L, Lp, pad, D);
+                     plane_stride, L, Lp, pad, D, cg, cgp);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
