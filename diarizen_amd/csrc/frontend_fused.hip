@@ -48,18 +48,32 @@ struct FusedArgs {
   int abl;                     // timing probe only (DZN_CONV01_ABL): 1 = skip the VALU phase, 2 = skip the MFMA phase (wrong results)
 };
 
-__global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// PP = true (round 3, "ping-pong"): ONE 512-thread workgroup per CU carries TWO tiles.  Wavefronts 0-3 (group 0) own
+// tile 2 x, wavefronts 4-7 (group 1) tile 2 x + 1, each with its private planes / strip in LDS, and group 1 runs one
+// barrier interval behind: while one group is in its VALU phase (conv0 + LayerNorm + GELU + split -> LDS) the other is in
+// its MFMA phase (conv1 from LDS), on every SIMD, by construction.  Measured with the phases switched off one at a time
+// (DZN_CONV01_ABL, scripts/probe_kernel_class.py, 374 windows): VALU alone 7.8 ms, MFMA alone 8.9 ms, both 13.9 ms with
+// two independent 256-thread workgroups per CU (PP = false: their phases overlap only by chance).
+template <bool PP>
+__global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  constexpr int GROUP_LDS = (2 * FF_PLANE + (int)sizeof(float) * (5 * (FF_FR - 1) + 10 + 6) + (int)sizeof(float2) * FF_FR + 15) / 16 * 16;
+  const int grp = PP ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+  unsigned char* smem = smem_all + grp * GROUP_LDS;
   unsigned char* pl0 = smem;                                   // hi plane  [FF_FR][64 ch] fp16, slots swizzled
   unsigned char* pl1 = smem + FF_PLANE;                        // lo plane
   float* sx = reinterpret_cast<float*>(smem + 2 * FF_PLANE);   // normalised samples of the strip
   float2* sst = reinterpret_cast<float2*>(sx + (5 * (FF_FR - 1) + 10 + 6));   // (mean, rstd) per conv0 frame
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x & 255, lane = tid & 63;  // thread / wavefront index inside the group
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y;
-  const int t1_0 = blockIdx.x * FF_BM;                 // first conv1 frame of the tile
+  const int ntile = (a.T1 + FF_BM - 1) / FF_BM;
+  int tile = PP ? 2 * (int)blockIdx.x + grp : (int)blockIdx.x;
+  const bool live = tile < ntile;                      // PP, odd tile count: the last group 1 re-does the last tile, stores nothing
+  tile = live ? tile : ntile - 1;
+  const int t1_0 = tile * FF_BM;                       // first conv1 frame of the tile
   const int f0 = 2 * t1_0;                             // first conv0 frame
   const int nfr = min(FF_FR, a.T0 - f0);               // conv0 frames that exist
   const int nsamp = 5 * (nfr - 1) + 10;
@@ -95,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a)
   const int KB = 3 * a.C0 / 32;            // 32-blocks of conv1's K
   const int nslab = a.C0 / 64;
 
+  if (PP && grp) __syncthreads();     // group 1 runs one interval behind (both groups execute the same number of barriers)
   for (int slab = 0; slab < nslab; ++slab) {
     __syncthreads();   // statistics written (first slab) / previous slab's planes fully consumed
     // ---- VALU phase: conv0 + LayerNorm + GELU + two-term split of channel (slab * 64 + lane).  A wavefront takes
@@ -178,6 +193,8 @@ __global__ __launch_bounds__(256, 2) void conv01_fused_kernel(const FusedArgs a)
     }
   }
 
+  if (PP && !grp) __syncthreads();    // matches group 1's offset barrier
+  if (!live) return;
   // ---- epilogue: lane (lr, lq) of block (i, jn) holds frame t1_0 + wm*64 + i*16 + lr, channels n0 .. n0 + 3 ----
   float* ob = a.out + (int64_t)b * a.T1 * a.N1p;
 #pragma unroll
@@ -246,16 +263,21 @@ int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, co
     a.a_scale = ldexpf(1.0f, 15 - e);
     a.a_inv = ldexpf(1.0f, e - 15);
   }
-  const size_t lds = 2 * FF_PLANE + sizeof(float) * (5 * (FF_FR - 1) + 10 + 6) + sizeof(float2) * FF_FR;
+  const size_t group_lds = (2 * FF_PLANE + sizeof(float) * (5 * (FF_FR - 1) + 10 + 6) + sizeof(float2) * FF_FR + 15) / 16 * 16;
+  static const bool pp = getenv("DZN_CONV01_NO_PP") == nullptr;     // two tiles per 512-thread workgroup, phases in anti-phase
   static unsigned long long attr_mask = 0;
-  if (first_use_on_device(attr_mask))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (first_use_on_device(attr_mask)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-  dim3 grid((T1 + FF_BM - 1) / FF_BM, B);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  }
+  const int ntile = (T1 + FF_BM - 1) / FF_BM;
   // algorithmic work: conv0 + conv1 flops; algorithmic HBM bytes: waveform in, conv1's raw output out
   const int pid = prof_begin(st, "conv01_fused", 2.0 * B * ((double)T0 * C0 * 10 + (double)T1 * 153.0 * 3 * C0),
                              B * (4.0 * N + 4.0 * (double)T1 * N1p));
-  hipLaunchKernelGGL(conv01_fused_kernel, grid, dim3(256), lds, st, a);
+  if (pp) hipLaunchKernelGGL(conv01_fused_kernel<true>, dim3((ntile + 1) / 2, B), dim3(512), 2 * group_lds, st, a);
+  else hipLaunchKernelGGL(conv01_fused_kernel<false>, dim3(ntile, B), dim3(256), group_lds, st, a);
   prof_end(pid, st);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
