@@ -11,6 +11,8 @@
 //      zero-bordered NHWC image the 3x3 contractions read.
 //  stats_pool_kernel : TSTP / StatsPool weighted mean + std for ALL speaker masks of a window
 //      from one trunk pass (resnet.py:49-66, PA/models/blocks/pooling.py:44-75,107-131).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -93,53 +95,66 @@ __global__ __launch_bounds__(256) void log_cmn_kernel(float* __restrict__ mel, i
 }
 
 // fb [B, T, NB]  ->  img [B, NB+2, T+2, C] (interior only; borders stay zero)
+// r3: one image per blockIdx.y, a workgroup walks a contiguous run of its pixels; a thread owns ONE channel quad for
+// the whole loop (its 36 taps + 4 biases live in registers), stores one float4 per pixel (a pixel's 32 channels = one
+// 128-byte line written by 8 neighbouring lanes) and the |max| tracker is updated once per workgroup.  r2's form
+// (flat index over everything: three 64-bit div/mods, 36 tap loads, four 4-byte stores and a tracker probe PER ELEMENT)
+// wrote its 3 GB per launch at 1.27 TB/s.
 template <typename TO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ fb, int B, int T,
                                                         int NB, int C,
                                                         const float* __restrict__ w,  // [C, 9] folded
                                                         const float* __restrict__ bias,
                                                         TO* __restrict__ img, float* __restrict__ amax) {
-  const int cq = C / 4;
-  const int64_t total = (int64_t)B * NB * T * cq;
-  // wave-uniform trip count (the tracker update below is a wave-level reduction); the last sweep is predicated
-  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < total; i0 += (int64_t)gridDim.x * 256) {
-    const bool ok = i0 + threadIdx.x < total;
-    const int64_t i = ok ? i0 + threadIdx.x : total - 1;
-    const int q = (int)(i % cq);
-    int64_t p = i / cq;
-    const int wv = (int)(p % T);
-    p /= T;
-    const int h = (int)(p % NB);
-    const int b = (int)(p / NB);
+  const int cq = C >> 2;                       // channel quads per pixel (8 for the 32-channel stem)
+  const int b = blockIdx.y;
+  const int q = threadIdx.x % cq, pl = threadIdx.x / cq, ppb = 256 / cq;     // pixel lane, pixels per sweep
+  float wr[4][9], br[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    br[c] = bias[q * 4 + c];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[c][k] = w[(q * 4 + c) * 9 + k];
+  }
+  const int npix = NB * T;
+  const int per = (npix + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  const float* fbb = fb + (int64_t)b * T * NB;
+  TO* ib = img + (int64_t)b * (NB + 2) * (T + 2) * C;
+  float mx = 0.f;
+  for (int p = p0 + pl; p < p1; p += ppb) {
+    const int h = p / T, wv = p - h * T;       // pixel (mel bin h, frame wv): consecutive pixels walk along time
     float in[9];
 #pragma unroll
     for (int dh = 0; dh < 3; ++dh)
 #pragma unroll
       for (int dw = 0; dw < 3; ++dw) {
         const int hh = h + dh - 1, ww = wv + dw - 1;
-        in[dh * 3 + dw] = (hh >= 0 && hh < NB && ww >= 0 && ww < T)
-                              ? fb[((int64_t)b * T + ww) * NB + hh] : 0.f;
+        in[dh * 3 + dw] = (hh >= 0 && hh < NB && ww >= 0 && ww < T) ? fbb[(int64_t)ww * NB + hh] : 0.f;
       }
     float o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int ch = q * 4 + c;
-      float a = 0.f;
+      float acc = 0.f;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) a = fmaf(in[k], w[ch * 9 + k], a);
-      o[c] = fmaxf(a + bias[ch], 0.f);
+      for (int k = 0; k < 9; ++k) acc = fmaf(in[k], wr[c][k], acc);
+      o[c] = fmaxf(acc + br[c], 0.f);
     }
-    TO* op = img + (((int64_t)b * (NB + 2) + h + 1) * (T + 2) + wv + 1) * C + q * 4;
-    if (ok) {
+    TO* op = ib + ((int64_t)(h + 1) * (T + 2) + wv + 1) * C + q * 4;
+    if constexpr (std::is_same<TO, float>::value) {
+      *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
 #pragma unroll
       for (int c = 0; c < 4; ++c) st_act(op, c, o[c]);
     }
-    if (amax) {   // per-image |max| tracker (DZN_PREC_F32_H2: scale of the stage-1 convolutions' fp16 split)
-      const float m = ok ? fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])) : 0.f;     // post-ReLU: non-negative
-      const int b0 = __builtin_amdgcn_readfirstlane(b);
-      if (__all(b == b0)) track_amax(amax + b0, m);
-      else track_amax_lane(amax + b, m);
-    }
+    mx = fmaxf(mx, fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])));     // post-ReLU: non-negative
+  }
+  if (amax) {   // per-image |max| tracker (DZN_PREC_F32_H2: scale of the stage-1 convolutions' fp16 split)
+    __shared__ float wmax[4];
+    const float m = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) track_amax_lane(amax + b, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
   }
 }
 
@@ -218,7 +233,12 @@ int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* 
                      void* img, int out_bf16, hipStream_t st, float* amax) {
   ProfScope prof_scope_(st, "stem_conv", 2.0 * B * NB * (double)T * C * 9.0,
                         (double)B * NB * T * 4.0 + (double)B * NB * T * C * (out_bf16 ? 2.0 : 4.0));   // fbank in, C-channel image out
-  const dim3 grid(grid_for((int64_t)B * NB * T * (C / 4)));
+  if (C % 4 || 256 % (C / 4)) return DZN_E_INVALID;
+  // ~8 sweeps of 256 / (C / 4) pixels per workgroup
+  const int npix = NB * T, ppb = 256 / (C / 4);
+  int gx = (npix + 8 * ppb - 1) / (8 * ppb);
+  gx = gx < 1 ? 1 : gx;
+  const dim3 grid(gx, B);
   if (out_bf16)
     hipLaunchKernelGGL(stem_conv_kernel<u16>, grid, dim3(256), 0, st, fb, B, T, NB, C, w, bias,
                        static_cast<u16*>(img), amax);

@@ -264,7 +264,11 @@ int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, co
     a.a_inv = ldexpf(1.0f, e - 15);
   }
   const size_t group_lds = (2 * FF_PLANE + sizeof(float) * (5 * (FF_FR - 1) + 10 + 6) + sizeof(float2) * FF_FR + 15) / 16 * 16;
-  static const bool pp = getenv("DZN_CONV01_NO_PP") == nullptr;     // two tiles per 512-thread workgroup, phases in anti-phase
+  // two tiles per 512-thread workgroup with the phases in anti-phase: measured SLOWER (15.7 vs 13.7 ms per 374 windows,
+  // profiles/r3_conv01_phase_probe.txt) — a phase that runs on ONE wavefront per SIMD is bound by its dependent chains
+  // (VALU alone: 13.4 ms in this form, 7.8 ms when two workgroups share the SIMDs), so forcing the overlap costs more
+  // than it hides.  Kept behind DZN_CONV01_PP=1 for the record; the default is two independent workgroups per CU.
+  static const bool pp = getenv("DZN_CONV01_PP") != nullptr;
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
