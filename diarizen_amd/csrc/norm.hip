@@ -8,6 +8,10 @@
 // Model.lnorm (model_wavlm_conformer.py:257) and every Conformer ln_norm (conformer.py).
 // HBM-bound: one wavefront per row, the row is held in registers between the two passes, so each
 // element is read once and written once.  Input / output may be fp32 or (bf16 engine mode) bf16.
+#include <cstdint>
+#include <initializer_list>
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -168,10 +172,148 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(const float* __restric
   }
 }
 
+// ---- float4 form (round 3), fp32 in / out ----
+// One wavefront-per-row with 4-byte loads issues ~100 instructions for a 160-channel row (the conv LayerNorm sites): the
+// kernel ran at 2.8 TB/s, instruction-bound.  Here G lanes (16 / 32 / 64) own a row, NV float4s each, so a wavefront
+// processes 64 / G rows per step with NV 16-byte loads and stores per lane; the two reductions run over the G lanes of a
+// row with xor shuffles.  Same two-pass arithmetic (mean, then centred squares) as the scalar form.
+template <int G, int NV>
+__global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* x, int64_t ldx, float* y,   /* y may alias x (post-norm layers) */
+                                                           int64_t ldy, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ post,
+                                                           int64_t rows, int C, int Cpad, float eps, int gelu,
+                                                           float* __restrict__ amax_out, int64_t amax_unit, int iters) {
+  constexpr int RPW = 64 / G;                  // rows per wavefront step
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / G, gl = lane % G;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * iters * RPW + sub;
+  // this lane's columns: 4 (gl + G k) .. + 3
+  float4 g4[NV], b4[NV], p4[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = 4 * (gl + G * k);
+    float gg[4], bb[4], pp[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool in = c + e < C;
+      gg[e] = (gamma && in) ? gamma[c + e] : 1.f;
+      bb[e] = (beta && gamma && in) ? beta[c + e] : 0.f;
+      pp[e] = (post && in) ? post[c + e] : 1.f;
+    }
+    g4[k] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+    b4[k] = make_float4(bb[0], bb[1], bb[2], bb[3]);
+    p4[k] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+  }
+  const float invC = 1.0f / (float)C;
+  float seen = -1.f;                           // last tracker value this lane group saw for `seen_unit`
+  int64_t seen_unit = -1;
+  for (int it = 0; it < iters; ++it) {
+    const int64_t row = row0 + (int64_t)it * RPW;
+    const bool valid = row < rows;
+    const int64_t rc = valid ? row : rows - 1;
+    const float* xp = x + rc * ldx;
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = 4 * (gl + G * k);
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c + 3 < C) {
+        v[k] = *reinterpret_cast<const float4*>(xp + c);
+      } else if (c < C) {                       // ragged last quad (C % 4 != 0)
+        v[k].x = xp[c];
+        if (c + 1 < C) v[k].y = xp[c + 1];
+        if (c + 2 < C) v[k].z = xp[c + 2];
+      }
+      sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum * invC;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = 4 * (gl + G * k);
+      const float d0 = c < C ? v[k].x - mean : 0.f, d1 = c + 1 < C ? v[k].y - mean : 0.f;
+      const float d2 = c + 2 < C ? v[k].z - mean : 0.f, d3 = c + 3 < C ? v[k].w - mean : 0.f;
+      sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = 1.0f / sqrtf(sq * invC + eps);
+    float* yp = y + rc * ldy;
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = 4 * (gl + G * k);
+      float in[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      const float gk[4] = {g4[k].x, g4[k].y, g4[k].z, g4[k].w}, bk[4] = {b4[k].x, b4[k].y, b4[k].z, b4[k].w};
+      const float pk[4] = {p4[k].x, p4[k].y, p4[k].z, p4[k].w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = (in[e] - mean) * rstd;
+        if (gamma) t = t * gk[e] + bk[e];
+        if (gelu) t = gelu_erf(t);
+        if (post) t *= pk[e];
+        o[e] = c + e < C ? t : 0.f;
+        m = fmaxf(m, fabsf(o[e]));
+      }
+      if (valid && c < Cpad) *reinterpret_cast<float4*>(yp + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (amax_out) {     // |max| of the row -> tracker of its unit (window); probed only when this lane group's maximum grows
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      const int64_t unit = amax_unit > 0 ? rc / amax_unit : 0;
+      if (unit != seen_unit) {
+        seen_unit = unit;
+        seen = -1.f;
+      }
+      if (valid && gl == 0 && m > seen) {
+        track_amax_lane(amax_out + unit, m);
+        seen = m;
+      }
+    }
+  }
+}
+
 template <typename TI, typename TO>
 int launch_ln_typed(const TI* x, int64_t ldx, TO* y, int64_t ldy, const float* g, const float* b,
                     const float* post, int64_t rows, int C, int Cpad, float eps, int gelu, hipStream_t s,
                     float* amax, int64_t amax_unit) {
+  if constexpr (std::is_same<TI, float>::value && std::is_same<TO, float>::value) {
+    const int needv = Cpad > C ? Cpad : C;
+    if (!(needv & 3) && !(ldx & 3) && !(ldy & 3) && needv <= 1024 && !(((uintptr_t)x | (uintptr_t)y) & 15)) {
+      // lanes per row / float4s per lane: least padding first, narrowest row group on ties
+      int G = 0, NV = 0, best = 1 << 30;
+      for (int gcand : {16, 32, 64}) {
+        const int nv = (needv + 4 * gcand - 1) / (4 * gcand);
+        if (nv <= 4 && nv * 4 * gcand < best) { best = nv * 4 * gcand; G = gcand; NV = nv; }
+      }
+      if (G) {
+        const int rpwv = 64 / G;
+        // ~8 wavefront steps per wavefront, at least 2048 workgroups when there are rows enough
+        int64_t steps = cdiv64(rows, rpwv);
+        int iters = (int)(steps / (2048 * 4));
+        iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+        const unsigned gridv = (unsigned)cdiv64(cdiv64(steps, iters), 4);
+#define DZN_LN4(GV, NVV)                                                                                         \
+  hipLaunchKernelGGL((layernorm_v4_kernel<GV, NVV>), dim3(gridv), dim3(256), 0, s, x, ldx, y, ldy, g, b, post, rows, \
+                     C, Cpad, eps, gelu, amax, amax_unit, iters)
+        if (G == 16 && NV == 1) DZN_LN4(16, 1);
+        else if (G == 16 && NV == 2) DZN_LN4(16, 2);
+        else if (G == 16 && NV == 3) DZN_LN4(16, 3);
+        else if (G == 16 && NV == 4) DZN_LN4(16, 4);
+        else if (G == 32 && NV == 3) DZN_LN4(32, 3);
+        else if (G == 32 && NV == 4) DZN_LN4(32, 4);
+        else if (G == 64 && NV == 3) DZN_LN4(64, 3);
+        else if (G == 64 && NV == 4) DZN_LN4(64, 4);
+        else G = 0;
+#undef DZN_LN4
+        if (G) return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+      }
+    }
+  }
   // with a tracker: contiguous runs of rows per wavefront, >= 8 waves per SIMD worth of wavefronts in flight
   int rpw = 1;
   if (amax) {
