@@ -368,7 +368,11 @@ def main():
     # the in-situ HIP-event profiler runs INSIDE the timed steps (two event records per launch on the launch stream;
     # measured cost 1 % of the step, reported as `unprofiled_ms_per_step` from one extra step below)
     if not args.no_profile:
+        # one untimed profiled step sizes the event pool: the timed region must not create HIP events
         _lib.profile_enable(True)
+        step()
+        launches = sum(p["launches"] for p in _lib.profile_collect())
+        _lib.profile_reserve(2 * launches * args.steps + 1024)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

@@ -151,6 +151,7 @@ def load() -> C.CDLL:
     sig("dzn_version", C.c_char_p, [])
     sig("dzn_profile_enable", i32, [i32])
     sig("dzn_profile_collect", i32, [C.POINTER(DznProfEntry), i32, C.POINTER(i32)])
+    sig("dzn_profile_reserve", i32, [i32])
     sig("dzn_op_relpos_bucket", i32, [i32, i32, i32])
     sig("dzn_linkage_centroid", i32, [vp, i32, i32, vp, i32])
     sig("dzn_cdist_cosine", i32, [vp, i32, i32, vp, i32, vp, i32])
@@ -183,12 +184,17 @@ EXPORTED = [
     "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid", "dzn_cdist_cosine",
     "dzn_vbx_create", "dzn_vbx_stats", "dzn_vbx_estep", "dzn_vbx_gamma", "dzn_vbx_destroy",
     "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",
-    "dzn_profile_enable", "dzn_profile_collect", "dzn_op_relpos_bucket",
+    "dzn_profile_enable", "dzn_profile_collect", "dzn_profile_reserve", "dzn_op_relpos_bucket",
 ]
 
 
 def profile_enable(on: bool) -> None:
     check(load().dzn_profile_enable(int(on)), None, "dzn_profile_enable")
+
+
+def profile_reserve(n_events: int) -> None:
+    """pre-create HIP events so that a timed region with the profiler on never allocates one"""
+    check(load().dzn_profile_reserve(int(n_events)), None, "dzn_profile_reserve")
 
 
 def profile_collect() -> list:

@@ -196,6 +196,8 @@ typedef struct dzn_prof_entry {
 } dzn_prof_entry;
 int dzn_profile_enable(int32_t on);
 int dzn_profile_collect(dzn_prof_entry* out, int32_t cap, int32_t* n);
+/* pre-create n_events HIP events (two per launch at most) so that a timed region never allocates one */
+int dzn_profile_reserve(int32_t n_events);
 
 /* host-side relative-position bucket of WavLM (W2V/components.py:629-666), exposed for tests */
 int dzn_op_relpos_bucket(int32_t rel, int32_t num_buckets, int32_t max_distance);
