@@ -171,7 +171,8 @@ int launch_col_scale(void* x, int x_bf16, int64_t rows, int C, int64_t ld, const
 int launch_split_weights_h2_natural(const float* W, int64_t rows, int K, void* W2, float* col_scale, hipStream_t s);
 int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, const float* w0, const float* gamma0,
                         const float* beta0, const float* lnq, int C0, int T0, int T1, const void* W2h,
-                        const float* col_scale, int N1p, float act_bound, float eps, float* out, hipStream_t st);
+                        const float* col_scale, int N1p, float act_bound, float eps, float* out, hipStream_t st,
+                        const float* gamma1 = nullptr, const float* beta1 = nullptr, int C1 = 0, float* amax1 = nullptr);
 // conformer.hip
 int launch_glu_dwconv(const float* u, int64_t ldu, const float* w, const float* bias, void* out,
                       int out_bf16, int64_t ldo, int B, int L, int A, int ks, hipStream_t st);

@@ -1058,13 +1058,17 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     if (!lnx) d.act = DZN_ACT_GELU;
     d.a_amax = am(conv_slot(cur));   // (r3: the group-norm element pass tracks its |max| too, so conv1 takes the fp16 split)
     if (!lnx) d.c_amax = am(conv_slot(nxt));
+    // (r3) the fused front end also finishes conv1's own LayerNorm + GELU in its epilogue (its tile holds whole rows)
+    const bool ln_in_01 = i == 1 && fuse01 && lnx && !lp && i != last && !getenv("DZN_CONV01_NO_LN");
     if (i == 1 && fuse01)
       chk(launch_conv01_fused(wave, B, N, stats, h->conv0_w, h->conv_ln[0].g, h->conv_ln[0].b, h->conv0_lnq, h->C[0],
-                              T[0], T[1], h->conv1_W2n, h->conv1_wscn, h->Cp[1], h->conv0_bound, 1e-5f, dst, st),
+                              T[0], T[1], h->conv1_W2n, h->conv1_wscn, h->Cp[1], h->conv0_bound, 1e-5f, ln_in_01 ? nxt : dst,
+                              st, ln_in_01 ? h->conv_ln[1].g : nullptr, ln_in_01 ? h->conv_ln[1].b : nullptr, h->C[1],
+                              ln_in_01 ? am(conv_slot(nxt)) : nullptr),
           "conv01 fused");
     else
       gemm(d, lp, lp && !lnx, "conv gemm");
-    if (lnx)  // channel LayerNorm + GELU (+ dummy_weight after the last conv, components.py:208)
+    if (lnx && !ln_in_01)  // channel LayerNorm + GELU (+ dummy_weight after the last conv, components.py:208)
       ln_t(dst, false, h->Cp[i], nxt, lp, h->Cp[i], h->conv_ln[i], (int64_t)B * T[i], h->Cp[i], 1, st,
            i == last ? h->dummy_w : nullptr, am(conv_slot(nxt)), T[i]);
     std::swap(cur, nxt);

@@ -45,6 +45,10 @@ struct FusedArgs {
   float* out;             // [B, T1, N1p] raw conv1 output
   int N, T0, T1, C0, N1p;
   float eps, a_scale, a_inv;   // power-of-two scale of the conv0 activations (from their static bound) and inverse
+  const float* gamma1;         // conv1's channel LayerNorm (+ GELU) fused into the epilogue when non-null: out = GELU(LN(conv1))
+  const float* beta1;
+  float* amax1;                // [B] |max| tracker of that output (scale of conv2's fp16 split) or null
+  int C1;                      // real conv1 channels (<= N1p)
   int abl;                     // timing probe only (DZN_CONV01_ABL): 1 = skip the VALU phase, 2 = skip the MFMA phase (wrong results)
 };
 
@@ -194,9 +198,80 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const F
   }
 
   if (PP && !grp) __syncthreads();    // matches group 1's offset barrier
-  if (!live) return;
   // ---- epilogue: lane (lr, lq) of block (i, jn) holds frame t1_0 + wm*64 + i*16 + lr, channels n0 .. n0 + 3 ----
   float* ob = a.out + (int64_t)b * a.T1 * a.N1p;
+  // undo the exact power-of-two operand scales first
+#pragma unroll
+  for (int jn = 0; jn < NI; ++jn) {
+    const float4 c4 = *reinterpret_cast<const float4*>(a.col_scale + wn * 80 + jn * 16 + lq * 4);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      acc[i][jn][0] *= a.a_inv * c4.x; acc[i][jn][1] *= a.a_inv * c4.y;
+      acc[i][jn][2] *= a.a_inv * c4.z; acc[i][jn][3] *= a.a_inv * c4.w;
+    }
+  }
+  if (a.gamma1) {
+    // r3: conv1's channel LayerNorm + GELU (W2V/components.py:63-70, 119-122) finished HERE: the 160 channels of a frame
+    // live in the two wavefronts wn = 0 / 1 of its row half, so the two row reductions (mean, then centred squares: the
+    // same two-pass arithmetic as norm.hip) go lane group -> wavefront (xor shuffles) -> the sibling wavefront through
+    // LDS.  The stand-alone pass it replaces re-read and re-wrote conv1's 3.1 GB per 374 windows.
+    __syncthreads();                                   // the planes are dead: their LDS carries the row partials now
+    float* red = reinterpret_cast<float*>(smem);       // [2 wn][128 rows]
+    float mean[MI], rstd[MI];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool in = wn * 80 + jn * 16 + lq * 4 + e < a.C1;
+            const float d = pass == 0 ? acc[i][jn][e] : acc[i][jn][e] - mean[i];
+            s1 += in ? (pass == 0 ? d : d * d) : 0.f;
+          }
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (lq == 0) red[wn * 128 + wm * 64 + i * 16 + lr] = s1;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * 64 + i * 16 + lr;
+        const float tot = red[r] + red[128 + r];        // fixed order: wn 0 then wn 1 on both wavefronts
+        if (pass == 0) mean[i] = tot / (float)a.C1;
+        else rstd[i] = 1.0f / sqrtf(tot / (float)a.C1 + a.eps);
+      }
+      __syncthreads();
+    }
+    float mx = 0.f;   // |max| over the rows that exist (rows past the strip hold finite junk from clamped frames)
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) {
+      const int n0 = wn * 80 + jn * 16 + lq * 4;
+      float g[4], be[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        g[e] = n0 + e < a.C1 ? a.gamma1[n0 + e] : 0.f;
+        be[e] = n0 + e < a.C1 ? a.beta1[n0 + e] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int t1 = t1_0 + wm * 64 + i * 16 + lr;
+        if (!live || t1 >= a.T1) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = n0 + e < a.C1 ? gelu_erf((acc[i][jn][e] - mean[i]) * rstd[i] * g[e] + be[e]) : 0.f;
+          mx = fmaxf(mx, fabsf(o[e]));
+        }
+        *reinterpret_cast<float4*>(ob + (int64_t)t1 * a.N1p + n0) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    if (a.amax1) track_amax(a.amax1 + b, mx);
+    return;
+  }
+  if (!live) return;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int t1 = t1_0 + wm * 64 + i * 16 + lr;
@@ -204,10 +279,8 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const F
 #pragma unroll
     for (int jn = 0; jn < NI; ++jn) {
       const int n0 = wn * 80 + jn * 16 + lq * 4;
-      const float4 c4 = *reinterpret_cast<const float4*>(a.col_scale + n0);
       const f32x4 v = acc[i][jn];
-      *reinterpret_cast<float4*>(ob + (int64_t)t1 * a.N1p + n0) =
-          make_float4(v[0] * a.a_inv * c4.x, v[1] * a.a_inv * c4.y, v[2] * a.a_inv * c4.z, v[3] * a.a_inv * c4.w);
+      *reinterpret_cast<float4*>(ob + (int64_t)t1 * a.N1p + n0) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -248,13 +321,16 @@ int launch_split_weights_h2_natural(const float* W, int64_t rows, int K, void* W
 // conv0 (k 10, s 5, C0 % 64 == 0) + LN + GELU + conv1 (k 3, s 2, 160 padded outputs): out = raw conv1 [B, T1, 160]
 int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, const float* w0, const float* gamma0,
                         const float* beta0, const float* lnq, int C0, int T0, int T1, const void* W2h,
-                        const float* col_scale, int N1p, float act_bound, float eps, float* out, hipStream_t st) {
+                        const float* col_scale, int N1p, float act_bound, float eps, float* out, hipStream_t st,
+                        const float* gamma1, const float* beta1, int C1, float* amax1) {
   if (B <= 0 || T1 <= 0) return DZN_OK;
+  if (gamma1 && (!beta1 || C1 <= 0 || C1 > N1p)) return DZN_E_INVALID;
   if ((C0 & 63) || N1p != 160 || !lnq || !W2h || !col_scale || !(act_bound > 0.f)) return DZN_E_INVALID;
   FusedArgs a{};
   a.wave = wave; a.wstats = wstats; a.w0 = w0; a.gamma0 = gamma0; a.beta0 = beta0; a.lnq = lnq;
   a.W2h = static_cast<const u16*>(W2h); a.col_scale = col_scale; a.out = out;
   a.N = N; a.T0 = T0; a.T1 = T1; a.C0 = C0; a.N1p = N1p; a.eps = eps;
+  a.gamma1 = gamma1; a.beta1 = beta1; a.C1 = C1; a.amax1 = amax1;
   static const int abl = getenv("DZN_CONV01_ABL") ? atoi(getenv("DZN_CONV01_ABL")) : 0;
   a.abl = abl;
   {   // exact power-of-two scale that puts the bound into [2^14, 2^15)

@@ -419,6 +419,10 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   if (d.N <= 32) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
   // 128x64 tiles run 4 wavefronts as 4x1 (32 rows x 64 columns each): the in-register operand
   // split is per A row, so wide-and-short wavefront tiles halve the VALU work per MFMA
+  // (r3 probe, profiles/r3_tile_choice_short_k.txt: in isolation the 128x128 tile is 4-7 % faster on the K = 256 .. 512
+  // shapes now that the epilogue is pipelined — 424 vs 444 us at 149226 x 1024 x 256; in the pipeline the step time did
+  // not move (1139 vs 1124-1142 ms), so the short-K launches stay on the narrow tile and the 128x128 symbol stays a
+  // homogeneous K >= 768 class for the roofline line)
   if (d.N <= 64 || d.K <= 512) return launch_split_cfg<128, 64, 4, 1, 2, NP, OCC64>(d, s);
   // 128-wide column tiles unless 64-wide ones save more than ~1/8 of the (padded) columns; widths that
   // are multiples of 80 but not of 64 (conv1 of the extractor: 153 -> 160) get exact 80-wide tiles
