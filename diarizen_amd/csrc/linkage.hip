@@ -11,19 +11,21 @@
 //   * D [n][n] float64 lives in HBM (41 GB at n = 72 k; 288 GB available), filled by a tiled
 //     pairwise-distance kernel (inactive columns / the diagonal hold +inf, so a row scan is a bare min);
 //   * the same greedy algorithm as scipy's fast_linkage runs on the device: per row a LOWER BOUND
-//     lb[z] of its minimum with a candidate neighbour nb[z]; each merge = one single-workgroup
-//     kernel (global argmin of lb, verify against D, rescan the row if the bound was stale, emit the
-//     dendrogram row) + one wide kernel (Lance-Williams centroid update of row / column `hi`,
-//     written in scipy's operation order in float64, bounds refreshed);
-//   * the global argmin of lb runs over per-block minima (256 rows per block, kept current by the update kernel), and
-//     the bound of the row a merge creates arrives exact from the update kernel's partial minima of that row — the
-//     rescans of rows whose bound went stale (0.6 per merge) keep 8 loads in flight per thread and mask retired
-//     columns by size[] (retired columns are not blanked: that was a second scattered write per row and merge);
-//   * no host round trip inside the loop: 2(n-1) launches are queued back to back (replaying them from a hipGraph
-//     was measured: no gain, the loop is not launch-bound).
+//     lb[z] of its minimum with a candidate neighbour nb[z]; the closest pair is the row with the smallest bound once
+//     that bound is exact, a stale bound is refreshed by rescanning its row; a merge is the Lance-Williams centroid
+//     update of row / column `hi`, written in scipy's operation order in float64;
+//   * r3: ONE launch per step (step_kernel, below) — every workgroup selects redundantly from per-workgroup records,
+//     then does its slice of the merge or of the row rescan; 6.2 us per launch, 718 ms at n = 35 790 with 2.2 rescans per
+//     merge (profiles/r3_linkage_step_vs_two_kernel.txt).  The r2 loop — a single-workgroup selection kernel + a wide
+//     update kernel per merge, 2253 ms on the same input — stays behind DZN_LINKAGE_TWO_KERNEL=1 as the cross-check of
+//     tests/test_ops_gpu.py;
+//   * no host round trip inside a batch of launches; retired columns are masked by size[], not blanked.
 // With no exact ties in the data the merge sequence — hence the dendrogram Z and every flat
 // clustering cut from it — equals scipy's (tests/test_ops_gpu.py compares Z and fcluster output).
 #include <math.h>
+#include <stdio.h>
+
+#include <chrono>
 
 #include <vector>
 
@@ -306,6 +308,227 @@ __global__ __launch_bounds__(LB_BLK) void update_kernel(double* __restrict__ D, 
   if (threadIdx.x == 0) { bmin[blockIdx.x] = v; barg[blockIdx.x] = id; }
 }
 
+
+// ---- r3: ONE launch per step --------------------------------------------------------------------------------------
+// The two-kernel loop above spends its time in the single workgroup of select_kernel (the dependent global round trips
+// of the bound fix-up, the block refresh, the argmin, the D look-up and — 0.6 times per merge — a 288 KB row rescan by
+// ONE workgroup) plus two launch gaps: ~30 us per merge at any n.  step_kernel folds the selection into the wide
+// kernel: every workgroup (256 rows / columns each) redundantly reduces the SAME published state — one record per
+// workgroup: the minimum bound of its rows with that row's candidate neighbour and whether the bound is exact
+// (D[x][nb[x]] == lb[x], checked by the owner when it publishes) — so all of them reach the same decision without
+// talking to each other, then each performs its slice of the step:
+//   * MERGE  (bound exact): the Lance-Williams update of its columns (as update_kernel), its partial minimum of the
+//     new row, its new record;
+//   * RESCAN (bound stale): its slice of the row scan — the scan that one workgroup did alone is spread over the chip —
+//     and its record with that row left out.
+// What a step publishes (records, partial minima, the step descriptor) is double-buffered by launch parity: a launch
+// only READS what the previous launch wrote and only WRITES the other copy, so the kernel boundary is the only
+// synchronisation.  State with a single owner (lb / nb / size / cid of a row, the columns of D) is fixed up by the
+// owner's thread at the start of the NEXT launch (the bound of the merged row from the partial minima, the sizes of
+// the merged pair); other workgroups substitute the previous step's values instead of reading those words.
+// Launches: (n - 1) merges + ~0.6 (n - 1) rescans instead of 2 (n - 1), each without the serial section.
+enum { STEP_NONE = 0, STEP_MERGE = 1, STEP_RESCAN = 2, STEP_DONE = 3, STEP_FAIL = 4 };
+struct StepState {
+  int kind, lo, hi, nlo, nhi, k, x, pad;
+  double dist;
+};
+struct StepRec {      // per workgroup: minimum bound of its rows
+  double v;
+  int x, y, exact, pad;
+};
+struct StepPart {     // per workgroup: minimum of its slice of a row (the merged row / the rescanned row)
+  double v;
+  int idx, pad;
+};
+
+// two block-wide (value, index) minima in one pass (shared barriers); results valid in every thread
+__device__ __forceinline__ void block_min_pair2(double v0, int i0, double v1, int i1, double& o0, int& oi0, double& o1,
+                                                int& oi1, double* sval, int* sidx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double a = __shfl_xor(v0, o, 64);
+    const int ai = __shfl_xor(i0, o, 64);
+    const double b = __shfl_xor(v1, o, 64);
+    const int bi = __shfl_xor(i1, o, 64);
+    if (a < v0 || (a == v0 && ai < i0)) { v0 = a; i0 = ai; }
+    if (b < v1 || (b == v1 && bi < i1)) { v1 = b; i1 = bi; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;   // nw <= 4: sval / sidx hold 2 x 4
+  __syncthreads();
+  if (lane == 0) { sval[wave] = v0; sidx[wave] = i0; sval[4 + wave] = v1; sidx[4 + wave] = i1; }
+  __syncthreads();
+  v0 = sval[0]; i0 = sidx[0]; v1 = sval[4]; i1 = sidx[4];
+  for (int w = 1; w < nw; ++w) {
+    const double a = sval[w], b = sval[4 + w];
+    const int ai = sidx[w], bi = sidx[4 + w];
+    if (a < v0 || (a == v0 && ai < i0)) { v0 = a; i0 = ai; }
+    if (b < v1 || (b == v1 && bi < i1)) { v1 = b; i1 = bi; }
+  }
+  o0 = v0; oi0 = i0; o1 = v1; oi1 = i1;
+}
+
+// first records: bounds from init_rows_kernel are exact
+__global__ __launch_bounds__(LB_BLK) void init_rec_kernel(int n, const double* __restrict__ lb, const int* __restrict__ nb,
+                                                          int* __restrict__ exf, StepRec* __restrict__ rec) {
+  __shared__ double sval[4];
+  __shared__ int sidx[4];
+  const int z = blockIdx.x * LB_BLK + threadIdx.x;
+  if (z < n) exf[z] = 1;
+  double v;
+  int x;
+  block_min_pair(z < n ? lb[z] : DINF, z < n ? z : 0x7fffffff, v, x, sval, sidx);
+  if (z == x) {
+    StepRec r;
+    r.v = v; r.x = x; r.y = nb[x]; r.exact = r.y >= 0; r.pad = 0;
+    rec[blockIdx.x] = r;
+  }
+}
+
+// A launch is latency-bound (a chain of global round trips and block reductions on ~141 workgroups), so the kernel is
+// written around the chain: (1) ONE round trip fetches everything that does not depend on the decision — the step
+// descriptor, the published records and partial minima, this thread's own row words (lb, nb, size, exact flag);
+// (2) one double reduction gives the fixed-up row's bound and the winner; (3) one round trip reads the two rows of D
+// (or the slice of the rescanned row); (4) one double reduction publishes the partial minimum and the record.  Whether a
+// bound is exact is tracked per row (exf[z], maintained by the row's own thread: the bound is exact until the distance to
+// the remembered neighbour changes without undercutting it) instead of looked up in D, which was a third round trip.
+__global__ __launch_bounds__(LB_BLK) void step_kernel(double* __restrict__ D, int n, double* __restrict__ lb,
+                                                      int* __restrict__ nb, int* __restrict__ size,
+                                                      int* __restrict__ cid, int* __restrict__ exf,
+                                                      double* __restrict__ Z, StepState* __restrict__ st2,
+                                                      StepRec* __restrict__ rec2, StepPart* __restrict__ part2,
+                                                      int parity) {
+  __shared__ double sval[8];
+  __shared__ int sidx[8];
+  __shared__ int sy[2];
+  const int G = gridDim.x, w = blockIdx.x, t = threadIdx.x;
+  const int z = w * LB_BLK + t;
+  const bool in = z < n;
+  const StepRec* rec = rec2 + (int64_t)parity * G;
+  StepRec* rec_out = rec2 + (int64_t)(parity ^ 1) * G;
+  const StepPart* part = part2 + (int64_t)parity * G;
+  StepPart* part_out = part2 + (int64_t)(parity ^ 1) * G;
+  StepState* st_out = st2 + (parity ^ 1);
+  // ---- (1) everything that does not depend on the decision ----
+  const StepState prev = st2[parity];
+  StepRec r0;
+  r0.v = DINF; r0.x = 0x7fffffff; r0.y = -1; r0.exact = 0;
+  StepPart p0;
+  p0.v = DINF; p0.idx = 0x7fffffff;
+  if (t < G) { r0 = rec[t]; p0 = part[t]; }
+  double my_lb = in ? lb[z] : DINF;
+  int my_nb = in ? nb[z] : -1;
+  int my_sz = in ? size[z] : 0;
+  int my_ex = in ? exf[z] : 0;
+  if (prev.kind == STEP_DONE || prev.kind == STEP_FAIL) {   // surplus launch: keep both copies of the descriptor final
+    if (w == 0 && t == 0) *st_out = prev;
+    return;
+  }
+  const bool owed = prev.kind == STEP_MERGE || prev.kind == STEP_RESCAN;
+  // ---- (2) the bound owed by the previous step + the winner over the records ----
+  double tv = owed ? p0.v : DINF, uv = r0.v;
+  int ti = owed ? p0.idx : 0x7fffffff, ui = r0.x;
+  for (int i = t + LB_BLK; i < G; i += LB_BLK) {            // n > 65 536 only
+    const StepRec r = rec[i];
+    const StepPart p = part[i];
+    if (owed && (p.v < tv || (p.v == tv && p.idx < ti))) { tv = p.v; ti = p.idx; }
+    if (r.v < uv || (r.v == uv && r.x < ui)) { uv = r.v; ui = r.x; }
+  }
+  double ev, d;
+  int eid, x;
+  block_min_pair2(tv, ti, uv, ui, ev, eid, d, x, sval, sidx);
+  const int ex = !owed ? 0x7fffffff : prev.kind == STEP_MERGE ? prev.hi : prev.x;   // the row left out of the records
+  const int ey = ev < DINF ? eid : -1;
+  bool lb_dirty = false, sz_dirty = false;
+  if (owed && z == ex) { my_lb = ev; my_nb = ey; my_ex = ey >= 0; lb_dirty = true; }
+  if (prev.kind == STEP_MERGE) {
+    if (z == prev.hi) { my_sz = prev.nlo + prev.nhi; cid[z] = n + prev.k - 1; sz_dirty = true; }
+    if (z == prev.lo) { my_sz = 0; sz_dirty = true; }
+  }
+  const int k = prev.k;
+  int y;
+  bool exact;
+  const bool extra_wins = owed && (ev < d || (ev == d && ex < x));
+  if (extra_wins) {
+    d = ev; x = ex; y = ey; exact = ey >= 0;
+  } else {
+    __syncthreads();
+    if (t < G && r0.x == x && r0.v == d) { sy[0] = r0.y; sy[1] = r0.exact; }
+    for (int i = t + LB_BLK; i < G; i += LB_BLK)
+      if (rec[i].x == x && rec[i].v == d) { sy[0] = rec[i].y; sy[1] = rec[i].exact; }
+    __syncthreads();
+    y = sy[0];
+    exact = sy[1] != 0 && y >= 0;
+  }
+  if (!(d < DINF) || x < 0 || x >= n) {    // NaN / inf distances: no pair left to merge
+    if (w == 0 && t == 0) { StepState s = prev; s.kind = STEP_FAIL; *st_out = s; }
+    return;
+  }
+  double pv = DINF;       // this thread's element of the row whose minimum the step publishes
+  int excl = -1;          // row left out of this step's records
+  if (!exact) {
+    // ---- RESCAN: this workgroup's slice of row x over the active columns ----
+    if (w == 0 && t == 0) {
+      StepState s = prev;
+      s.kind = STEP_RESCAN; s.x = x; s.k = k; s.pad = prev.pad + 1;   // pad counts the rescans (diagnostics)
+      *st_out = s;
+    }
+    if (in && my_sz != 0) pv = D[(int64_t)x * n + z];
+    excl = x;
+  } else {
+    // ---- MERGE: Lance-Williams update of this workgroup's columns ----
+    const int lo = x < y ? x : y, hi = x < y ? y : x;
+    const bool sub = prev.kind == STEP_MERGE;    // words of the previous pair are being rewritten by their owners
+    const int nlo = sub && lo == prev.hi ? prev.nlo + prev.nhi : size[lo];   // (lo / hi are active: never prev.lo)
+    const int nhi = sub && hi == prev.hi ? prev.nlo + prev.nhi : size[hi];
+    if (w == 0 && t == 0) {
+      const int ia = sub && lo == prev.hi ? n + prev.k - 1 : cid[lo];
+      const int ib = sub && hi == prev.hi ? n + prev.k - 1 : cid[hi];
+      Z[4 * k + 0] = (double)(ia < ib ? ia : ib);
+      Z[4 * k + 1] = (double)(ia < ib ? ib : ia);
+      Z[4 * k + 2] = d;
+      Z[4 * k + 3] = (double)(nlo + nhi);
+      StepState s;
+      s.kind = k + 1 >= n - 1 ? STEP_DONE : STEP_MERGE;
+      s.lo = lo; s.hi = hi; s.nlo = nlo; s.nhi = nhi; s.k = k + 1; s.x = -1; s.pad = prev.pad; s.dist = d;
+      *st_out = s;
+    }
+    if (in) {
+      if (z == hi) {
+        D[(int64_t)hi * n + lo] = DINF;
+        my_lb = DINF; my_nb = -1; my_ex = 0; lb_dirty = true;   // exact bound at the start of the next launch
+      } else if (z == lo) {
+        my_lb = DINF; my_ex = 0; lb_dirty = true;               // retired
+      } else if (my_sz != 0) {
+        const double dxi = D[(int64_t)lo * n + z], dyi = D[(int64_t)hi * n + z];
+        // scipy _hierarchy_distance_update.pxi, _centroid(d_xi, d_yi, d_xy, size_x, size_y, size_i), same order
+        const double nd = sqrt((((nlo * dxi * dxi) + (nhi * dyi * dyi)) - (nlo * nhi * d * d) / (nlo + nhi)) / (nlo + nhi));
+        D[(int64_t)hi * n + z] = nd;
+        D[(int64_t)z * n + hi] = nd;             // column lo is NOT blanked: readers of a row mask by size[]
+        if (my_nb == lo) { my_nb = hi; my_ex = nd == my_lb; lb_dirty = true; }      // a guess; lb stays a lower bound
+        else if (my_nb == hi) { my_ex = nd == my_lb; lb_dirty = true; }             // the neighbour's distance moved
+        if (nd < my_lb) { my_lb = nd; my_nb = hi; my_ex = 1; lb_dirty = true; }
+        pv = nd;
+      }
+    }
+  }
+  // ---- (4) publish: partial minimum of the new / rescanned row, record of this workgroup's rows ----
+  double bv, rv;
+  int bi, rx;
+  block_min_pair2(pv, in ? z : 0x7fffffff, (in && z != excl) ? my_lb : DINF, in ? z : 0x7fffffff, bv, bi, rv, rx, sval, sidx);
+  if (t == 0) {
+    StepPart p;
+    p.v = bv; p.idx = bi; p.pad = 0;
+    part_out[w] = p;
+  }
+  if (z == rx) {          // rx is always a row of this workgroup (every thread contributes its own index)
+    StepRec r;
+    r.v = rv; r.x = rx; r.y = rv < DINF ? my_nb : -1; r.exact = rv < DINF && my_ex != 0 && my_nb >= 0; r.pad = 0;
+    rec_out[w] = r;
+  }
+  if (in && lb_dirty) { lb[z] = my_lb; nb[z] = my_nb; exf[z] = my_ex; }
+  if (in && sz_dirty) size[z] = my_sz;
+}
+
 #define LCHK(call)                                   \
   do {                                               \
     if ((call) != hipSuccess) { rc = DZN_E_HIP; goto done; } \
@@ -321,6 +544,12 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   int *nb = nullptr, *size = nullptr, *cid = nullptr, *barg = nullptr, *hp_idx = nullptr;
   const int nblk = (n + LB_BLK - 1) / LB_BLK;
   MergeState* st = nullptr;
+  StepState* st2 = nullptr;
+  StepRec* rec2 = nullptr;
+  StepPart* part2 = nullptr;
+  int* exf = nullptr;
+  // DZN_LINKAGE_TWO_KERNEL=1: the r2 loop (one single-workgroup selection + one wide update per merge), kept for A/B timing
+  const bool two_kernel = getenv("DZN_LINKAGE_TWO_KERNEL") != nullptr;
   std::vector<int> ones(n, 1), ids(n);
   for (int i = 0; i < n; ++i) ids[i] = i;
   MergeState st0{};
@@ -346,12 +575,42 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
     const int tiles = (n + 63) / 64;
     hipLaunchKernelGGL(pdist_kernel, dim3(tiles, tiles), dim3(256), 0, 0, E, n, dim, D);
     hipLaunchKernelGGL(init_rows_kernel, dim3(n), dim3(256), 0, 0, D, n, lb, nb);
-    hipLaunchKernelGGL(block_minima_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, lb, n, bmin, barg);
-    for (int k = 0; k < n - 1; ++k) {
-      hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, 0, D, n, lb, nb, size, cid, Z, st, bmin, barg, hp_val,
-                         hp_idx);
-      hipLaunchKernelGGL(update_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, D, n, lb, nb, size, st, bmin, barg, hp_val,
-                         hp_idx);
+    if (two_kernel) {
+      hipLaunchKernelGGL(block_minima_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, lb, n, bmin, barg);
+      for (int k = 0; k < n - 1; ++k) {
+        hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, 0, D, n, lb, nb, size, cid, Z, st, bmin, barg, hp_val,
+                           hp_idx);
+        hipLaunchKernelGGL(update_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, D, n, lb, nb, size, st, bmin, barg, hp_val,
+                           hp_idx);
+      }
+    } else {
+      // one launch per step (merge or rescan); the number of rescans is data dependent, so launches are queued in
+      // batches sized from the merges still missing and the step descriptor is read back between batches (surplus
+      // launches after the last merge return at once)
+      LCHK(hipMalloc(&st2, 2 * sizeof(StepState)));
+      LCHK(hipMalloc(&rec2, (size_t)2 * nblk * sizeof(StepRec)));
+      LCHK(hipMalloc(&part2, (size_t)2 * nblk * sizeof(StepPart)));
+      LCHK(hipMalloc(&exf, (size_t)n * sizeof(int)));
+      LCHK(hipMemset(st2, 0, 2 * sizeof(StepState)));
+      hipLaunchKernelGGL(init_rec_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, n, lb, nb, exf, rec2);
+      int64_t launched = 0;
+      int remaining = n - 1;
+      const auto t_loop = std::chrono::steady_clock::now();
+      for (int round = 0; remaining > 0; ++round) {
+        if (round > 64 + n) { rc = DZN_E_INVALID; goto done; }   // cannot happen: every batch completes >= 1 merge
+        const int batch = remaining + remaining / 2 + 32;
+        for (int i = 0; i < batch; ++i, ++launched)
+          hipLaunchKernelGGL(step_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, D, n, lb, nb, size, cid, exf, Z, st2, rec2, part2,
+                             (int)(launched & 1));
+        LCHK(hipGetLastError());
+        StepState hs;
+        LCHK(hipMemcpy(&hs, st2 + (launched & 1), sizeof(StepState), hipMemcpyDeviceToHost));
+        if (hs.kind == STEP_FAIL) { rc = DZN_E_INVALID; goto done; }   // non-finite distances
+        remaining = hs.kind == STEP_DONE ? 0 : n - 1 - hs.k;
+        if (remaining == 0 && getenv("DZN_LINKAGE_DEBUG"))
+          fprintf(stderr, "linkage: n %d, %lld launches in %d batches, %d rescans, loop %.1f ms\n", n, (long long)launched,
+                  round + 1, hs.pad, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count());
+      }
     }
   }
   LCHK(hipGetLastError());
@@ -360,6 +619,7 @@ done:
   (void)hipFree(D); (void)hipFree(E); (void)hipFree(lb); (void)hipFree(Z);
   (void)hipFree(nb); (void)hipFree(size); (void)hipFree(cid); (void)hipFree(st);
   (void)hipFree(bmin); (void)hipFree(hp_val); (void)hipFree(barg); (void)hipFree(hp_idx);
+  (void)hipFree(st2); (void)hipFree(rec2); (void)hipFree(part2); (void)hipFree(exf);
   return rc;
 }
 

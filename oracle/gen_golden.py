@@ -593,12 +593,36 @@ def gen_configs():
     print("wavlm_configs:", {n: len(v["encoder_ff_interm_features"]) for n, v in out.items()})
 
 
-GENERATORS = {"configs": gen_configs, "seg": gen_seg, "seg_tt": gen_seg_tt, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
+# ------------------------------------------------------------------ centroid linkage at scale (row f1)
+def linkage_scale_case(n: int = 30011, dim: int = 48, K: int = 9, seed: int = 23) -> np.ndarray:
+    """speaker-structured float32 embeddings built from ELEMENTWISE float32 operations on seeded draws only (no sums, no
+    BLAS): the same bits on any host running this image, so a dendrogram computed here can be compared elsewhere."""
+    r = np.random.default_rng(seed)
+    cent = r.standard_normal((K, dim), dtype=np.float32)
+    lab = r.integers(0, K, n)
+    noise = r.standard_normal((n, dim), dtype=np.float32)
+    return (cent[lab] * np.float32(0.25) + noise * np.float32(0.11)).astype(np.float32)
+
+
+def gen_linkage_scale():
+    """tests/golden/linkage_30k.npz: scipy.cluster.hierarchy.linkage(method="centroid", metric="euclidean") — the call the
+    reference makes (PA/pipelines/clustering.py:407-416) — on linkage_scale_case(): n = 30 011 (the
+    device linkage at n >= 30 000; scipy needs ~4 min and 3.6 GB for it, so the dendrogram is committed, 0.4 MB)."""
+    import hashlib
+    from scipy.cluster.hierarchy import linkage
+    e = linkage_scale_case()
+    Z = linkage(e, method="centroid", metric="euclidean")
+    np.savez_compressed(GOLD / "linkage_30k.npz", ids=Z[:, :2].astype(np.int32), size=Z[:, 3].astype(np.int32), dist=Z[:, 2],
+                        emb_md5=np.array(hashlib.md5(e.tobytes()).hexdigest()))
+    print("linkage_30k:", Z.shape, "last merges", Z[-3:, 2])
+
+
+GENERATORS = {"linkage_scale": gen_linkage_scale, "configs": gen_configs, "seg": gen_seg, "seg_tt": gen_seg_tt, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
               "e2e": gen_e2e, "host_ref": gen_host_ref, "host_forced": gen_host_forced}
 
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
-    todo = sys.argv[1:] or list(GENERATORS)
+    todo = sys.argv[1:] or [g for g in GENERATORS if g != "linkage_scale"]   # (4 min of scipy: on request)
     torch.set_num_threads(8)
     for k in todo:
         GENERATORS[k]()

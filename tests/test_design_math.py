@@ -195,6 +195,124 @@ def _linkage_model(e, BLK):
     return Z, rescans
 
 
+def _linkage_step_model(e, BLK):
+    """numpy model of csrc/linkage.hip's r3 loop: ONE launch per step (step_kernel).  Every workgroup reduces the same
+    published records (minimum bound of its rows, that row's neighbour, exact flag) + the one row whose bound is fixed up
+    at the start of the launch, and all reach the same decision: MERGE (bound exact) or RESCAN (stale).  What a launch
+    reads was written by the PREVIOUS launch (the model keeps `pub` = the published copy and builds `new` separately);
+    words of the previous merge's pair are substituted, not read."""
+    n = len(e)
+    G = (n + BLK - 1) // BLK
+    x64 = e.astype(np.float64)
+    D = np.sqrt(((x64[:, None, :] - x64[None, :, :]) ** 2).sum(-1))
+    np.fill_diagonal(D, np.inf)
+    lb = D.min(axis=1)
+    nb = D.argmin(axis=1).astype(np.int64)
+    size = np.ones(n, dtype=np.int64)
+    cid = np.arange(n)
+    Z = np.zeros((n - 1, 4))
+    BIG = 2 ** 31 - 1
+    exf = np.ones(n, dtype=bool)        # bound of the row is exact (D[z, nb[z]] == lb[z])
+
+    def publish(excl):
+        recs = []
+        for w in range(G):
+            rows = np.arange(w * BLK, min((w + 1) * BLK, n))
+            vals = np.where(rows == excl, np.inf, lb[rows])
+            j = int(np.argmin(vals))                        # lowest row on ties
+            v, x = vals[j], int(rows[j])
+            y, exact = -1, False
+            if v < np.inf:
+                y = int(nb[x])
+                exact = y >= 0 and D[x, y] == v
+                # the kernel does not look D up: it keeps a per-row flag, maintained by the row's owner (below)
+                assert exact == bool(exf[x] and y >= 0), (x, y)
+            recs.append((v, x, y, exact))
+        return recs
+
+    def partial_minima(row):
+        parts = []
+        for w in range(G):
+            seg = row[w * BLK:(w + 1) * BLK]
+            j = int(np.argmin(seg))
+            parts.append((seg[j], w * BLK + j))
+        return parts
+
+    pub = dict(kind="none", k=0, rec=publish(-1), part=None)
+    launches = rescans = 0
+    while True:
+        prev = pub
+        if prev["kind"] == "done":
+            break
+        launches += 1
+        assert launches < 4 * n + 8
+        ev, ex, ey = np.inf, BIG, -1
+        if prev["kind"] in ("merge", "rescan"):             # fix-ups owed by the previous step (owner threads)
+            ev, idx = min(prev["part"], key=lambda t: (t[0], t[1]))
+            ex = prev["hi"] if prev["kind"] == "merge" else prev["x"]
+            ey = idx if ev < np.inf else -1
+            lb[ex], nb[ex], exf[ex] = ev, ey, ey >= 0
+            if prev["kind"] == "merge":
+                size[prev["hi"]] = prev["nlo"] + prev["nhi"]
+                cid[prev["hi"]] = n + prev["k"] - 1
+                size[prev["lo"]] = 0
+        k = prev["k"]
+        cand = [(v, x) for v, x, _, _ in prev["rec"]] + [(ev, ex)]
+        d, x = min(cand)
+        assert d < np.inf and 0 <= x < n
+        if x == ex:
+            y, exact = ey, True
+        else:
+            (y, exact), = [(yy, xx) for v, r, yy, xx in prev["rec"] if r == x and v == d]
+        exact = exact and y >= 0
+        if not exact:
+            rescans += 1
+            row = np.where(size != 0, D[x], np.inf)
+            pub = dict(kind="rescan", k=k, x=x, part=partial_minima(row), rec=publish(x))
+            continue
+        lo, hi = (x, y) if x < y else (y, x)
+        nlo, nhi = int(size[lo]), int(size[hi])
+        Z[k] = (min(cid[lo], cid[hi]), max(cid[lo], cid[hi]), d, nlo + nhi)
+        newrow = np.full(n, np.inf)
+        for z in range(n):
+            if z == hi:
+                D[hi, lo] = np.inf
+                lb[z], nb[z], exf[z] = np.inf, -1, False
+            elif z == lo:
+                lb[z], exf[z] = np.inf, False
+            elif size[z] != 0:
+                dxi, dyi = D[lo, z], D[hi, z]
+                sx, sy = float(nlo), float(nhi)
+                nd = np.sqrt((((sx * dxi * dxi) + (sy * dyi * dyi)) - (sx * sy * d * d) / (sx + sy)) / (sx + sy))
+                newrow[z] = nd
+                D[hi, z] = D[z, hi] = nd
+                if nb[z] == lo:
+                    nb[z], exf[z] = hi, nd == lb[z]         # a guess; lb stays a lower bound
+                elif nb[z] == hi:
+                    exf[z] = nd == lb[z]                    # the remembered neighbour's distance moved
+                if nd < lb[z]:
+                    lb[z], nb[z], exf[z] = nd, hi, True
+        pub = dict(kind="done" if k + 1 >= n - 1 else "merge", k=k + 1, lo=lo, hi=hi, nlo=nlo, nhi=nhi,
+                   part=partial_minima(newrow), rec=publish(-1))
+    return Z, rescans, launches
+
+
+def test_linkage_step_model_equals_scipy():
+    """The one-launch-per-step loop (r3) is again the same greedy centroid linkage: dendrogram equal to scipy's, and the
+    launch count stays below the 2 (n - 1) of the two-kernel loop."""
+    from scipy.cluster.hierarchy import linkage
+    r = np.random.default_rng(11)
+    for n, K, BLK in ((2, 1, 4), (3, 1, 4), (23, 3, 4), (60, 4, 8), (61, 5, 3), (40, 2, 64), (97, 6, 16), (200, 5, 32)):
+        cent = r.standard_normal((K, 12))
+        e = (cent[r.integers(0, K, n)] + 0.3 * r.standard_normal((n, 12))).astype(np.float32)
+        e /= np.linalg.norm(e, axis=1, keepdims=True)
+        Z, rescans, launches = _linkage_step_model(e, BLK)
+        Zs = linkage(e.astype(np.float64), method="centroid", metric="euclidean")
+        assert np.array_equal(Z[:, [0, 1, 3]], Zs[:, [0, 1, 3]]), (n, K, BLK)
+        assert np.abs(Z[:, 2] - Zs[:, 2]).max() < 1e-12
+        assert launches == n - 1 + rescans and launches <= 2 * (n - 1) + 1
+
+
 def test_linkage_algorithm_model_equals_scipy():
     """The restructured selection of csrc/linkage.hip (block minima, exact bound of the merged row, masked rescans) is a
     different route to the SAME greedy centroid linkage: the model reproduces scipy's dendrogram on clustered unit vectors

@@ -402,6 +402,46 @@ def test_linkage_centroid_equals_scipy(built_lib, gpu, C):
         assert np.array_equal(fcluster(Zs, thr, "distance"), fcluster(Zg, thr, "distance"))
 
 
+def test_linkage_centroid_30k_equals_scipy_golden(built_lib, gpu):
+    """the device linkage at n >= 30 000 against scipy's dendrogram of the same embeddings
+    (tests/golden/linkage_30k.npz, made by oracle/gen_golden.py linkage_scale — scipy needs minutes for it; the
+    embeddings are regenerated here from elementwise float32 operations on seeded draws and checked by their md5)."""
+    import hashlib
+    from pathlib import Path
+    import numpy as np
+    from scipy.cluster.hierarchy import fcluster
+    from diarizen_amd import ops
+    from oracle.gen_golden import linkage_scale_case
+    g = np.load(Path(__file__).parent / "golden" / "linkage_30k.npz")
+    e = linkage_scale_case()
+    assert len(e) >= 30000 and hashlib.md5(e.tobytes()).hexdigest() == str(g["emb_md5"])
+    Zg = ops.linkage_centroid(e)
+    assert np.array_equal(Zg[:, :2].astype(np.int32), g["ids"]) and np.array_equal(Zg[:, 3].astype(np.int32), g["size"])
+    assert np.abs(Zg[:, 2] - g["dist"]).max() <= 1e-12 * g["dist"].max()
+    Zs = np.column_stack([g["ids"].astype(np.float64), g["dist"], g["size"].astype(np.float64)])
+    for thr in (0.8, 1.5, 2.5):
+        assert np.array_equal(fcluster(Zs, thr, "distance"), fcluster(Zg, thr, "distance"))
+
+
+def test_linkage_step_loop_equals_two_kernel_loop(built_lib, gpu, monkeypatch):
+    """r3: one launch per step (merge or rescan, every workgroup selecting redundantly from the published records)
+    against the r2 loop (single-workgroup selection + wide update): bit-identical dendrograms, also for n that is not a
+    multiple of the 256-row block, n = 2, and duplicated embeddings (zero distances, ties broken by the lowest row)."""
+    import numpy as np
+    from diarizen_amd import ops
+    from oracle.gen_golden import linkage_scale_case
+    for n in (2, 3, 255, 256, 257, 1000, 4097):
+        e = linkage_scale_case(n=n, dim=32, K=4, seed=n)
+        if n >= 255:
+            e[7] = e[3]
+            e[100] = e[3]
+        Za = ops.linkage_centroid(e)
+        monkeypatch.setenv("DZN_LINKAGE_TWO_KERNEL", "1")
+        Zb = ops.linkage_centroid(e)
+        monkeypatch.delenv("DZN_LINKAGE_TWO_KERNEL")
+        assert np.array_equal(Za, Zb), n
+
+
 def test_cdist_cosine_equals_scipy(built_lib, gpu):
     """csrc/linkage.hip dzn_cdist_cosine vs scipy.spatial.distance.cdist(metric="cosine") (the assignment step,
     PA/pipelines/clustering.py:207-216): float64 with in-order sums.  scipy's own summation order is the library

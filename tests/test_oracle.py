@@ -211,3 +211,17 @@ def test_oracle_does_not_import_the_product():
             if fn.endswith(".py"):
                 src = open(os.path.join(root, d, fn)).read()
                 assert not re.search(forbidden, src, flags=re.M), (d, fn)
+
+
+def test_linkage_scale_golden_matches_its_generator():
+    """tests/golden/linkage_30k.npz (scipy's centroid dendrogram at n = 30 011, the reference's call): the embeddings it was
+    computed on regenerate to the same bytes here (elementwise float32 operations on seeded draws only), and the
+    dendrogram is a complete one (every merge id used once, the last cluster holds every embedding)."""
+    import hashlib
+    from oracle.gen_golden import linkage_scale_case
+    g = np.load(GOLD / "linkage_30k.npz")
+    e = linkage_scale_case()
+    n = len(e)
+    assert n >= 30000 and hashlib.md5(e.tobytes()).hexdigest() == str(g["emb_md5"])
+    assert g["ids"].shape == (n - 1, 2) and int(g["size"][-1]) == n
+    assert np.array_equal(np.sort(g["ids"].ravel()), np.arange(2 * n - 2))
