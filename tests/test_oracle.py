@@ -219,7 +219,7 @@ def test_linkage_scale_golden_matches_its_generator():
     dendrogram is a complete one (every merge id used once, the last cluster holds every embedding)."""
     import hashlib
     from oracle.gen_golden import linkage_scale_case
-    g = np.load(GOLD / "linkage_30k.npz")
+    g = np.load(os.path.join(GOLD, "linkage_30k.npz"))
     e = linkage_scale_case()
     n = len(e)
     assert n >= 30000 and hashlib.md5(e.tobytes()).hexdigest() == str(g["emb_md5"])
