@@ -46,7 +46,7 @@ DTYPE_NOTE = {"f32": "f32 (fp32 MFMA v_mfma_f32_16x16x4_f32)",
                      "data, norms, softmax, residual stream fp32"}
 PEAK_HBM_GBS = 8000.0
 TRAFFIC_SOURCE = ("committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x 2 "
-                  "correction; scripts/final_measure.sh -> profiles/) — not measured in this run")
+                  "correction; scripts/final_measure_r3.sh -> profiles/) — not measured in this run")
 ALT_STEPS = 5          # timed steps of every comparison leg (other fp32 modes, reduced precision)
 
 
@@ -66,10 +66,12 @@ def pmc_table(args):
     (separate passes per counter, gfx950 FETCH_SIZE correction: scripts/pmc_traffic.py, scripts/pmc_mfma.py).
     bench.py cannot run rocprofv3 on itself, so the table is read from profiles/ and only when the workload matches
     the one the passes were taken on; otherwise `traffic` is null."""
-    path = ROOT / "profiles" / f"r2_pmc_{args.precision}_30min_b{args.batch}.json"
-    if not path.exists() or args.minutes != 30.0 or args.model != "wavlm_large_s80_md" or args.window != 8.0:
+    found = sorted((ROOT / "profiles").glob(f"r*_pmc_{args.precision}_30min_b{args.batch}.json"))   # newest round last
+    if not found or args.minutes != 30.0 or args.model != "wavlm_large_s80_md" or args.window != 8.0:
         return None
-    return json.loads(path.read_text())
+    table = json.loads(found[-1].read_text())
+    table["_file"] = f"profiles/{found[-1].name}"
+    return table
 
 
 def pmc_lookup(table, kernel_class: str, field: str):
@@ -431,7 +433,7 @@ def main():
                             "peak": round(PEAK_TFLOPS[prec], 1), "unit": "TFLOP/s",
                             "frac": round(ach / PEAK_TFLOPS[prec], 4),
                             "traffic": pmc_lookup(traffic, top["name"], "hbm_bytes_per_launch"),
-                            "traffic_source": TRAFFIC_SOURCE if traffic else None,
+                            "traffic_source": f"{TRAFFIC_SOURCE} [{traffic.get('_file')}]" if traffic else None,
                             "launches": top["launches"],
                             "avg_launch_ms": round(top["ms"] / top["launches"], 4),
                             "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 3),
