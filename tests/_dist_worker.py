@@ -54,4 +54,27 @@ if rank == 0:
     assert torch.equal(emb.cpu(), full.embeddings.cpu()), "sharded embeddings differ"
     print(f"DIST_OK backend={backend} world={world} windows={C}")
 dist.barrier()
+eng.close()
+
+# ---- the whole pipeline under the process group: every rank decodes only the byte range of its windows (audio.WavSource),
+# runs them, the results are all-gathered with the block-partition assertion, rank 0 runs the host stage.  Its RTTM must be
+# the committed 1-GPU golden (tests/golden/e2e_EN2002a_30s.rttm — the RTTM test_pipeline_gpu.py holds the unsharded
+# pipeline to).
+if os.environ.get("DZN_TEST_RTTM", "1") == "1":
+    import copy
+    from diarizen_amd.pipeline import DiariZenPipeline
+    from oracle.gen_golden import E2E_CONFIG
+    gold = Path(__file__).resolve().parent / "golden"
+    big = get_seg_config("wavlm_large_s80_md")
+    conf = copy.deepcopy(E2E_CONFIG)
+    conf["inference"]["args"]["batch_size"] = 16
+    pipe = DiariZenPipeline(None, None, config=conf, device=dev, precision="f32h",
+                            seg_state=turn_taking_state_dict(big, 0), emb_state=emb_state_dict(0))
+    ann = pipe(str(gold / "EN2002a_30s.wav"), sess_name="EN2002a")
+    if rank == 0:
+        assert ann.to_rttm() == (gold / "e2e_EN2002a_30s.rttm").read_text(), "sharded pipeline RTTM != 1-GPU golden"
+        print(f"DIST_RTTM_OK backend={backend} world={world} load_s={pipe.timings['load_s']:.3f}")
+    else:
+        assert ann is None
+    dist.barrier()
 dist.destroy_process_group()

@@ -27,11 +27,16 @@ def _run(nproc, backend, port):
 def test_window_shard_gather_rccl_world1(built_lib, gpu):
     r = _run(1, "nccl", 29611)
     assert r.returncode == 0 and "DIST_OK backend=nccl world=1" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "DIST_RTTM_OK backend=nccl world=1" in r.stdout
 
 
 def test_window_shard_gather_two_ranks_one_device(built_lib, gpu):
     r = _run(2, "nccl", 29612)
     if r.returncode == 0 and "DIST_OK backend=nccl world=2" in r.stdout:
+        assert "DIST_RTTM_OK backend=nccl world=2" in r.stdout
         return
     r2 = _run(2, "gloo", 29613)
     assert r2.returncode == 0 and "DIST_OK backend=gloo world=2" in r2.stdout, (r.stderr[-1500:], r2.stdout[-1500:], r2.stderr[-3000:])
+    # (r3) the 2-rank rehearsal of the WHOLE pipeline (range decode, gather with the partition assertion, host stage on
+    # rank 0) reproduces the 1-GPU RTTM golden
+    assert "DIST_RTTM_OK backend=gloo world=2" in r2.stdout, r2.stdout[-1500:]
