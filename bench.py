@@ -194,18 +194,6 @@ def e2e_leg(args, dev, wave_host):
                     "turn-taking weights"}
 
 
-class SynthSource:
-    """lazy recording for DiariZenPipeline.device_stage: a rank synthesises only the samples it asks for"""
-
-    def __init__(self, num_samples: int, seed: int = 3407):
-        self.num_samples, self.seed = num_samples, seed
-
-    def read(self, start: int, n: int):
-        from testkit.synth import synth_recording_range
-        n = max(0, min(n, self.num_samples - start))
-        return synth_recording_range(start, n, total=self.num_samples, seed=self.seed).numpy()
-
-
 def strong_leg(args, dev, rank, world, minutes):
     """BASELINE configs[3]: ONE recording of `minutes` whose windows are sharded over the ranks, END TO END — each rank
     reads + uploads only its slice, runs segmentation + embeddings on its windows, one RCCL all-gather per tensor, then
@@ -226,7 +214,36 @@ def strong_leg(args, dev, rank, world, minutes):
                                     "ahc_criterion": "distance", "ahc_threshold": 0.1, "min_cluster_size": 13}}}
     pipe = DiariZenPipeline(None, None, config=copy.deepcopy(conf), device=dev, precision=args.precision,
                             seg_state=turn_taking_state_dict(cfg, 0), emb_state=emb_state_dict(0))
-    src = SynthSource(int(minutes * 60 * 16000))
+    # the recording is a real RIFF file on local disk, so the timed region pays the byte-range decode a deployment pays
+    # (audio.WavSource), not the synthesis: every rank synthesises the samples of ITS window block (1 / world of the
+    # work) and writes them at their byte offset of one shared 16-bit PCM file; blocks overlap by one window of halo
+    # with identical data
+    import struct
+    from diarizen_amd import dist as dz_dist
+    from diarizen_amd.audio import WavSource
+    from testkit.synth import synth_recording_range
+    total = int(minutes * 60 * 16000)
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dzn_strong_{int(minutes)}min_{os.getuid()}.wav")
+    if rank == 0:
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 36 + 2 * total) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16)
+                    + b"data" + struct.pack("<I", 2 * total))
+            f.truncate(44 + 2 * total)
+    if world > 1:
+        dist.barrier()
+    r = pipe._runner
+    c0, c1 = dz_dist.shard_range(r.num_windows(total), rank, world)
+    lo, n = c0 * r.step, ((c1 - c0 - 1) * r.step + r.window if c1 > c0 else 0)
+    n = max(0, min(n, total - lo))
+    if n:
+        x = synth_recording_range(lo, n, total=total)
+        with open(path, "r+b") as f:
+            f.seek(44 + 2 * lo)
+            f.write((x.numpy() * 32767.0).astype("<i2").tobytes())
+        del x
+    if world > 1:
+        dist.barrier()
+    src = WavSource(path)
     best = None
     for _ in range(2):                       # first pass warms allocations / tables / RCCL channels
         if world > 1:
@@ -249,6 +266,10 @@ def strong_leg(args, dev, rank, world, minutes):
     if rank != 0:
         return None
     audio_s = src.num_samples / 16000.0
+    try:
+        os.remove(path)
+    except OSError:
+        pass
     return {"workload": f"{args.model} full pipeline, ONE {minutes:g} min synthetic recording, {seg.shape[0]} windows sharded over "
                         f"{world} rank(s) (contiguous blocks), all-gather, host stage on rank 0",
             "scaling": "strong", "n_gpus": world, "audio_s": audio_s,
@@ -257,7 +278,7 @@ def strong_leg(args, dev, rank, world, minutes):
             "device_only_audio_seconds_per_s": round(audio_s / dev_s, 1),
             "amdahl_serial_frac": round(host_s / (dev_s + host_s), 4),
             "speakers": len(ann.labels()), "rttm_lines": len(ann.to_rttm().splitlines()),
-            "note": "sharded_s = max over ranks of [slice synthesis + upload + segmentation + embeddings + RCCL all-gather + D2H]; "
+            "note": "sharded_s = max over ranks of [byte-range decode of the rank's block of a 16-bit PCM file + upload + segmentation + embeddings + RCCL all-gather + D2H]; "
                     "serial_host_s = rank 0's counting + AHC + assignment + reconstruction + RTTM; seeded turn-taking weights"}
 
 

@@ -1,16 +1,10 @@
-# round 3: the whole GPU suite + smoke + the default bench line
+# round 3: the whole GPU suite + smoke + the bench's strong-scaling leg (one 4 h file) at world size 1
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r3l}; mkdir -p $O
-( time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 | cut -c1-400 ) > $O/all_gpu_tests.log 2>&1; cat $O/all_gpu_tests.log
+O=gpurun_out/${1:-r3full}; mkdir -p $O
+export DZN_DECISION_WINDOWS=32
+( time timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -15 | cut -c1-400 ) > $O/all_gpu_tests.log 2>&1; cat $O/all_gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | cut -c1-300
-timeout 300 python scripts/probe_kernel_class.py 374 stem conv01 layernorm conv3x3 2>&1 | tail -6
-( time timeout 900 python bench.py --no-alt ) > $O/bench_default.json 2> $O/bench_default.err
-python - <<PY
+timeout 900 python bench.py --steps 1 --warmup 1 --no-alt --no-cpu-baseline --strong-minutes 240 > $O/bench_with_strong_4h_leg.json 2> $O/bench_strong.err; python - <<PY
 import json
-try:
-    d=json.loads(open("$O/bench_default.json").read().strip().splitlines()[-1])
-    print("default", d["value"], d["ms_per_step"], d.get("e2e"))
-    for k in d["kernels"][:10]: print("   ", {a:b for a,b in k.items() if a!='alg_bytes_per_launch'})
-except Exception as e:
-    print("bench failed", e); print(open("$O/bench_default.err").read()[-2500:])
+d=json.loads(open("$O/bench_with_strong_4h_leg.json").read().strip().splitlines()[-1]); print(d["value"], d.get("strong_scaling_e2e"))
 PY
