@@ -414,12 +414,13 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
 #endif
   }
   if constexpr (NP == 2) {
-    // (r3) the streamed ping-pong form (gemm_pp.hip, 256 x 192 tiles, 8 wavefronts) for the big plain contractions whose
-    // width is a multiple of 192 (q/k/v and FFN-in of the pruned layers: 960, 1152, 768, 1920, 576, ...): 340 / 371
-    // TFLOP/s in the pipeline where the 128 x 128 tile has 303 / 321 (N = 960 / 1920, profiles/r3_gemm_pq_probe.txt).
-    // Other widths lose to tile padding (N = 1024: 272 vs 280) and stay on the 128-wide tile.  DZN_GEMM_NO_PQ=1 disables.
-    static const bool no_pq = getenv("DZN_GEMM_NO_PQ") != nullptr;
-    if (!no_pq && d.nz <= 1 && d.M >= 16384 && d.K >= 640 && d.N % 192 == 0 && !d.a_rowoff)
+    // (r3) DZN_GEMM_PQ=1: the streamed ping-pong form (gemm_pp.hip, 256 x 192 tiles, 8 wavefronts) for the big plain
+    // contractions whose width is a multiple of 192 (q/k/v and FFN-in of the pruned layers: 960, 1152, 768, 1920, ...):
+    // 335 TFLOP/s on those launches where the 128 x 128 tile has ~305, but only +0.5 % on the step (1627.9 vs 1620.3
+    // audio-s/s, same box, profiles/r3_gemm_pq_probe.txt) — inside the box-to-box spread, so the default keeps ONE
+    // contraction kernel; other widths lose to tile padding (N = 1024: 272 vs 280).
+    static const bool pq = getenv("DZN_GEMM_PQ") != nullptr;
+    if (pq && d.nz <= 1 && d.M >= 16384 && d.K >= 640 && d.N % 192 == 0 && !d.a_rowoff)
       return launch_gemm_pp(d, s, NP, "pq192r3");
   }
   // launch bounds pin the occupancy the tile was tuned at (r3: the pipelined epilogue gives the register allocator
