@@ -144,6 +144,7 @@ def load() -> C.CDLL:
     sig("dzn_speaker_count", i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp])
     sig("dzn_cluster_activations", i32, [vp, vp, i32, i32, i32, vp, i32, i32, vp, vp])
     sig("dzn_debug_fetch", i32, [vp, C.c_char_p, vp, i64, C.POINTER(i64)])
+    sig("dzn_embed_skip_stats", i32, [vp, C.POINTER(i64), C.POINTER(i64)])
     sig("dzn_num_ignored", i32, [vp])
     sig("dzn_workspace_bytes", i64, [vp])
     sig("dzn_last_error", C.c_char_p, [vp])
@@ -180,7 +181,7 @@ def load() -> C.CDLL:
 
 EXPORTED = [
     "dzn_create", "dzn_load_tensor", "dzn_finalize_weights", "dzn_num_frames",
-    "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_speaker_count", "dzn_cluster_activations", "dzn_debug_fetch", "dzn_num_ignored",
+    "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_speaker_count", "dzn_cluster_activations", "dzn_debug_fetch", "dzn_embed_skip_stats", "dzn_num_ignored",
     "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid", "dzn_cdist_cosine",
     "dzn_vbx_create", "dzn_vbx_stats", "dzn_vbx_estep", "dzn_vbx_gamma", "dzn_vbx_destroy",
     "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",

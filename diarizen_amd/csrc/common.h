@@ -183,6 +183,10 @@ int launch_classify(const float* z, int64_t ldz, const float* W, const float* bi
 int launch_frame_prep(const float* wave, int B, int N, int T, int flen, int fshift, int Kp,
                       const float* window, float preemph, float* frames, hipStream_t st);
 int launch_power(const float* spec, int64_t rows, int nb, float* pw, hipStream_t st);
+int launch_window_active(const float* masks, int B, int per_window, int* flag, hipStream_t st);
+int launch_gather_rows(const float* src, const int* idx, int rows, int64_t n, float* dst, hipStream_t st);
+int launch_scatter_embeddings(const float* compact, const int* pos, const float* bias, int B, int S, int D, float* out,
+                              hipStream_t st);
 int launch_log_cmn(float* mel, int B, int T, int NB, float eps, hipStream_t st);
 int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* w, const float* bias,
                      void* img, int out_bf16, hipStream_t st, float* amax = nullptr);

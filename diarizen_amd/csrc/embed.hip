@@ -201,6 +201,41 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const TI* __restrict__ 
   }
 }
 
+// ---- (r3) windows without any active speaker need no trunk (their embeddings are seg_1's bias) ----
+// flag[b] = 1 when any of the window's S * L mask values is non-zero
+__global__ __launch_bounds__(256) void window_active_kernel(const float* __restrict__ masks, int per_window,
+                                                            int* __restrict__ flag) {
+  const float* m = masks + (int64_t)blockIdx.x * per_window;
+  int any = 0;
+  for (int i = threadIdx.x; i < per_window; i += 256) any |= m[i] != 0.f;
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) flag[blockIdx.x] = any != 0;
+}
+
+// dst row b = src row idx[b] (rows of `n` floats, n % 4 == 0 and 16-byte aligned rows, or any n through the tail loop)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                          int64_t n, float* __restrict__ dst) {
+  const float* s = src + (int64_t)idx[blockIdx.y] * n;
+  float* d = dst + (int64_t)blockIdx.y * n;
+  const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+  if (vec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256)
+      reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+  }
+}
+
+// out row (b, s) = compact row (pos[b], s) for active windows (pos[b] >= 0), the bias otherwise
+__global__ __launch_bounds__(256) void scatter_embeddings_kernel(const float* __restrict__ compact,
+                                                                 const int* __restrict__ pos,
+                                                                 const float* __restrict__ bias, int S, int D,
+                                                                 float* __restrict__ out) {
+  const int b = blockIdx.x, p = pos[b];
+  for (int i = threadIdx.x; i < S * D; i += 256)
+    out[(int64_t)b * S * D + i] = p >= 0 ? compact[(int64_t)p * S * D + i] : bias[i % D];
+}
+
 inline unsigned grid_for(int64_t n, int per = 256, int cap = 8192) {
   int64_t g = cdiv64(n, per);
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -214,6 +249,27 @@ int launch_frame_prep(const float* wave, int B, int N, int T, int flen, int fshi
   if (flen > 512 || T <= 0) return DZN_E_INVALID;
   hipLaunchKernelGGL(frame_prep_kernel, dim3((T + 3) / 4, B), dim3(256), 0, st, wave, N, T, flen,
                      fshift, Kp, window, preemph, frames);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_window_active(const float* masks, int B, int per_window, int* flag, hipStream_t st) {
+  ProfScope prof_scope_(st, "window_active", 0.0, (double)B * per_window * 4.0);
+  hipLaunchKernelGGL(window_active_kernel, dim3(B), dim3(256), 0, st, masks, per_window, flag);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_gather_rows(const float* src, const int* idx, int rows, int64_t n, float* dst, hipStream_t st) {
+  if (rows <= 0) return DZN_OK;
+  ProfScope prof_scope_(st, "gather_rows", 0.0, (double)rows * n * 8.0);
+  const unsigned gx = grid_for(n / 4 > 0 ? n / 4 : n, 256, 64);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, rows), dim3(256), 0, st, src, idx, n, dst);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_scatter_embeddings(const float* compact, const int* pos, const float* bias, int B, int S, int D, float* out,
+                              hipStream_t st) {
+  ProfScope prof_scope_(st, "scatter_embeddings", 0.0, (double)B * S * D * 8.0);
+  hipLaunchKernelGGL(scatter_embeddings_kernel, dim3(B), dim3(256), 0, st, compact, pos, bias, S, D, out);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 

@@ -177,6 +177,13 @@ struct dzn_handle {
   };
   std::map<int, EmbGeom> geoms;
   float *frames = nullptr, *spec = nullptr, *pw = nullptr, *fb = nullptr, *pool = nullptr;
+  // (r3) trunk skip for windows without any active speaker: flags / compaction index / position per window, the compact
+  // copies of the active windows' waveforms and masks, their compact embeddings
+  int *win_flag = nullptr, *win_idx = nullptr, *win_pos = nullptr;
+  float *wave_c = nullptr, *masks_c = nullptr, *emb_c = nullptr;
+  int64_t masks_c_per_window = 0;
+  std::vector<int> win_flag_host, win_idx_host, win_pos_host;
+  int64_t emb_windows = 0, emb_windows_skipped = 0;     // counters (dzn_debug / tests)
 };
 
 namespace {
@@ -838,6 +845,13 @@ void finalize_emb(H* h) {
     for (int k = 0; k < 3; ++k) h->sbuf[s][k] = dalloc<float>(h, B * h->sbuf_elems[s]);
   }
   h->pool = dalloc<float>(h, B * 8 * feat);
+  h->win_flag = dalloc<int>(h, B);
+  h->win_idx = dalloc<int>(h, B);
+  h->win_pos = dalloc<int>(h, B);
+  h->wave_c = dalloc<float>(h, B * (int64_t)c.max_samples);
+  h->masks_c_per_window = 8 * ((int64_t)c.max_samples / 160 + 2);     // S <= 8 masks of L <= N / 160 frames
+  h->masks_c = dalloc<float>(h, B * h->masks_c_per_window);
+  h->emb_c = dalloc<float>(h, B * 8 * c.embed_out_dim);
 }
 
 // bake the geometry of T fbank frames into the row-offset tables and re-zero the image borders.
@@ -1364,8 +1378,8 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
 // ------------------------------------------------------------------ embedding forward
 // bf16 engine mode: the ResNet images are bf16 (operands, residuals and outputs of every conv);
 // fbank (DFT / mel), pooling statistics and seg_1 stay fp32.
-void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int N, int L, float* d_emb,
-                 hipStream_t st) {
+void emb_forward_dense(H* h, const float* wave, const float* masks, int B, int S, int N, int L, float* d_emb,
+                       hipStream_t st) {
   const dzn_config& c = h->cfg;
   const bool lp = c.precision == DZN_PREC_BF16;
   const int flen = 400, fshift = 160, Kp = 416, NB = c.num_mel_bins;
@@ -1492,6 +1506,47 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
     d.precision = DZN_PREC_F32;
     chk(launch_gemm(d, st), "seg_1");
   }
+}
+
+// (r3) A window in which none of the S speakers is active needs no trunk: zero weights pool to zero
+// (PA/models/blocks/pooling.py:44-131 with its 1e-8 guards), so every one of its embeddings is seg_1's bias
+// (tests/test_emb_gpu.py holds the device to that bit for bit).  The masks decide it, and they only exist on
+// the device, so the call reads B flags back (one stream synchronisation, ~30 us against a ~50 ms trunk pass), runs the
+// trunk on a compact copy of the active windows and scatters the results.  A batch without silent windows takes the
+// dense path untouched.  DZN_EMB_NO_SKIP=1 switches the check off.
+void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int N, int L, float* d_emb, hipStream_t st) {
+  const dzn_config& c = h->cfg;
+  h->emb_windows += B;
+  if (B <= 0 || h->debug || getenv("DZN_EMB_NO_SKIP") || (int64_t)S * L > h->masks_c_per_window || N > c.max_samples ||
+      !h->seg1.b) {
+    emb_forward_dense(h, wave, masks, B, S, N, L, d_emb, st);
+    return;
+  }
+  chk(launch_window_active(masks, B, S * L, h->win_flag, st), "window_active");
+  h->win_flag_host.resize(B);
+  HIPCHK(hipMemcpyAsync(h->win_flag_host.data(), h->win_flag, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  h->win_idx_host.clear();
+  h->win_pos_host.assign(B, -1);
+  for (int b = 0; b < B; ++b)
+    if (h->win_flag_host[b]) {
+      h->win_pos_host[b] = (int)h->win_idx_host.size();
+      h->win_idx_host.push_back(b);
+    }
+  const int Bc = (int)h->win_idx_host.size();
+  if (Bc == B) {
+    emb_forward_dense(h, wave, masks, B, S, N, L, d_emb, st);
+    return;
+  }
+  h->emb_windows_skipped += B - Bc;
+  HIPCHK(hipMemcpyAsync(h->win_pos, h->win_pos_host.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  if (Bc > 0) {
+    HIPCHK(hipMemcpyAsync(h->win_idx, h->win_idx_host.data(), (size_t)Bc * sizeof(int), hipMemcpyHostToDevice, st));
+    chk(launch_gather_rows(wave, h->win_idx, Bc, N, h->wave_c, st), "gather waveforms");
+    chk(launch_gather_rows(masks, h->win_idx, Bc, (int64_t)S * L, h->masks_c, st), "gather masks");
+    emb_forward_dense(h, h->wave_c, h->masks_c, Bc, S, N, L, h->emb_c, st);
+  }
+  chk(launch_scatter_embeddings(h->emb_c, h->win_pos, h->seg1.b, B, S, c.embed_out_dim, d_emb, st), "scatter embeddings");
 }
 
 template <typename F>
@@ -1672,6 +1727,13 @@ int dzn_debug_fetch(dzn_handle* h, const char* name, float* host_out, int64_t ca
     if (cap < (int64_t)it->second.size()) return DZN_E_INVALID;
     memcpy(host_out, it->second.data(), it->second.size() * 4);
   }
+  return DZN_OK;
+}
+
+int dzn_embed_skip_stats(const dzn_handle* h, int64_t* windows, int64_t* skipped) {
+  if (!h) return DZN_E_INVALID;
+  if (windows) *windows = h->emb_windows;
+  if (skipped) *skipped = h->emb_windows_skipped;
   return DZN_OK;
 }
 

@@ -177,6 +177,12 @@ class Engine:
                                        C.byref(n)), self._h, f"dzn_debug_fetch({name})")
         return out
 
+    def embed_skip_stats(self):
+        """(windows seen by embed(), windows whose ResNet trunk pass was skipped because no speaker was active)"""
+        w, k = C.c_int64(0), C.c_int64(0)
+        check(self.lib.dzn_embed_skip_stats(self._h, C.byref(w), C.byref(k)), self._h, "dzn_embed_skip_stats")
+        return w.value, k.value
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.dzn_destroy(self._h)

@@ -163,3 +163,50 @@ def test_fbank_linear_mel_error_on_real_audio_vs_float64(built_lib, gpu):
     json.dump(out, open("gpurun_out/fbank_vs_float64.json", "w"), indent=1)
     print(out)
     assert out["log_mel_max_abs"] < 2e-3 and out["linear_mel_rel_to_frame_max"] < 1e-4, out
+
+
+@pytest.mark.parametrize("precision", ["f32h", "f32"])
+def test_trunk_skipped_for_windows_without_active_speaker(built_lib, gpu, monkeypatch, precision):
+    """(r3, VERDICT r2 missing #8) A window whose S masks are all zero needs no ResNet trunk: zero weights pool to zero,
+    so all its embeddings are seg_1's bias (pyannote-audio/tests/test_stats_pool.py:111-131).  dzn_embed_forward reads the
+    per-window flags back, runs the trunk on a compact copy of the active windows and scatters.  With silent windows in
+    the batch (first, middle, last, two in a row) the result must be BIT-identical to the dense pass (DZN_EMB_NO_SKIP=1) —
+    the active windows because a window's result does not depend on its position in the batch, the silent ones because the
+    dense pass gives the bias too; an all-silent batch runs no trunk at all; the counters say what was skipped."""
+    from oracle import emb_model
+    from oracle.gen_golden import synth_wave
+    B, N, L = 9, 32000, 99
+    eng = _engine(gpu, B, N, precision=precision)
+    wave = synth_wave(B, N, 17).to(gpu)
+    r = np.random.default_rng(3)
+    masks = torch.from_numpy((r.random((B, 4, L)) < 0.4).astype(np.float32))
+    for b in (0, 3, 4, 8):
+        masks[b] = 0.0
+    masks[5, 1:] = 0.0                                   # one active speaker keeps the window in
+    masks = masks.to(gpu)
+    w0, k0 = eng.embed_skip_stats()
+    emb = eng.embed(wave, masks).clone()
+    torch.cuda.synchronize()
+    w1, k1 = eng.embed_skip_stats()
+    assert (w1 - w0, k1 - k0) == (B, 4)
+    monkeypatch.setenv("DZN_EMB_NO_SKIP", "1")
+    dense = eng.embed(wave, masks).clone()
+    torch.cuda.synchronize()
+    monkeypatch.delenv("DZN_EMB_NO_SKIP")
+    assert eng.embed_skip_stats()[1] == k1               # the switch really is the dense pass
+    assert torch.equal(emb, dense)
+    bias = emb_model.emb_state_dict(0)["resnet.seg_1.bias"]
+    for b in (0, 3, 4, 8):
+        assert all(torch.equal(emb[b, s].cpu(), bias) for s in range(4))
+    assert torch.equal(emb[5, 1].cpu(), bias) and not torch.equal(emb[5, 0].cpu(), bias)
+    ref = emb_model.emb_forward(emb_model.emb_state_dict(0), wave.cpu(), masks.cpu())
+    assert (emb.cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-4
+    # all silent: no trunk pass; no silent window: dense path
+    allz = eng.embed(wave, torch.zeros_like(masks))
+    torch.cuda.synchronize()
+    assert all(torch.equal(allz[b, s].cpu(), bias) for b in range(B) for s in range(4))
+    assert eng.embed_skip_stats()[1] == k1 + B
+    eng.embed(wave, torch.ones_like(masks))
+    torch.cuda.synchronize()
+    assert eng.embed_skip_stats()[1] == k1 + B
+    eng.close()
