@@ -90,9 +90,22 @@ def single_speaker_frame_mask(seg: np.ndarray, min_frames: int) -> np.ndarray:
     return n >= min_frames
 
 
+def active_speakers(seg: np.ndarray) -> np.ndarray:
+    """[C, L, S] -> bool [C, S]: the local speaker is active in at least one frame (`np.sum(seg, axis=1) > 0`,
+    PA/pipelines/clustering.py:111-131, diarizen/pipelines/inference.py:160).  u8 decisions with S == 4 are OR-ed as one
+    32-bit word per frame: 5 ms instead of 60 ms for the strided byte reduction at 4 h (17 991 x 399 x 4)."""
+    if seg.dtype != np.uint8:
+        return np.sum(seg, axis=1) > 0
+    C, L, S = seg.shape
+    if S == 4 and L > 0:
+        w = np.ascontiguousarray(seg).view(np.uint32).reshape(C, L)
+        return np.bitwise_or.reduce(w, axis=1).view(np.uint8).reshape(C, 4) != 0
+    return seg.any(axis=1)
+
+
 def filter_embeddings(embeddings: np.ndarray, seg: np.ndarray, min_frames_ratio: float = 0.1,
                       max_num_embeddings: float = np.inf):
-    active = seg.any(axis=1) if seg.dtype == np.uint8 else np.sum(seg, axis=1) > 0
+    active = active_speakers(seg)
     valid = ~np.any(np.isnan(embeddings), axis=2)
     min_frames = round(min_frames_ratio * seg.shape[1])
     keep = active * valid * single_speaker_frame_mask(seg, min_frames)

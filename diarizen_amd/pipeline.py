@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import audio as audio_io
-from .clustering import AgglomerativeClustering, VBxClustering
+from .clustering import AgglomerativeClustering, VBxClustering, active_speakers
 from .configs import RESNET34
 from .core import Annotation, SlidingWindow
 from .engine import Engine
@@ -76,7 +76,7 @@ def run_host_stage(seg: np.ndarray, emb: np.ndarray, *, chunks: SlidingWindow, c
                             segmentations=seg if hard_decisions else segf, min_clusters=min_speakers,
                             max_clusters=max_speakers)
     count.data = np.minimum(count.data, max_speakers).astype(np.int8)
-    inactive = ~seg.any(axis=1) if hard_decisions else np.sum(segf, axis=1) == 0
+    inactive = ~active_speakers(seg) if hard_decisions else np.sum(segf, axis=1) == 0
     hard = np.array(hard, copy=True)
     hard[inactive] = -2
     res = post.reconstruct(hard, count) if post is not None else None
