@@ -137,6 +137,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
     __syncthreads();
     if (j + 1 < nmine) fetch(tile_of(j + 1));   // in flight during the MFMA phase
 
+    // (r3) the residual rows of this tile travel during the multiply phase instead of after it (one HBM round trip of
+    // the epilogue hidden; 16 more registers live across the MFMAs)
+    float* ob = a.out + (int64_t)b * img;
+    const float* rb = a.R ? a.R + (int64_t)b * img : nullptr;
+    float4 r4[4];
+    bool okm[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int q = q0 + mh * 64 + mb * 16 + lr;
+      const int col = q % P;
+      okm[mb] = q < P + npix && col >= 1 && col <= a.Ws;
+      r4[mb] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (NP == 2) {     // (the three-term variant has no registers to spare: it loads in the epilogue)
+        if (rb && okm[mb]) r4[mb] = *reinterpret_cast<const float4*>(rb + (int64_t)q * 32 + nb * 16 + lq * 4);
+      }
+    }
+
     // ---- multiply: 4 pixel blocks x 9 taps x 6 products; accumulators D[oc][pixel]; two pixel blocks
     // at a time keeps the fragment registers at 24 (the strip prefetch needs the rest) ----
     f32x4 acc[4];
@@ -167,13 +184,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
       }
 
     // ---- epilogue: lane holds pixel lr of block mb, output channels nb*16 + 4 lq .. +3 ----
-    float* ob = a.out + (int64_t)b * img;
-    const float* rb = a.R ? a.R + (int64_t)b * img : nullptr;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const int q = q0 + mh * 64 + mb * 16 + lr;
-      const int col = q % P;
-      if (q < P + npix && col >= 1 && col <= a.Ws) {
+      if (okm[mb]) {
         const int64_t o = (int64_t)q * 32 + nb * 16 + lq * 4;
         f32x4 v = acc[mb];
         if constexpr (NP == 2) {   // undo the exact power-of-two operand scales
@@ -185,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (rb) {
-          const float4 r4 = *reinterpret_cast<const float4*>(rb + o);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          if constexpr (NP != 2) r4[mb] = *reinterpret_cast<const float4*>(rb + o);
+          v[0] += r4[mb].x; v[1] += r4[mb].y; v[2] += r4[mb].z; v[3] += r4[mb].w;
         }
         if (a.post_relu) {
 #pragma unroll
