@@ -238,7 +238,8 @@ def strong_leg(args, dev, rank, world, minutes):
     from diarizen_amd.audio import WavSource
     from testkit.synth import synth_recording_range
     total = int(minutes * 60 * 16000)
-    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dzn_strong_{int(minutes)}min_{os.getuid()}.wav")
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"),      # one name for all ranks of THIS job
+                        f"dzn_strong_{int(minutes)}min_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}.wav")
     if rank == 0:
         with open(path, "wb") as f:
             f.write(b"RIFF" + struct.pack("<I", 36 + 2 * total) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16)
