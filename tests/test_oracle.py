@@ -225,3 +225,31 @@ def test_linkage_scale_golden_matches_its_generator():
     assert n >= 30000 and hashlib.md5(e.tobytes()).hexdigest() == str(g["emb_md5"])
     assert g["ids"].shape == (n - 1, 2) and int(g["size"][-1]) == n
     assert np.array_equal(np.sort(g["ids"].ravel()), np.arange(2 * n - 2))
+
+
+def test_fbank_equals_the_function_transformers_ships_in_place_of_torchaudio_kaldi_fbank():
+    """a16: torchaudio is absent, so `torchaudio.compliance.kaldi.fbank` itself cannot be run.  transformers'
+    Speech2TextFeatureExtractor calls exactly that function when torchaudio is installed and, when it is not, its own
+    numpy path which its maintainers keep equivalent (transformers/models/speech_to_text/
+    feature_extraction_speech_to_text.py:_extract_fbank_features: povey window, 25 / 10 ms, pre-emphasis 0.97, DC removal,
+    kaldi mel scale, log floor 1.19e-7 = torchaudio's defaults).  WeSpeaker's call differs from those defaults by
+    `window_type="hamming"` only (PA/models/embedding/wespeaker/__init__.py:69-103), so the SAME method with its window
+    swapped to hamming is the closest runnable stand-in for the reference's fbank: the oracle's restatement equals it to
+    1e-6 in float64 and 4e-5 in float32 (float32 rounding of the power spectrum, see the test above)."""
+    fx = pytest.importorskip("transformers.models.speech_to_text.feature_extraction_speech_to_text")
+    au = pytest.importorskip("transformers.audio_utils")
+    from oracle import emb_model
+    from oracle.gen_golden import synth_wave
+    fe = fx.Speech2TextFeatureExtractor(feature_size=80, num_mel_bins=80, sampling_rate=16000, dither=0.0)
+    fe.window = au.window_function(400, "hamming", periodic=False)
+    w = synth_wave(1, 16000, 5)[0]
+    theirs = fe._extract_fbank_features(w.numpy().astype(np.float64))        # scales by 2**15 itself
+    mine = emb_model.kaldi_fbank(w * (1 << 15)).numpy()
+    assert theirs.shape == mine.shape == (98, 80)
+    assert np.abs(theirs - mine).max() <= 6e-5
+    torch.set_default_dtype(torch.float64)
+    try:
+        mine64 = emb_model.kaldi_fbank((w * (1 << 15)).double()).numpy()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert np.abs(theirs - mine64).max() <= 3e-6
