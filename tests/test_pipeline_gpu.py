@@ -221,3 +221,26 @@ def test_streaming_session_equals_offline(pipeline, tmp_path):
     assert sess.stats["uploads"] >= len(chunks)
     with pytest.raises(RuntimeError):
         sess.feed(chunks[0])
+
+
+def test_eval_scp_harness_on_the_fixture(built_lib, gpu, tmp_path):
+    """BASELINE configs[4] harness (scripts/eval_scp.py = recipes/diar_ssl/infer_avg.py:28-97 + the scoring of
+    run_stage.sh:84-91): a Kaldi wav.scp of two sessions (the fixture under two names), the reference RTTM of the set, a
+    UEM — one RTTM per session is written and equals the golden, DER is 0 per file and overall, a UEM that drops the second
+    half of a session drops its reference speech from the score."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("eval_scp", os.path.join(os.path.dirname(GOLD), "..", "scripts", "eval_scp.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = open(os.path.join(GOLD, "e2e_EN2002a_30s.rttm")).read()
+    scp, ref, uem, out = tmp_path / "wav.scp", tmp_path / "ref.rttm", tmp_path / "all.uem", tmp_path / "out"
+    scp.write_text(f"sessA {WAV}\nsessB {WAV}\n")
+    ref.write_text(gold.replace("EN2002a", "sessA") + gold.replace("EN2002a", "sessB"))
+    uem.write_text("sessA 1 0.000 30.000\nsessB 1 0.000 15.000\n")
+    res = mod.main(["-i", str(scp), "-o", str(out), "--ref-rttm", str(ref), "--uem", str(uem), "--synthetic-weights"])
+    assert res["recordings"] == 2 and res["der_overall"]["der"] == 0.0
+    assert set(res["der_files"]) == {"sessA", "sessB"} and all(f["der"] == 0.0 for f in res["der_files"].values())
+    assert (out / "sessA.rttm").read_text() == gold.replace("EN2002a", "sessA")
+    assert (out / "sessB.rttm").read_text() == gold.replace("EN2002a", "sessB")
+    assert res["der_files"]["sessB"]["total"] < res["der_files"]["sessA"]["total"]       # the UEM cut sessB's scored speech
+    assert (out / "result_collar0").exists()
