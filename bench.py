@@ -1,11 +1,12 @@
 """bench.py — headline benchmark: audio-seconds/s of the wavlm-large-s80 sliding-window hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f32|bf16] [--minutes 30]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f32h|f32s|f32|f16] [--minutes 30]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the device hot path over ONE synthetic recording per rank
 (BASELINE.json configs[2]: wavlm-large-s80, 30 min of 16 kHz mono, window 8 s, step 0.8 s ->
-2241 windows, batch 256 by default: windows are independent, results do not depend on the batch): for every batch of windows  segmentation (WavLM + Conformer + powerset)
+2241 windows in 6 balanced launches of 374 (--batch 384 is the maximum): windows are independent, results do not depend
+on the batch): for every batch of windows  segmentation (WavLM + Conformer + powerset)
 -> median filter + overlap-excluded masks -> ResNet34 embeddings (trunk shared by the 4 local
 speakers), all through the C ABI of libdzn_hip.so, the recording already resident in HBM.  The
 step ends with the hand-off the host clustering needs: u8 decisions + f32 embeddings copied to
@@ -13,8 +14,10 @@ the host (N=1) or all-gathered over RCCL (N>1; weak scaling: every rank owns its
 Host clustering is a separate ("next") row and is not inside the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (in-situ HIP-event
-timing of the dominant kernel class over the timed steps) and `cpu_baseline` (the oracle — a CPU
-port of the reference arithmetic — on a bounded sample of the same workload).
+timing of the dominant kernel class over the timed steps), `cpu_baseline` (the oracle — a CPU
+port of the reference arithmetic — on a bounded sample of the same workload), `parity` (what holds the path to the
+reference), the same workload in the other arithmetic modes, `e2e` (the whole pipeline incl. host clustering) and, with
+N > 1 ranks (or --strong-minutes), `strong_scaling_e2e`: ONE 4 h recording sharded over the ranks, end to end.
 """
 from __future__ import annotations
 
@@ -493,7 +496,7 @@ def main():
                             "avg_launch_ms": round(top["ms"] / top["launches"], 4)}
             # north_star asks for two more figures: MFMA utilisation on the attention contractions and HBM GB/s on
             # the conv frontend.  Rates are live (HIP events of this run); MfmaUtil / PMC bytes come from the
-            # committed rocprofv3 --pmc passes of the same command (profiles/, scripts/final_measure.sh).
+            # committed rocprofv3 --pmc passes of the same command (profiles/, scripts/final_measure_r3.sh).
             for key, names in (("attention", ("attention_relpos_f32s", "attention_relpos_f32h", "attention_relpos_f32")),
                                ("conv_frontend", ("conv0_ln_gelu", "conv01_fused"))):
                 p = next((p for p in prof if p["name"] in names), None)
