@@ -797,3 +797,23 @@ def test_der_uem_collar_and_set_scoring():
     s = score_set(ref_text, hyp, "f1 1 0 20\nf2 1 0 5\n")
     assert abs(s["files"]["f1"]["der"] - 0.1) < 1e-9 and abs(s["files"]["f2"]["der"] - 0.2) < 1e-9
     assert abs(s["overall"]["der"] - 3.0 / 25.0) < 1e-9 and s["missing_in_reference"] == []
+
+
+def test_top_count_selection_equals_the_reference_call_on_tied_activations():
+    """postprocess._top_count_mask (threshold at the c-th largest activation; frames with a tie AT that boundary take
+    the reference's `np.argsort(-activations)` call, PA/pipelines/utils/diarization.py:228-236) against that call on
+    every frame — integer overlap-add counts with many ties, count 0, count > number of clusters, one cluster."""
+    from diarizen_amd.postprocess import _top_count_mask
+
+    def reference(a, c):
+        order = np.argsort(-a, axis=-1)
+        sel = (np.arange(a.shape[1])[None, :] < c[:, None]).astype(a.dtype)
+        b = np.zeros_like(a)
+        np.put_along_axis(b, order, sel, axis=-1)
+        return b
+
+    r = np.random.default_rng(1)
+    for n, K, hi, maxc in ((5000, 13, 3, 2), (5000, 4, 2, 4), (3000, 1, 5, 1), (4000, 7, 11, 3), (100, 5, 1, 5), (0, 4, 3, 2)):
+        a = r.integers(0, hi + 1, (n, K)).astype(np.float32)
+        c = np.minimum(r.integers(0, maxc + 1, n), K).astype(np.int64)
+        assert np.array_equal(_top_count_mask(a, c), reference(a, c)), (n, K)
