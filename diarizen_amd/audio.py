@@ -25,7 +25,7 @@ def load_wav(src: Union[str, bytes, BinaryIO, io.BytesIO]) -> Tuple[np.ndarray, 
     (tag 0xFFFE: the real format is the first two bytes of the SubFormat GUID) — everything `torchaudio.load`
     reads from a .wav; the standard `wave` module refuses 24-bit extensible and float files."""
     if isinstance(src, (bytes, bytearray)):
-        data = bytes(src)
+        data = src
     elif hasattr(src, "read"):
         if hasattr(src, "seek"):
             src.seek(0)
@@ -33,15 +33,16 @@ def load_wav(src: Union[str, bytes, BinaryIO, io.BytesIO]) -> Tuple[np.ndarray, 
     else:
         with open(src, "rb") as f:
             data = f.read()
-    if data[:4] not in (b"RIFF", b"RF64") or data[8:12] != b"WAVE":
+    if bytes(data[:4]) not in (b"RIFF", b"RF64") or bytes(data[8:12]) != b"WAVE":
         raise ValueError("not a RIFF/WAVE file")
+    view = memoryview(data)        # (slicing `bytes` copies: a 4 h file was copied twice before it was decoded)
     pos, fmt, body = 12, None, None
     while pos + 8 <= len(data):
-        cid, size = data[pos:pos + 4], int.from_bytes(data[pos + 4:pos + 8], "little")
+        cid, size = bytes(view[pos:pos + 4]), int.from_bytes(view[pos + 4:pos + 8], "little")
         if cid == b"fmt ":
-            fmt = data[pos + 8:pos + 8 + size]
+            fmt = bytes(view[pos + 8:pos + 8 + size])
         elif cid == b"data":
-            body = data[pos + 8:] if size in (0, 0xFFFFFFFF) else data[pos + 8:pos + 8 + size]   # streamed files
+            body = view[pos + 8:] if size in (0, 0xFFFFFFFF) else view[pos + 8:pos + 8 + size]   # streamed files
             break
         pos += 8 + size + (size & 1)
     if fmt is None or body is None or len(fmt) < 16:
@@ -63,14 +64,16 @@ def load_wav(src: Union[str, bytes, BinaryIO, io.BytesIO]) -> Tuple[np.ndarray, 
         if width == 1:
             x = (np.frombuffer(body, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
         elif width == 2:
-            x = np.frombuffer(body, dtype="<i2").astype(np.float32) / 32768.0
+            x = np.frombuffer(body, dtype="<i2").astype(np.float32)
+            x *= np.float32(1.0 / 32768.0)                   # in place; a power of two, so identical to the division
         elif width == 3:
             b3 = np.frombuffer(body, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
             v = b3[:, 0] | (b3[:, 1] << 8) | (b3[:, 2] << 16)
             v = np.where(v & 0x800000, v - 0x1000000, v)
             x = v.astype(np.float32) / 8388608.0
         elif width == 4:
-            x = np.frombuffer(body, dtype="<i4").astype(np.float32) / 2147483648.0
+            x = np.frombuffer(body, dtype="<i4").astype(np.float32)
+            x *= np.float32(1.0 / 2147483648.0)
         else:
             raise ValueError(f"unsupported PCM width {width}")
     elif tag == 3:                                           # IEEE float
@@ -82,6 +85,8 @@ def load_wav(src: Union[str, bytes, BinaryIO, io.BytesIO]) -> Tuple[np.ndarray, 
             raise ValueError(f"unsupported float width {width}")
     else:
         raise ValueError(f"unsupported WAVE format tag {tag} ({bits} bit)")
+    if nch == 1:
+        return x.reshape(1, -1), sr                              # already [1, samples], contiguous
     return x.reshape(-1, nch).T.copy(), sr
 
 
