@@ -491,9 +491,12 @@ REF = "/root/reference"
 
 def _install_reference_inference(monkeypatch):
     """Import the reference's REAL PA/core/inference.py (+ utils/multi_task.py, utils/powerset.py) by path, with stub
-    parents for what is not installed here: pyannote.core (-> diarizen_amd.core), pytorch_lightning, and a transcription
-    of the fork's thin `pyannote.audio.core.model.Model` wrapper (PA/core/model.py:138-195: it only builds `.audio`,
-    `.specifications`, `._receptive_field`) and of task.Specifications / Resolution / Problem (PA/core/task.py:46-136)."""
+    parents for what is not installed here: pyannote.core (-> diarizen_amd.core), pytorch_lightning, lightning_fabric,
+    torchmetrics, and a transcription of task.Specifications / Resolution / Problem (PA/core/task.py:46-136: task.py itself
+    needs pytorch_lightning + pyannote.database).  (r3) `pyannote.audio.core.model` is the fork's REAL PA/core/model.py,
+    loaded by path: `Model.__init__` (audio, specifications, powerset, validation_metric) and `_receptive_field` run as
+    written; `Audio` is the two-method stand-in of compat.py (PA/core/io.py needs torchaudio).  r2 used a transcription of
+    that class."""
     import importlib.util
     import sys
     import types
@@ -544,27 +547,9 @@ def _install_reference_inference(monkeypatch):
         def __iter__(self):
             yield self
 
-    class Model(torch.nn.Module):
-        def __init__(self, sample_rate=16000, num_channels=1, task=None, max_speakers_per_chunk=4,
-                     max_speakers_per_frame=2, duration=5, min_duration=5, warm_up=0.0, mono="downmix"):
-            super().__init__()
-            if num_channels > 1:
-                mono = None
-            self.num_channels, self.sample_rate = num_channels, sample_rate
-            self.audio = AudioLite(sample_rate, mono)
-            self.specifications = Specifications(
-                problem=Problem.MONO_LABEL_CLASSIFICATION, resolution=Resolution.FRAME, duration=duration,
-                min_duration=min_duration, warm_up=(warm_up, warm_up) if not isinstance(warm_up, tuple) else warm_up,
-                classes=[f"speaker#{i + 1}" for i in range(max_speakers_per_chunk)],
-                powerset_max_classes=max_speakers_per_frame, permutation_invariant=True)
-
-        @cached_property
-        def _receptive_field(self):
-            size = self.receptive_field_size(num_frames=1)
-            step = self.receptive_field_size(num_frames=2) - size
-            start = self.receptive_field_center(frame=0) - (size - 1) / 2
-            return mycore.SlidingWindow(start=start / self.sample_rate, duration=size / self.sample_rate,
-                                        step=step / self.sample_rate)
+    class _Metric:                            # torchmetrics / pyannote.audio.torchmetrics: constructed by Model.__init__
+        def __init__(self, *a, **k):
+            pass
 
     mod("pyannote")
     mod("pyannote.core", Segment=mycore.Segment, SlidingWindow=mycore.SlidingWindow,
@@ -575,10 +560,23 @@ def _install_reference_inference(monkeypatch):
     mod("pyannote.audio")
     mod("pyannote.audio.core")
     mod("pyannote.audio.core.io", AudioFile=object)
-    mod("pyannote.audio.core.model", Model=Model, Specifications=Specifications)
-    mod("pyannote.audio.core.task", Resolution=Resolution, Specifications=Specifications, Problem=Problem)
+    mod("pyannote.audio.core.task", Resolution=Resolution, Specifications=Specifications, Problem=Problem, Task=object)
     mod("pyannote.audio.utils")
     mod("pyannote.audio.utils.reproducibility", fix_reproducibility=lambda *a, **k: None)
+    # what PA/core/model.py imports beyond that and this image lacks (none of it is reached by Model.__init__ /
+    # _receptive_field except Audio and the metric constructors)
+    sys.modules["pyannote.audio"].__version__ = "3.1.1"
+    sys.modules["pyannote.audio.core.io"].Audio = AudioLite
+    mod("lightning_fabric")
+    mod("lightning_fabric.utilities")
+    mod("lightning_fabric.utilities.cloud_io", _load=lambda *a, **k: None)
+    mod("diarizen")
+    mod("diarizen.utils", instantiate=lambda *a, **k: None)
+    mod("torchmetrics", Metric=_Metric, MetricCollection=_Metric)
+    mod("pyannote.audio.torchmetrics", **{n: _Metric for n in (
+        "DiarizationErrorRate", "FalseAlarmRate", "MissedDetectionRate", "OptimalDiarizationErrorRate",
+        "OptimalDiarizationErrorRateThreshold", "OptimalFalseAlarmRate", "OptimalMissedDetectionRate",
+        "OptimalSpeakerConfusionRate", "SpeakerConfusionRate")})
 
     def load(name, rel):
         spec = importlib.util.spec_from_file_location(name, os.path.join(PA, rel))
@@ -587,8 +585,12 @@ def _install_reference_inference(monkeypatch):
         spec.loader.exec_module(m)
         return m
 
+    # utils/multi_task.py and core/model.py import each other (in the package, model.py has `Specifications` from task.py
+    # in its namespace before it pulls multi_task in): a placeholder carrying that one name stands in until the real file runs
+    mod("pyannote.audio.core.model", Specifications=Specifications)
     load("pyannote.audio.utils.multi_task", "utils/multi_task.py")
     load("pyannote.audio.utils.powerset", "utils/powerset.py")
+    load("pyannote.audio.core.model", "core/model.py")          # (r3) the fork's REAL Model base, not a transcription
     return load("pyannote.audio.core.inference", "core/inference.py")
 
 
