@@ -3,6 +3,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f32h|f32s|f32|f16] [--minutes 30]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no launcher in the environment (WORLD_SIZE unset) makes bench.py launch its own N ranks
+(`torch.distributed.run --standalone`-style rendezvous on 127.0.0.1, one GPU each, RCCL); it refuses to run — non-zero
+exit, clear message — when fewer than N devices are visible or when the process group that comes up does not have N
+ranks.  `DZN_BENCH_ONE_DEVICE=1` (rehearsal on a 1-GPU box) maps every rank to device 0 and stages the collective
+through gloo, because RCCL refuses duplicate devices.
+
 One "step" = one pass of the device hot path over ONE synthetic recording per rank
 (BASELINE.json configs[2]: wavlm-large-s80, 30 min of 16 kHz mono, window 8 s, step 0.8 s ->
 2241 windows in 6 balanced launches of 374 (--batch 384 is the maximum): windows are independent, results do not depend
@@ -114,23 +120,51 @@ def pmc_lookup(table, kernel_class: str, field: str):
 
 
 def cpu_baseline(seg_cfg, sd, esd, window: int, step_s: float, budget_windows: int = 8):
-    """The oracle (CPU port of the reference arithmetic, oracle/) on a bounded sample: B windows
-    through segmentation + the embedding stage AS THE REFERENCE EXECUTES IT (one ResNet pass per
-    (window, local speaker), PA/pipelines/speaker_diarization.py:295-353)."""
+    """CPU timing of the same arithmetic on a bounded sample: B windows through segmentation + the embedding stage AS THE
+    REFERENCE EXECUTES IT (one ResNet pass per (window, local speaker), PA/pipelines/speaker_diarization.py:295-353).
+    kind = "reference" when /root/reference is present (build container): the reference's OWN modules — wav2vec2_model +
+    ConformerEncoder wired as model_wavlm_conformer.py:58-76,250-262 and wespeaker/resnet.py ResNet34, strict state_dict
+    loads (oracle/gen_golden.py) — with the oracle's fbank in front of the ResNet (torchaudio is absent).  On the GPU box
+    there is no /root/reference: kind = "port", the oracle restatement of the same modules."""
     from oracle import emb_model, seg_model
+    from oracle import gen_golden
     from oracle.gen_golden import synth_wave
     threads = torch.get_num_threads()
     wave = synth_wave(budget_windows, window, 99)
+    kind = "port"
+    if gen_golden.REF.exists():
+        try:
+            import warnings
+            fwd = gen_golden.build_reference_seg(seg_cfg, sd)
+            resnet, _ = gen_golden.load_reference_resnet()
+            net = resnet.ResNet34(80, 256, pooling_func="TSTP", two_emb_layer=False)
+            net.load_state_dict({k[len("resnet."):]: v for k, v in esd.items()}, strict=True)
+            net.eval()
+            kind = "reference"
+        except Exception as e:           # an incomplete reference tree: fall back to the port, say so
+            print(f"[bench] reference modules not importable ({type(e).__name__}: {e}); cpu_baseline uses the oracle", file=sys.stderr)
     t0 = time.perf_counter()
-    logp = seg_model.seg_forward(sd, seg_cfg, wave)
-    ml = seg_model.to_multilabel(logp, seg_cfg)
-    masks = ml.permute(0, 2, 1).contiguous()
-    for s in range(masks.shape[1]):
-        emb_model.emb_forward(esd, wave, masks[:, s])
+    if kind == "reference":
+        with torch.inference_mode(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            logp, _ = fwd(wave)
+            ml = seg_model.to_multilabel(logp, seg_cfg)
+            masks = ml.permute(0, 2, 1).contiguous()
+            fb = emb_model.compute_fbank(wave)
+            for s_ in range(masks.shape[1]):
+                net(fb.clone(), weights=masks[:, s_])
+    else:
+        logp = seg_model.seg_forward(sd, seg_cfg, wave)
+        ml = seg_model.to_multilabel(logp, seg_cfg)
+        masks = ml.permute(0, 2, 1).contiguous()
+        for s_ in range(masks.shape[1]):
+            emb_model.emb_forward(esd, wave, masks[:, s_])
     dt = time.perf_counter() - t0
+    what = ("the reference's own wav2vec2_model + ConformerEncoder + ResNet34 modules (imported from /root/reference)"
+            if kind == "reference" else "oracle restatement of the reference modules (no /root/reference on this box)")
     return {"value": round(budget_windows * step_s / dt, 4), "unit": "audio-seconds/s", "cores": threads,
-            "kind": "port",
-            "sample": f"{budget_windows} windows of {window} samples: oracle seg forward + 4 ResNet34 "
+            "kind": kind,
+            "sample": f"{budget_windows} windows of {window} samples: {what}: seg forward + 4 ResNet34 "
                       f"passes per window (as the reference executes), fp32 torch CPU, {dt:.1f} s"}
 
 
@@ -172,44 +206,105 @@ def run_mode(cfg, sd, esd, wave, args, window, precision, full, dev):
     return dt
 
 
-def e2e_leg(args, dev, wave_host):
-    """BASELINE configs[2] names segmentation + embedding + AHC: ONE untimed-for-the-headline pass of the whole
-    DiariZenPipeline (device stage, then speaker counting / AHC / reconstruction / RTTM on the host) over the same
-    recording, with the seeded turn-taking weights so that the host stage sees non-degenerate decisions."""
-    import copy
-    import numpy as np
-    from diarizen_amd.configs import get_seg_config
-    from diarizen_amd.pipeline import DiariZenPipeline
-    from testkit.weights import emb_state_dict, turn_taking_state_dict
-    cfg = get_seg_config(args.model)
-    conf = {"model": {"path": "diarizen.models.eend.model_wavlm_conformer.Model",
+def pipeline_conf(args, cfg):
+    return {"model": {"path": "diarizen.models.eend.model_wavlm_conformer.Model",
                       "args": {"wavlm_src": args.model, "wavlm_layer_num": cfg.wavlm_layer_num,
                                "wavlm_feat_dim": cfg.embed_dim, "chunk_size": int(args.window)}},
             "inference": {"args": {"seg_duration": args.window, "segmentation_step": 0.1, "batch_size": args.batch,
                                    "apply_median_filtering": True}},
             "clustering": {"args": {"method": "AgglomerativeClustering", "min_speakers": 1, "max_speakers": 20,
                                     "ahc_criterion": "distance", "ahc_threshold": 0.1, "min_cluster_size": 13}}}
-    pipe = DiariZenPipeline(None, None, config=copy.deepcopy(conf), device=dev, precision=args.precision,
-                            seg_state=turn_taking_state_dict(cfg, 0), emb_state=emb_state_dict(0))
+
+
+def e2e_leg(args, dev, wave_host, sd, esd):
+    """BASELINE configs[2] as it is worded — segmentation + embedding + AHC: `--e2e-steps` timed passes of the whole
+    DiariZenPipeline (host -> HBM upload, device stage, D2H, then speaker counting / AHC / assignment / reconstruction /
+    RTTM on the host) over the same recording and the same weights as the headline steps; mean over the passes."""
+    import copy
+    import numpy as np
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.pipeline import DiariZenPipeline
+    cfg = get_seg_config(args.model)
+    pipe = DiariZenPipeline(None, None, config=copy.deepcopy(pipeline_conf(args, cfg)), device=dev, precision=args.precision,
+                            seg_state=sd, emb_state=esd)
     x = np.ascontiguousarray(wave_host.numpy())
-    best = None
-    for _ in range(2):                      # first pass warms allocations / tables
+    seg, emb = pipe.device_stage(x)          # untimed: allocations / tables
+    ann = pipe.host_stage(seg, emb, "bench")
+    K = max(1, args.e2e_steps)
+    dev_s = host_s = 0.0
+    per = []
+    for _ in range(K):
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         seg, emb = pipe.device_stage(x)
         t1 = time.perf_counter()
         ann = pipe.host_stage(seg, emb, "bench")
         t2 = time.perf_counter()
-        best = (t1 - t0, t2 - t1, ann)
-    dev_s, host_s, ann = best
+        dev_s += t1 - t0
+        host_s += t2 - t1
+        per.append(round(t2 - t0, 4))
+    dev_s /= K
+    host_s /= K
     audio_s = len(x) / 16000.0
     active = int((seg.sum(1) > 0).sum())
-    return {"device_s": round(dev_s, 3), "host_s": round(host_s, 3), "upload_included": True,
-            "audio_seconds_per_s": round(audio_s / (dev_s + host_s), 1),
+    return {"audio_seconds_per_s": round(audio_s / (dev_s + host_s), 1), "steps": K, "s_per_step": per,
+            "device_s": round(dev_s, 4), "host_s": round(host_s, 4), "upload_included": True,
             "speakers": len(ann.labels()), "rttm_lines": len(ann.to_rttm().splitlines()),
             "active_window_speakers": active,
-            "note": "DiariZenPipeline device stage (host->HBM upload + segmentation + masks + embeddings + D2H) then host "
-                    "counting + AHC (centroid linkage) + constrained assignment + reconstruction + RTTM; seeded "
-                    "turn-taking weights"}
+            "note": "mean of `steps` passes of DiariZenPipeline: host->HBM upload + segmentation + masks + embeddings + D2H "
+                    "(device_s), then host counting + AHC (centroid linkage) + constrained assignment + reconstruction + "
+                    "RTTM (host_s); same recording and seeded turn-taking weights as the headline steps"}
+
+
+def config1_leg(args, dev):
+    """BASELINE configs[1]: wavlm-base-s80, segmentation only, 5 s windows, ONE batch of 32 at a time (the reference's own
+    configuration for that line), driver-timed beside the headline.  A pass = the 3591 windows of a 30-min recording
+    in 113 launches of <= 32; `streams` > 1 (default 2) runs consecutive batches on separate engine handles / HIP streams,
+    because a 32-window launch (7968 rows) under-fills 256 CUs and its 113 kernels are launch-granularity bound."""
+    from diarizen_amd.configs import RESNET34, get_seg_config
+    from diarizen_amd.engine import Engine
+    from diarizen_amd.inference import WindowRunner
+    from testkit.weights import turn_taking_state_dict
+    name, win_s, batch = "wavlm_base_s80_md", 5.0, 32
+    cfg = get_seg_config(name)
+    sd = turn_taking_state_dict(cfg, 0)
+    window = int(win_s * 16000)
+    nstream = max(1, args.config1_streams)
+    wave = synth_recording(int(args.config1_minutes * 60 * 16000), seed=1).to(dev)
+    out = {}
+    for ns in sorted({1, nstream}):
+        engines = [Engine(cfg, sd, None, None, max_batch=batch, max_samples=window, precision=args.precision, device=dev)
+                   for _ in range(ns)]
+        runners = [WindowRunner(e, win_s, 0.1, batch) for e in engines]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(ns)] if ns > 1 else [torch.cuda.current_stream(dev)]
+        views = runners[0].windows_view(wave)
+        C = views.shape[0]
+
+        def one():
+            torch.cuda.synchronize()
+            segs = []
+            for i, s0 in enumerate(range(0, C, batch)):
+                k = i % ns
+                with torch.cuda.stream(streams[k]):
+                    r = runners[k].run_views(views, s0, min(s0 + batch, C), with_embeddings=False)
+                    segs.append(r.segmentations)
+            torch.cuda.synchronize()
+            return torch.cat(segs).cpu()
+        one()
+        t0 = time.perf_counter()
+        for _ in range(args.config1_steps):
+            res = one()
+        dt = (time.perf_counter() - t0) / args.config1_steps
+        for e in engines:
+            e.close()
+        out[ns] = {"audio_seconds_per_s": round(wave.numel() / 16000.0 / dt, 1), "windows_per_s": round(C / dt, 1),
+                   "ms_per_batch_of_32": round(dt * 1e3 / -(-C // batch), 4), "streams": ns, "steps": args.config1_steps}
+    best = max(out.values(), key=lambda v: v["audio_seconds_per_s"])
+    return {"workload": f"{name} segmentation only, {win_s:g} s windows, batch {batch}, {C} windows of a {args.config1_minutes:g} min "
+                        f"synthetic recording per step (BASELINE configs[1]); unprofiled",
+            **best, "by_streams": {str(k): v["audio_seconds_per_s"] for k, v in out.items()},
+            "alg_gflop_per_window": 15.21,
+            "alg_tflops": round(best["windows_per_s"] * 15.21e-3, 1)}
 
 
 def strong_leg(args, dev, rank, world, minutes):
@@ -223,14 +318,7 @@ def strong_leg(args, dev, rank, world, minutes):
     from diarizen_amd.pipeline import DiariZenPipeline
     from testkit.weights import emb_state_dict, turn_taking_state_dict
     cfg = get_seg_config(args.model)
-    conf = {"model": {"path": "diarizen.models.eend.model_wavlm_conformer.Model",
-                      "args": {"wavlm_src": args.model, "wavlm_layer_num": cfg.wavlm_layer_num,
-                               "wavlm_feat_dim": cfg.embed_dim, "chunk_size": int(args.window)}},
-            "inference": {"args": {"seg_duration": args.window, "segmentation_step": 0.1, "batch_size": args.batch,
-                                   "apply_median_filtering": True}},
-            "clustering": {"args": {"method": "AgglomerativeClustering", "min_speakers": 1, "max_speakers": 20,
-                                    "ahc_criterion": "distance", "ahc_threshold": 0.1, "min_cluster_size": 13}}}
-    pipe = DiariZenPipeline(None, None, config=copy.deepcopy(conf), device=dev, precision=args.precision,
+    pipe = DiariZenPipeline(None, None, config=copy.deepcopy(pipeline_conf(args, cfg)), device=dev, precision=args.precision,
                             seg_state=turn_taking_state_dict(cfg, 0), emb_state=emb_state_dict(0))
     # the recording is a real RIFF file on local disk, so the timed region pays the byte-range decode a deployment pays
     # (audio.WavSource), not the synthesis: every rank synthesises the samples of ITS window block (1 / world of the
@@ -301,6 +389,54 @@ def strong_leg(args, dev, rank, world, minutes):
                     "serial_host_s = rank 0's counting + AHC + assignment + reconstruction + RTTM; seeded turn-taking weights"}
 
 
+def launcher_command(args, argv, port: int):
+    """the command `--gpus N` re-executes itself through: one rank per GPU of this node, rendezvous on 127.0.0.1"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
+def self_launch(args, argv, one_device: bool) -> int:
+    """`python bench.py --gpus N` with no launcher around it: check that N devices exist, then start the N ranks.
+    Returns the launcher's exit code (rank 0 prints the JSON line on the inherited stdout)."""
+    import socket
+    import subprocess
+    if not args.rendezvous_check:
+        if not torch.cuda.is_available():
+            print("bench.py needs a HIP device (the product has no CPU path)", file=sys.stderr)
+            return 2
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not one_device:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible HIP devices, torch.cuda.device_count() = {ndev}; "
+                  f"refusing to time fewer ranks than asked for (DZN_BENCH_ONE_DEVICE=1 rehearses the N-rank path on one "
+                  f"device through gloo)", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    return subprocess.call(launcher_command(args, argv, port), env=env)
+
+
+def rendezvous_check(args, rank: int, world: int):
+    """launcher self-test (no GPU needed): the ranks `--gpus N` started form ONE gloo group of N, every rank contributes
+    to an all-reduce, rank 0 prints what came up."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()})
+    if rank == 0:
+        print(json.dumps({"rendezvous": "ok", "n_gpus": world, "backend": "gloo", "sum_of_rank_ids": t.item(), "ranks": ranks}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,29 +463,59 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra steps in the other fp32 modes")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (device + host AHC) leg")
+    ap.add_argument("--e2e-steps", type=int, default=3, help="timed passes of the end-to-end leg (upload + device + host AHC)")
+    ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE configs[1] leg (base-s80, 5 s x 32, segmentation only)")
+    ap.add_argument("--config1-steps", type=int, default=2)
+    ap.add_argument("--config1-minutes", type=float, default=30.0)
+    ap.add_argument("--config1-streams", type=int, default=2,
+                    help="engine handles / HIP streams that consecutive 32-window batches of the configs[1] leg alternate over")
+    ap.add_argument("--weights", default="turn_taking", choices=["turn_taking", "plain"],
+                    help="turn_taking (default): seeded weights whose decisions look like turn taking (both mask branches of "
+                         "get_embeddings, silent windows, many powerset classes); plain: seeded N(0,1) init (one class per frame)")
+    ap.add_argument("--rendezvous-check", action="store_true",
+                    help="launcher self-test (runs without a GPU): bring up the --gpus N ranks on gloo, all-reduce, print "
+                         "{n_gpus, ranks} and exit")
     ap.add_argument("--strong-minutes", type=float, default=None,
                     help="length of the ONE recording of the strong-scaling end-to-end leg (BASELINE configs[3]: 240); "
                          "default: 240 when --gpus > 1, off at 1 GPU")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    one_device = bool(os.environ.get("DZN_BENCH_ONE_DEVICE"))    # rehearsal only: N ranks on device 0 (gloo staging)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:], one_device))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report "
+                         f"n_gpus for a job of a different size")
+    if args.rendezvous_check:
+        return rendezvous_check(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
-    if os.environ.get("DZN_BENCH_ONE_DEVICE"):       # debug only: exercise the N>1 code path on a 1-GPU box
+    ndev = torch.cuda.device_count()
+    if one_device:
         local_rank = 0
+    elif ndev < world or local_rank >= ndev:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {world} visible HIP devices, torch.cuda.device_count() = {ndev} "
+                         f"(DZN_BENCH_ONE_DEVICE=1 rehearses the N-rank path on one device)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("DZN_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm.  RCCL refuses two ranks on one device, so the one-device rehearsal stages through gloo.
+        backend = os.environ.get("DZN_BENCH_BACKEND", "gloo" if one_device else "nccl")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from diarizen_amd import _lib
     from diarizen_amd.configs import RESNET34, get_seg_config
@@ -357,10 +523,13 @@ def main():
     from diarizen_amd.engine import Engine
     from diarizen_amd.inference import WindowRunner
     from testkit.synth import synth_recording_range
-    from testkit.weights import emb_state_dict, seg_state_dict   # seeded random init
+    from testkit.weights import emb_state_dict, seg_state_dict, turn_taking_state_dict   # seeded init (no checkpoints offline)
 
     cfg = get_seg_config(args.model)
-    sd = seg_state_dict(cfg, 0)
+    # the timed steps run on the workload the metric names: weights whose hard decisions change within a window, so the
+    # clean-mask AND the fallback branch of prepare_masks, silent (window, speaker) pairs and the trunk-skip path all
+    # occur — same kernels and flops as plain seeded weights (which put every frame in one powerset class)
+    sd = turn_taking_state_dict(cfg, 0) if args.weights == "turn_taking" else seg_state_dict(cfg, 0)
     esd = emb_state_dict(0)
     sr = 16000
     window = int(args.window * sr)
@@ -427,8 +596,13 @@ def main():
     dt = time.perf_counter() - t0
     prof = [] if args.no_profile else _lib.profile_collect()
     _lib.profile_enable(False)
+    per_rank_ms = [round(dt / args.steps * 1e3, 2)]
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tdev = dev if backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([dt], device=tdev, dtype=torch.float64)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank_ms = [round(e.item() / args.steps * 1e3, 2) for e in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     torch.cuda.synchronize()
@@ -523,7 +697,10 @@ def main():
         out = {
             "metric": "audio-seconds/s (RTF) for wavlm-large-s80 pipeline, 16 kHz mono",
             "value": round(value, 2), "unit": "audio-seconds/s", "rtf": round(1.0 / value, 6),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": (world if backend == "nccl" else 0) if world > 1 else 1,
+            "collective_backend": ("rccl (torch.distributed 'nccl' on ROCm)" if backend == "nccl" else backend) if world > 1 else None,
+            "per_rank_ms_per_step": per_rank_ms,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
@@ -532,7 +709,9 @@ def main():
                                    f"{args.window:g} s, step {0.1 * args.window:g} s, {n_windows} windows, "
                                    f"batch {args.batch}; host clustering excluded from `value` (see `e2e`)",
                        "windows_per_step": n_windows, "batch": args.batch, "launches": batches_note(n_windows, args.batch),
-                       "weights": "seeded random init (no checkpoints offline)"},
+                       "weights": ("seeded turn-taking weights (testkit/weights.py: random init + Hann depthwise taps + calibrated "
+                                   "classifier -> many powerset classes, both mask branches; no checkpoints offline)"
+                                   if args.weights == "turn_taking" else "seeded random init (no checkpoints offline)")},
             "windows_per_s": round((1 if strong else world) * n_windows * args.steps / dt, 1),
             "unprofiled_ms_per_step": round(unprofiled_ms, 2),
             "roofline": roofline,
@@ -562,16 +741,25 @@ def main():
         if world == 1 and full and not args.no_e2e and args.minutes <= 60:
             eng = None
             torch.cuda.empty_cache()
-            out["e2e"] = e2e_leg(args, dev, wave_host)
+            out["e2e"] = e2e_leg(args, dev, wave_host, sd, esd)
         if strong_min > 0 and full and not args.no_e2e and world == 1:     # one GPU: the same leg as the N > 1 runs, for the curve
             eng = None
             torch.cuda.empty_cache()
             strong_res = strong_leg(args, dev, rank, world, strong_min)
         if strong_res is not None:
             out["strong_scaling_e2e"] = strong_res
+        if world == 1 and not args.no_config1:
+            eng = None
+            torch.cuda.empty_cache()
+            out["config1"] = config1_leg(args, dev)
         if not args.no_cpu_baseline and world == 1 and full:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, esd, window, 0.1 * args.window)
-        print(json.dumps(out))
+        # first-class companions of `value`, right behind it: the end-to-end rate (configs[2] as worded: upload + device
+        # + host AHC, mean of --e2e-steps passes) and the same steps on the fp32 MFMA instruction (strict IEEE fp32 operands)
+        head = {k: out.pop(k) for k in ("metric", "value", "unit", "rtf")}
+        head["e2e_value"] = out.get("e2e", {}).get("audio_seconds_per_s")
+        head["fp32_mfma_value"] = out.get("fp32_mfma_mode", {}).get("value")
+        print(json.dumps({**head, **out}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

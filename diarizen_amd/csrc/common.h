@@ -116,10 +116,11 @@ static inline bool prec_is_split(int p) { return p == DZN_PREC_F32_SPLIT || prec
 
 // ---- kernel launchers (implemented in the .hip files) ----
 int launch_gemm(const dzn_gemm_desc& d, hipStream_t s);
-int launch_gemm_lowp(const dzn_gemm_desc& d, hipStream_t s);  // gemm_lowp.hip: A and W both bf16
+#ifdef DZN_TUNING
+int launch_gemm_lowp(const dzn_gemm_desc& d, hipStream_t s);  // gemm_lowp.hip: A and W both bf16 (bf16 engine mode: DZN_TUNING builds only)
+#endif
 int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s); // gemm_split.hip: fp32 via 3-way bf16 split
 int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s);  // gemm_split_pre.hip: A pre-split planes
-int launch_gemm_pp(const dzn_gemm_desc& d, hipStream_t s, int np, const char* cfg);  // gemm_pp.hip: 8-wavefront ping-pong
 int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
                            hipStream_t st, int cg = 0, int cgp = 0);   // D = plane row width (groups padded from cg to cgp channels)
 int launch_pad_rows_split2(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,

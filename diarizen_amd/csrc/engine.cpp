@@ -1585,6 +1585,12 @@ int dzn_create(const dzn_config* cfg, dzn_handle** out) {
     last_create_error = "bad max_batch / max_samples / precision";
     return DZN_E_INVALID;
   }
+#ifndef DZN_TUNING
+  if (cfg->precision == DZN_PREC_BF16) {
+    last_create_error = "the bf16 engine mode is quarantined: it exists only in DZN_TUNING=1 builds (reduced precision = DZN_PREC_F16)";
+    return DZN_E_INVALID;
+  }
+#endif
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     last_create_error = "no HIP device visible (libdzn_hip has no CPU fallback)";
@@ -1752,7 +1758,13 @@ int dzn_destroy(dzn_handle* h) {
   return DZN_OK;
 }
 
-const char* dzn_version(void) { return "dzn-hip 0.1.0 (gfx950, MFMA f32/bf16)"; }
+const char* dzn_version(void) {
+#ifdef DZN_TUNING
+  return "dzn-hip 0.2.0 (gfx950, MFMA f32 / fp16x2 / bf16x3) [tuning build: probe tiles + the quarantined bf16 engine mode]";
+#else
+  return "dzn-hip 0.2.0 (gfx950, MFMA f32 / fp16x2 / bf16x3)";
+#endif
+}
 
 int dzn_op_relpos_bucket(int32_t rel, int32_t num_buckets, int32_t max_distance) {
   return relpos_bucket(rel, num_buckets, max_distance);

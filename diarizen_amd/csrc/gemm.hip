@@ -436,7 +436,11 @@ int launch_gemm(const dzn_gemm_desc& din, hipStream_t s) {
   if (d.alpha == 0.f) d.alpha = 1.f;
   if (d.precision == DZN_PREC_BF16) {
     if (!d.W16) return DZN_E_INVALID;
+#ifdef DZN_TUNING
     if (d.a_bf16) return launch_gemm_lowp(d, s);
+#else
+    if (d.a_bf16) return DZN_E_INVALID;    // bf16 activations: the quarantined bf16 engine mode, DZN_TUNING builds only
+#endif
     if (d.c_bf16 || d.r_bf16) return DZN_E_INVALID;
     return launch_prec<true>(d, s);
   }

@@ -1,3 +1,4 @@
+#ifdef DZN_TUNING   // the bf16 engine mode is quarantined: compiled only by DZN_TUNING=1 builds
 // gemm_lowp.hip — bf16 MFMA contraction with BOTH operands bf16 in HBM (the "bf16" engine mode).
 //
 // Same contract as gemm.hip (dzn_gemm_desc: two-level K addressing, row-offset tables, z batching,
@@ -245,3 +246,5 @@ int launch_gemm_lowp(const dzn_gemm_desc& d, hipStream_t s) {
     default: return launch_lowp_cfg<128, 128, 2, 2>(d, s);
   }
 }
+
+#endif  // DZN_TUNING

@@ -379,7 +379,6 @@ template <int NP>
 int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   const char* force = g_force_cfg();                    // tuning knob: force one tile shape
   if (force) {
-    if (!strncmp(force, "pp", 2) || !strncmp(force, "pq", 2)) return launch_gemm_pp(d, s, NP, force);   // gemm_pp.hip: 8-wavefront ping-pong tiles
     // production tiles by name
     if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2, NP, NP <= 2 ? 3 : 2>(d, s);
     if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2, NP, 2>(d, s);
@@ -413,16 +412,8 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     }
 #endif
   }
-  if constexpr (NP == 2) {
-    // (r3) DZN_GEMM_PQ=1: the streamed ping-pong form (gemm_pp.hip, 256 x 192 tiles, 8 wavefronts) for the big plain
-    // contractions whose width is a multiple of 192 (q/k/v and FFN-in of the pruned layers: 960, 1152, 768, 1920, ...):
-    // 335 TFLOP/s on those launches where the 128 x 128 tile has ~305, but only +0.5 % on the step (1627.9 vs 1620.3
-    // audio-s/s, same box, profiles/r3_gemm_pq_probe.txt) — inside the box-to-box spread, so the default keeps ONE
-    // contraction kernel; other widths lose to tile padding (N = 1024: 272 vs 280).
-    static const bool pq = getenv("DZN_GEMM_PQ") != nullptr;
-    if (pq && d.nz <= 1 && d.M >= 16384 && d.K >= 640 && d.N % 192 == 0 && !d.a_rowoff)
-      return launch_gemm_pp(d, s, NP, "pq192r3");
-  }
+  // (r3's 8-wavefront ping-pong forms — gemm_pp.hip, 256 x 192 tiles — measured +0.5 % on the step and were removed in r4;
+  // the A/B record is profiles/r3_gemm_pq_probe.txt, the source is in the history at 7bb9ad7)
   // launch bounds pin the occupancy the tile was tuned at (r3: the pipelined epilogue gives the register allocator
   // room to trade occupancy for more loads in flight; 128x64 tiles want 3 workgroups per CU, 128x128 two)
   constexpr int OCC64 = NP <= 2 ? 3 : 2;

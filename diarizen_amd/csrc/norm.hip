@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* x, int64
         o[e] = c + e < C ? t : 0.f;
         m = fmaxf(m, fabsf(o[e]));
       }
-      if (valid && c < Cpad) *reinterpret_cast<float4*>(yp + c) = make_float4(o[0], o[1], o[2], o[3]);
+      if (valid && c < (Cpad > C ? Cpad : C)) *reinterpret_cast<float4*>(yp + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
     if (amax_out) {     // |max| of the row -> tracker of its unit (window); probed only when this lane group's maximum grows
 #pragma unroll

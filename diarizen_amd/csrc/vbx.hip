@@ -140,12 +140,12 @@ extern "C" int dzn_vbx_create(const double* h_X, const double* h_Phi, const doub
                               int32_t K, int32_t device, void** out_state) {
   if (!h_X || !h_Phi || !h_gamma0 || !out_state || E < 1 || D < 1 || K < 1) return DZN_E_INVALID;
   int rc = DZN_OK;
+  DeviceGuard dg(device);
+  if (!dg.ok) return DZN_E_HIP;      // before the state exists: nothing to release
   VbState* s = new VbState();
   double *X = nullptr, *Phi = nullptr;
   s->E = E; s->D = D; s->K = K; s->device = device;
   s->nchunk = (E + VB_CHUNK - 1) / VB_CHUNK;
-  DeviceGuard dg(device);
-  if (!dg.ok) return DZN_E_HIP;
   if (hipMalloc(&X, (size_t)E * D * 8) != hipSuccess) { rc = DZN_E_NOMEM; goto done; }
   VCHK(hipMalloc(&Phi, (size_t)D * 8));
   VCHK(hipMalloc(&s->rho, (size_t)E * D * 8));

@@ -36,20 +36,43 @@ except ImportError:  # pragma: no cover
 EMBEDDING_REPO = "pyannote/wespeaker-voxceleb-resnet34-LM"
 
 
+def _lightning_safe_globals():
+    """non-tensor globals the known Lightning checkpoints carry (pyannote/wespeaker-voxceleb-resnet34-LM pickles a
+    `TorchVersion` in its `pyannote.audio` version block; hyper-parameter blocks use plain containers), allow-listed so
+    that the tensors-only unpickler loads them — nothing here executes code on load"""
+    import collections
+    allow = [collections.OrderedDict, collections.defaultdict, dict, list, tuple, set, frozenset, complex, slice]
+    try:
+        from torch.torch_version import TorchVersion
+        allow.append(TorchVersion)
+    except Exception:       # pragma: no cover
+        pass
+    return allow
+
+
 def _load_checkpoint(path: str) -> Dict[str, torch.Tensor]:
-    """plain state_dict (DiariZen hub `pytorch_model.bin`) or Lightning checkpoint (WeSpeaker).  Tensors-only
-    unpickling first; the permissive loader only for checkpoints that carry other python objects (Lightning)."""
+    """plain state_dict (DiariZen hub `pytorch_model.bin`) or Lightning checkpoint (WeSpeaker, PA/core/model.py:459-473).
+    Always the tensors-only unpickler: first as is, then with the known Lightning globals allow-listed (the real
+    pyannote/WeSpeaker checkpoint holds a `TorchVersion`, which `weights_only=True` rejects on its own — the breakage
+    pyannote hit with torch 2.6).  The permissive unpickler is an explicit opt-in (DZN_TRUST_CHECKPOINTS=1), never a
+    silent fallback."""
     import pickle
+    first = None
+    ckpt = None
     try:
         ckpt = torch.load(path, map_location="cpu", weights_only=True)
-    except pickle.UnpicklingError:
-        # the safe loader refused a non-tensor global.  Only the WeSpeaker checkpoint is a Lightning pickle with such
-        # objects (PA/core/model.py:459-473); executing arbitrary pickles is opt-in, never a silent fallback.
-        if os.environ.get("DZN_TRUST_CHECKPOINTS") != "1":
-            raise RuntimeError(f"{path}: not a tensors-only checkpoint.  If this file comes from a source you trust (e.g. the "
-                               f"pyannote/wespeaker-voxceleb-resnet34-LM Lightning checkpoint), set DZN_TRUST_CHECKPOINTS=1 to "
-                               f"load it with the full unpickler.") from None
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    except (pickle.UnpicklingError, RuntimeError, TypeError) as e:
+        first = e
+    if ckpt is None:
+        try:
+            with torch.serialization.safe_globals(_lightning_safe_globals()):
+                ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        except (pickle.UnpicklingError, RuntimeError, TypeError, AttributeError) as e:
+            if os.environ.get("DZN_TRUST_CHECKPOINTS") != "1":
+                raise RuntimeError(f"{path}: not loadable with the tensors-only unpickler ({type(first).__name__}: {first}; with "
+                                   f"the Lightning allow-list: {type(e).__name__}: {e}).  If this file comes from a source you "
+                                   f"trust, set DZN_TRUST_CHECKPOINTS=1 to load it with the full unpickler.") from None
+            ckpt = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(ckpt, dict) and "state_dict" in ckpt and isinstance(ckpt["state_dict"], dict):
         ckpt = ckpt["state_dict"]          # Lightning checkpoint (PA/core/model.py:459-473)
     return ckpt

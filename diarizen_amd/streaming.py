@@ -53,6 +53,11 @@ class StreamingSession:
         self.slot_free = [None] * slots                                 # event: the slot's H2D copy has completed
         self.next_slot = 0
         self.copy_stream = torch.cuda.Stream(device=dev)
+        # the zero fill of dev_wave above is queued on the CURRENT stream; the chunk copies run on copy_stream — without this
+        # edge the first copies could land before the memset and be zeroed by it.  record_stream: the caching allocator
+        # must not recycle dev_wave while copies on the other stream are pending.
+        self.copy_stream.wait_stream(torch.cuda.current_stream(dev))
+        self.dev_wave.record_stream(self.copy_stream)
         self.n = 0                                                      # samples received
         self.done = 0                                                   # windows computed
         self.seg = []                                                   # per batch: u8 [c, L, S] host arrays

@@ -75,6 +75,15 @@ def main(argv=None):
         emb = args.embedding_model or str(Path(args.diarizen_hub) / "wespeaker" / "pytorch_model.bin")
         pipe = DiariZenPipeline(args.diarizen_hub, emb, device=dev, precision=args.precision, rttm_out_dir=args.out_dir)
     os.makedirs(args.out_dir, exist_ok=True)
+    # ranks share only the output directory: a done-file per rank, named after THIS job (launcher run id + rendezvous port) so
+    # that the leftovers of an aborted earlier run are not mistaken for this run's, removed before any work starts, and
+    # written atomically (temp file + os.replace) so that rank 0 never reads half a file
+    job = f"{os.environ.get('TORCHELASTIC_RUN_ID', 'solo')}_{os.environ.get('MASTER_PORT', '0')}"
+
+    def done_file(r):
+        return Path(args.out_dir) / f".done_{job}_rank{r}.json"
+    for stale in Path(args.out_dir).glob(f".done_*_rank{rank}.json"):
+        stale.unlink(missing_ok=True)
     scp = load_scp(args.in_wav_scp)
     mine = list(scp.items())[rank::world]
     audio_s = wall = 0.0
@@ -84,14 +93,16 @@ def main(argv=None):
         wall += time.perf_counter() - t0
         audio_s += pipe.timings["audio_s"]
         print(f"[rank {rank}] {rec}: {pipe.timings['audio_s']:.1f} s of audio in {time.perf_counter() - t0:.2f} s", flush=True)
-    (Path(args.out_dir) / f".done_rank{rank}.json").write_text(json.dumps({"files": [r for r, _ in mine], "audio_s": audio_s, "wall_s": wall}))
+    tmp = done_file(rank).with_suffix(".tmp")
+    tmp.write_text(json.dumps({"files": [r for r, _ in mine], "audio_s": audio_s, "wall_s": wall}))
+    os.replace(tmp, done_file(rank))
     if rank != 0:
         return None
-    while not all((Path(args.out_dir) / f".done_rank{r}.json").exists() for r in range(world)):     # ranks share only the directory
+    while not all(done_file(r).exists() for r in range(world)):
         time.sleep(0.2)
-    done = [json.loads((Path(args.out_dir) / f".done_rank{r}.json").read_text()) for r in range(world)]
+    done = [json.loads(done_file(r).read_text()) for r in range(world)]
     for r in range(world):
-        (Path(args.out_dir) / f".done_rank{r}.json").unlink()
+        done_file(r).unlink()
     summary = {"recordings": len(scp), "ranks": world, "audio_s": sum(d["audio_s"] for d in done),
                "wall_s_max_rank": max(d["wall_s"] for d in done), "precision": args.precision}
     summary["audio_seconds_per_s"] = summary["audio_s"] / summary["wall_s_max_rank"] if summary["wall_s_max_rank"] > 0 else None

@@ -1,0 +1,79 @@
+"""`python bench.py --gpus N` must itself produce an N-rank job: the driver's SCALE run calls exactly
+that command when no launcher wraps it.  CPU-only tests of the launcher path: the real spawn through
+torch.distributed.run (gloo rendezvous on 127.0.0.1), the refusal when fewer than N devices are visible, and the
+refusal when a launcher started a different number of ranks than --gpus says."""
+from __future__ import annotations
+
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+from types import SimpleNamespace
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DZN_BENCH_ONE_DEVICE")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--rendezvous-check"], env=_clean_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["rendezvous"] == "ok" and out["n_gpus"] == 2
+    assert sorted(x["rank"] for x in out["ranks"]) == [0, 1]
+    assert sorted(x["local_rank"] for x in out["ranks"]) == [0, 1]          # one device index per rank
+    assert len({x["pid"] for x in out["ranks"]}) == 2                         # two processes, not one rank counted twice
+    assert out["sum_of_rank_ids"] == 3.0                                     # both contributed to the collective
+
+
+def test_world_size_must_equal_gpus():
+    env = _clean_env()
+    env.update(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=3" in r.stderr and "--gpus 2" in r.stderr
+
+
+def test_refuses_fewer_devices_than_ranks(monkeypatch, capsys):
+    b = _bench()
+    import torch
+    calls = []
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    args = SimpleNamespace(gpus=2, rendezvous_check=False)
+    assert b.self_launch(args, ["--gpus", "2"], one_device=False) != 0
+    assert not calls, "must not start ranks it has no devices for"
+    assert "needs 2 visible HIP devices" in capsys.readouterr().err
+    # the one-device rehearsal is an explicit opt-in and does launch
+    assert b.self_launch(args, ["--gpus", "2", "--steps", "1"], one_device=True) == 0
+    (cmd, env), = calls
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "1"] and cmd[-5].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_no_gpu_is_a_loud_failure():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=_clean_env(), capture_output=True,
+                       text=True, timeout=600)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "HIP device" in r.stderr

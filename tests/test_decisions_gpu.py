@@ -51,7 +51,9 @@ def decision_parity(gpu, n_windows: int, batch: int = 32):
                          "min_top2_margin": float(margin.min()),
                          "frames_with_margin_below_1e-3": int((margin < 1e-3).sum())},
               "modes": {}}
-    for precision in ("f32s", "f32h", "f32", "bf16", "f16"):
+    from diarizen_amd import _lib
+    has_bf16 = b"tuning build" in _lib.load().dzn_version()      # quarantined mode: DZN_TUNING=1 builds only
+    for precision in ("f32s", "f32h", "f32", "f16") + (("bf16",) if has_bf16 else ()):
         eng = Engine(cfg, sd, max_batch=batch, max_samples=N, precision=precision, device=gpu)
         outs = []
         for b in range(0, n_windows, batch):
@@ -80,7 +82,8 @@ def test_argmax_flip_rate_vs_oracle(built_lib, gpu):
         assert m["max_abs_dlogp"] <= 1e-3, (p, m)
         assert m["flip_rate"] <= 1e-3, (p, m)
         assert m["max_oracle_margin_of_flipped_frames"] <= 2e-3, (p, m)
-    m = rep["modes"]["bf16"]
-    assert m["flip_rate"] <= 0.2 and np.isfinite(m["max_abs_dlogp"]), m
+    if "bf16" in rep["modes"]:
+        m = rep["modes"]["bf16"]
+        assert m["flip_rate"] <= 0.2 and np.isfinite(m["max_abs_dlogp"]), m
     m = rep["modes"]["f16"]                 # single-term fp16 (2^-11 per operand): reported, loose bound like bf16
     assert m["flip_rate"] <= 0.05 and np.isfinite(m["max_abs_dlogp"]), m

@@ -121,6 +121,9 @@ def test_embedding_reduced_precision_engines(built_lib, gpu, precision):
     cosine >= 0.999 vs the reference golden, inactive speaker still exactly the bias"""
     from oracle import emb_model
     from oracle.gen_golden import synth_wave
+    if precision == "bf16":
+        from conftest import needs_bf16_mode
+        needs_bf16_mode(built_lib)
     g = np.load(os.path.join(GOLD, "emb_resnet.npz"))
     B, N = int(g["B"]), int(g["N"])
     eng = _engine(gpu, B, N, precision=precision)

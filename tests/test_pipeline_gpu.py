@@ -163,7 +163,8 @@ def test_der_between_arithmetic_modes(built_lib, gpu):
     from oracle.gen_golden import E2E_CONFIG
     cfg = get_seg_config("wavlm_large_s80_md")
     rttm = {}
-    for prec in ("f32h", "f32s", "f32", "bf16", "f16"):
+    has_bf16 = b"tuning build" in built_lib.dzn_version()        # quarantined mode: DZN_TUNING=1 builds only
+    for prec in ("f32h", "f32s", "f32", "f16") + (("bf16",) if has_bf16 else ()):
         pipe = DiariZenPipeline(None, None, config=copy.deepcopy(E2E_CONFIG), device=gpu, precision=prec,
                                 seg_state=turn_taking_state_dict(cfg, 0), emb_state=emb_state_dict(0))
         rttm[prec] = pipe(WAV, sess_name="EN2002a").to_rttm()
@@ -172,16 +173,18 @@ def test_der_between_arithmetic_modes(built_lib, gpu):
     for prec in ("f32h", "f32s", "f32"):
         assert rttm[prec] == gold
         assert der_rttm(gold, rttm[prec], "EN2002a")["der"] == 0.0
-    d = der_rttm(gold, rttm["bf16"], "EN2002a")
-    print("bf16 vs fp32 RTTM on EN2002a_30s (seeded stress weights):", {k: round(v, 4) for k, v in d.items() if k != "mapping"})
-    assert d["der"] <= 0.6
+    d = None
+    if has_bf16:
+        d = der_rttm(gold, rttm["bf16"], "EN2002a")
+        print("bf16 vs fp32 RTTM on EN2002a_30s (seeded stress weights):", {k: round(v, 4) for k, v in d.items() if k != "mapping"})
+        assert d["der"] <= 0.6
     d16 = der_rttm(gold, rttm["f16"], "EN2002a")
     print("f16 vs fp32 RTTM on EN2002a_30s (seeded stress weights):", {k: round(v, 4) for k, v in d16.items() if k != "mapping"})
     assert d16["der"] <= 0.6
     if os.path.isdir("gpurun_out"):
         import json
         with open("gpurun_out/der_reduced_modes.json", "w") as f:
-            json.dump({"reference": "fp32-mode RTTM (== golden)", "bf16": {k: v for k, v in d.items() if k != "mapping"},
+            json.dump({"reference": "fp32-mode RTTM (== golden)", "bf16": {k: v for k, v in d.items() if k != "mapping"} if d else None,
                        "f16": {k: v for k, v in d16.items() if k != "mapping"}}, f, indent=1)
 
 

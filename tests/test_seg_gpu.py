@@ -114,6 +114,8 @@ def test_seg_fp32_matches_reference_golden_turn_taking(built_lib, gpu, name, pre
 
 @pytest.mark.parametrize("name", ["tiny_ln", "wavlm_large_s80_md"])
 def test_seg_bf16_within_tolerance(built_lib, gpu, name):
+    from conftest import needs_bf16_mode
+    needs_bf16_mode(built_lib)
     cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, "bf16")
     ref = torch.from_numpy(g["logp"])
     err = (logp - ref).abs().max().item()
@@ -201,6 +203,8 @@ def test_seg_dense_wavlm_base(built_lib, gpu, precision):
 def test_seg_bf16_group_norm_models(built_lib, gpu, name):
     """bf16 engine on the base-style models (group-norm extractor, post-norm encoder, 48-channel
     positional-conv groups for base: that contraction stays on fp32 activations)"""
+    from conftest import needs_bf16_mode
+    needs_bf16_mode(built_lib)
     cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, "bf16")
     ref = torch.from_numpy(g["logp"])
     assert (logp - ref).abs().max().item() <= 1e-1
