@@ -591,6 +591,7 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0           # this rank's own K steps (before it waits for the others)
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -599,10 +600,11 @@ def main():
     per_rank_ms = [round(dt / args.steps * 1e3, 2)]
     if dist is not None:
         tdev = dev if backend == "nccl" else torch.device("cpu")
-        tt = torch.tensor([dt], device=tdev, dtype=torch.float64)
+        tt = torch.tensor([dt_own], device=tdev, dtype=torch.float64)
         every = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(every, tt)
         per_rank_ms = [round(e.item() / args.steps * 1e3, 2) for e in every]
+        tt = torch.tensor([dt], device=tdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     torch.cuda.synchronize()

@@ -94,6 +94,7 @@ class DznGemmDesc(C.Structure):
         ("W2h", C.c_void_p), ("col_scale", C.c_void_p), ("a_amax", C.c_void_p), ("c_amax", C.c_void_p),
         ("amax_unit", C.c_int32),
         ("stat_partial", C.c_void_p), ("stat_final", C.c_void_p), ("stat_C", C.c_int32), ("stat_eps", C.c_float),
+        ("z_count", C.c_void_p), ("z_list", C.c_void_p), ("ln_centered", C.c_int32),
     ]
 
 

@@ -185,19 +185,19 @@ int launch_frame_prep(const float* wave, int B, int N, int T, int flen, int fshi
                       const float* window, float preemph, float* frames, hipStream_t st);
 int launch_power(const float* spec, int64_t rows, int nb, float* pw, hipStream_t st);
 int launch_window_active(const float* masks, int B, int per_window, int* flag, hipStream_t st);
-int launch_gather_rows(const float* src, const int* idx, int rows, int64_t n, float* dst, hipStream_t st);
-int launch_scatter_embeddings(const float* compact, const int* pos, const float* bias, int B, int S, int D, float* out,
-                              hipStream_t st);
+int launch_compact_active(const int* flag, int B, int* count, int* list, long long* totals, hipStream_t st);
 int launch_log_cmn(float* mel, int B, int T, int NB, float eps, hipStream_t st);
 int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* w, const float* bias,
-                     void* img, int out_bf16, hipStream_t st, float* amax = nullptr);
+                     void* img, int out_bf16, hipStream_t st, float* amax = nullptr, const int* z_count = nullptr,
+                     const int* z_list = nullptr);   // (z_count, z_list): device-chosen subset of the B images
 int launch_stats_pool(const void* img, int in_bf16, int B, int H, int W, int C, const float* masks, int S,
-                      int L, float* stats, hipStream_t st);
+                      int L, float* stats, hipStream_t st, const int* active = nullptr);   // active[b] == 0 -> zeros
 
 // conv_split.hip: 3x3 stride-1 conv 32 -> 32 over zero-bordered NHWC images (DZN_PREC_F32_SPLIT)
 int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias, const float* R, float* out, int B,
                              int Hs, int Ws, int relu, int post_relu, hipStream_t s, float* amax = nullptr,
-                             const void* W2h = nullptr, const float* col_scale = nullptr, const float* amax_in = nullptr);
+                             const void* W2h = nullptr, const float* col_scale = nullptr, const float* amax_in = nullptr,
+                             const int* z_count = nullptr, const int* z_list = nullptr);
 
 // post.hip
 int launch_prepare_masks(const uint8_t* ml, int B, int L, int S, int median, int exclude_overlap,

@@ -45,6 +45,8 @@ struct ConvArgs {
   float* amax;         // |max| tracker of `out` per image (DZN_PREC_F32_H2 consumers) or nullptr
   const float* amax_in;    // NP = 2: per-image |max| of `in`
   const float* col_scale;  // NP = 2: [32] inverse weight scales
+  const int* z_count;      // device-chosen subset of the B images: z_count[0] entries of z_list, or nullptr = all
+  const int* z_list;
 };
 
 template <int NP>
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
   const int64_t img = (int64_t)(a.Hs + 2) * P * 32;   // elements per image
   const int npix = a.Hs * P;                          // flat pixels of the rows that hold outputs
   const int tiles_img = (npix + CS_TP - 1) / CS_TP;
-  const int ntiles = tiles_img * a.B;
+  const int nB = a.z_list ? a.z_count[0] : a.B;       // images this launch works on
   const int last_pix = (a.Hs + 2) * P - 1;
 
   // this wavefront's weight fragments: A operand rows = output channels nb*16 + lr, k = 8 lq .. 8 lq + 7
@@ -81,8 +83,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
   static_assert(NITEM <= NIT * 256, "7 items per thread");
   float4 u4[NIT], v4[NIT];
   auto fetch = [&](int tile) {
-    const int b = tile / tiles_img;
-    const int q0 = P + (tile - b * tiles_img) * CS_TP;
+    const int bi = tile / tiles_img;
+    const int b = a.z_list ? a.z_list[bi] : bi;
+    const int q0 = P + (tile - bi * tiles_img) * CS_TP;
     const float* ib = a.in + (int64_t)b * img;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
   // was fetched from HBM ~3.4 times (PMC FETCH_SIZE: 7.2 GB per launch for 2.1 GB of input; now 3.4 GB).
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (gridDim.x + 7 - xcd) >> 3;
   const int per_img = slot < tiles_img ? (tiles_img - slot + nslot - 1) / nslot : 0;  // my tiles per image
-  const int nimg = xcd < a.B ? (a.B - xcd + 7) / 8 : 0;
+  const int nimg = xcd < nB ? (nB - xcd + 7) / 8 : 0;
   const int nmine = per_img * nimg;
   auto tile_of = [&](int j) {   // j-th tile of this workgroup
     const int ii = j / per_img;
@@ -129,8 +132,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
   if (nmine > 0) fetch(tile_of(0));
   for (int j = 0; j < nmine; ++j) {
     const int tile = tile_of(j);
-    const int b = tile / tiles_img;
-    const int q0 = P + (tile - b * tiles_img) * CS_TP;    // first output pixel (flat, padded coords)
+    const int bi = tile / tiles_img;
+    const int b = a.z_list ? a.z_list[bi] : bi;
+    const int q0 = P + (tile - bi * tiles_img) * CS_TP;    // first output pixel (flat, padded coords)
     float in_scale = 1.f, in_inv = 1.f;
     if constexpr (NP == 2) h2_scale(a.amax_in[b], in_scale, in_inv);
     split_store(in_scale);      // every input pixel of the strip is split exactly once
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const ConvArg
 // W2h / col_scale / amax_in all given -> fp16 two-term variant, else the bf16 three-term one (W3).
 int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias, const float* R, float* out, int B,
                              int Hs, int Ws, int relu, int post_relu, hipStream_t s, float* amax, const void* W2h,
-                             const float* col_scale, const float* amax_in) {
+                             const float* col_scale, const float* amax_in, const int* z_count, const int* z_list) {
   if (B <= 0 || Hs <= 0 || Ws <= 0) return DZN_OK;
   if (!in || !W3 || !bias || !out) return DZN_E_INVALID;
   const bool h2 = W2h && col_scale && amax_in;
@@ -236,7 +240,8 @@ int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_split_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  ConvArgs a{in, static_cast<const u16*>(h2 ? W2h : W3), bias, R, out, B, Hs, Ws, relu, post_relu, amax, amax_in, col_scale};
+  ConvArgs a{in, static_cast<const u16*>(h2 ? W2h : W3), bias, R, out, B, Hs, Ws, relu, post_relu, amax, amax_in, col_scale, z_list ? z_count : nullptr,
+             z_count ? z_list : nullptr};
   const int grid = 512;   // persistent: 2 workgroups per CU; XCD-major work distribution inside the kernel
   const int pid = prof_begin(s, h2 ? "conv3x3_c32_f32h" : "conv3x3_c32_f32s", 2.0 * B * Hs * (double)Ws * 32.0 * 288.0,
                              (double)B * Hs * Ws * 32.0 * 4.0 * (R ? 3.0 : 2.0));   // image in + out (+ residual), once

@@ -105,9 +105,14 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                                                         int NB, int C,
                                                         const float* __restrict__ w,  // [C, 9] folded
                                                         const float* __restrict__ bias,
-                                                        TO* __restrict__ img, float* __restrict__ amax) {
+                                                        TO* __restrict__ img, float* __restrict__ amax,
+                                                        const int* __restrict__ z_count, const int* __restrict__ z_list) {
   const int cq = C >> 2;                       // channel quads per pixel (8 for the 32-channel stem)
-  const int b = blockIdx.y;
+  int b = blockIdx.y;
+  if (z_list) {                                // device-chosen subset of the batch (windows with an active speaker)
+    if (b >= z_count[0]) return;
+    b = z_list[b];
+  }
   const int q = threadIdx.x % cq, pl = threadIdx.x / cq, ppb = 256 / cq;     // pixel lane, pixels per sweep
   float wr[4][9], br[4];
 #pragma unroll
@@ -163,9 +168,22 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 template <typename TI>
 __global__ __launch_bounds__(256) void stats_pool_kernel(const TI* __restrict__ img, int H, int W,
                                                          int C, const float* __restrict__ masks,
-                                                         int S, int L, float* __restrict__ stats) {
+                                                         int S, int L, float* __restrict__ stats,
+                                                         const int* __restrict__ active) {
   extern __shared__ float sw[];  // [S][W] interpolated weights
   const int b = blockIdx.y, h = blockIdx.x;
+  if (active && !active[b]) {
+    // a window without any active speaker: its trunk pass was skipped, its image is stale.  All-zero weights pool to
+    // mean = 0 / 1e-8 = 0 and std = sqrt(0 / 2e-8) = 0 for every feature (PA/models/blocks/pooling.py:44-75) — the very
+    // values the loop below produces for zero masks, written directly
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+      for (int s = 0; s < S; ++s) {
+        float* op = stats + ((int64_t)b * S + s) * (2 * C * H);
+        op[c * H + h] = 0.f;
+        op[C * H + c * H + h] = 0.f;
+      }
+    return;
+  }
   // F.interpolate(mode="nearest"): src = min(floor(dst * (L / W)), L - 1)  (float32 scale)
   const float scale = (float)L / (float)W;
   for (int i = threadIdx.x; i < S * W; i += blockDim.x) {
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const TI* __restrict__ 
   }
 }
 
-// ---- (r3) windows without any active speaker need no trunk (their embeddings are seg_1's bias) ----
+// ---- windows without any active speaker need no trunk (their embeddings are seg_1's bias) ----
 // flag[b] = 1 when any of the window's S * L mask values is non-zero
 __global__ __launch_bounds__(256) void window_active_kernel(const float* __restrict__ masks, int per_window,
                                                             int* __restrict__ flag) {
@@ -212,28 +230,38 @@ __global__ __launch_bounds__(256) void window_active_kernel(const float* __restr
   if (threadIdx.x == 0) flag[blockIdx.x] = any != 0;
 }
 
-// dst row b = src row idx[b] (rows of `n` floats, n % 4 == 0 and 16-byte aligned rows, or any n through the tail loop)
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx,
-                                                          int64_t n, float* __restrict__ dst) {
-  const float* s = src + (int64_t)idx[blockIdx.y] * n;
-  float* d = dst + (int64_t)blockIdx.y * n;
-  const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
-  if (vec) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256)
-      reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
-  } else {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+// (r4) the subset is built ON THE DEVICE: list[0 .. count) = the active windows in ascending order, count[0] = how many
+// (one workgroup; B is a batch size).  Every trunk kernel takes (count, list) and its surplus grid rows exit, so the
+// host never reads the flags back — dzn_embed_forward stays enqueue-only.  totals[0] += B, totals[1] += B - count
+// (dzn_embed_skip_stats).
+__global__ __launch_bounds__(256) void compact_active_kernel(const int* __restrict__ flag, int B, int* __restrict__ count,
+                                                             int* __restrict__ list, long long* __restrict__ totals) {
+  __shared__ int wsum[4];
+  __shared__ int base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += 256) {
+    const int b = b0 + threadIdx.x;
+    const int f = b < B ? (flag[b] != 0) : 0;
+    const unsigned long long bal = __ballot(f);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (f) list[off + before] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
   }
-}
-
-// out row (b, s) = compact row (pos[b], s) for active windows (pos[b] >= 0), the bias otherwise
-__global__ __launch_bounds__(256) void scatter_embeddings_kernel(const float* __restrict__ compact,
-                                                                 const int* __restrict__ pos,
-                                                                 const float* __restrict__ bias, int S, int D,
-                                                                 float* __restrict__ out) {
-  const int b = blockIdx.x, p = pos[b];
-  for (int i = threadIdx.x; i < S * D; i += 256)
-    out[(int64_t)b * S * D + i] = p >= 0 ? compact[(int64_t)p * S * D + i] : bias[i % D];
+  if (threadIdx.x == 0) {
+    count[0] = base;
+    if (totals) {
+      totals[0] += B;
+      totals[1] += B - base;
+    }
+  }
 }
 
 inline unsigned grid_for(int64_t n, int per = 256, int cap = 8192) {
@@ -258,18 +286,8 @@ int launch_window_active(const float* masks, int B, int per_window, int* flag, h
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
-int launch_gather_rows(const float* src, const int* idx, int rows, int64_t n, float* dst, hipStream_t st) {
-  if (rows <= 0) return DZN_OK;
-  ProfScope prof_scope_(st, "gather_rows", 0.0, (double)rows * n * 8.0);
-  const unsigned gx = grid_for(n / 4 > 0 ? n / 4 : n, 256, 64);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, rows), dim3(256), 0, st, src, idx, n, dst);
-  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
-}
-
-int launch_scatter_embeddings(const float* compact, const int* pos, const float* bias, int B, int S, int D, float* out,
-                              hipStream_t st) {
-  ProfScope prof_scope_(st, "scatter_embeddings", 0.0, (double)B * S * D * 8.0);
-  hipLaunchKernelGGL(scatter_embeddings_kernel, dim3(B), dim3(256), 0, st, compact, pos, bias, S, D, out);
+int launch_compact_active(const int* flag, int B, int* count, int* list, long long* totals, hipStream_t st) {
+  hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(256), 0, st, flag, B, count, list, totals);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
@@ -286,7 +304,7 @@ int launch_log_cmn(float* mel, int B, int T, int NB, float eps, hipStream_t st) 
 }
 
 int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* w, const float* bias,
-                     void* img, int out_bf16, hipStream_t st, float* amax) {
+                     void* img, int out_bf16, hipStream_t st, float* amax, const int* z_count, const int* z_list) {
   ProfScope prof_scope_(st, "stem_conv", 2.0 * B * NB * (double)T * C * 9.0,
                         (double)B * NB * T * 4.0 + (double)B * NB * T * C * (out_bf16 ? 2.0 : 4.0));   // fbank in, C-channel image out
   if (C % 4 || 256 % (C / 4)) return DZN_E_INVALID;
@@ -297,22 +315,22 @@ int launch_stem_conv(const float* fb, int B, int T, int NB, int C, const float* 
   const dim3 grid(gx, B);
   if (out_bf16)
     hipLaunchKernelGGL(stem_conv_kernel<u16>, grid, dim3(256), 0, st, fb, B, T, NB, C, w, bias,
-                       static_cast<u16*>(img), amax);
+                       static_cast<u16*>(img), amax, z_count, z_list);
   else
     hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, st, fb, B, T, NB, C, w, bias,
-                       static_cast<float*>(img), amax);
+                       static_cast<float*>(img), amax, z_count, z_list);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
 int launch_stats_pool(const void* img, int in_bf16, int B, int H, int W, int C, const float* masks, int S,
-                      int L, float* stats, hipStream_t st) {
+                      int L, float* stats, hipStream_t st, const int* active) {
   ProfScope prof_scope_(st, "stats_pool", 0.0, (double)B * H * W * C * (in_bf16 ? 2.0 : 4.0) + (double)B * S * L * 4.0);
   const size_t lds = (size_t)S * W * sizeof(float);
   if (in_bf16)
     hipLaunchKernelGGL(stats_pool_kernel<u16>, dim3(H, B), dim3(256), lds, st, static_cast<const u16*>(img),
-                       H, W, C, masks, S, L, stats);
+                       H, W, C, masks, S, L, stats, active);
   else
     hipLaunchKernelGGL(stats_pool_kernel<float>, dim3(H, B), dim3(256), lds, st,
-                       static_cast<const float*>(img), H, W, C, masks, S, L, stats);
+                       static_cast<const float*>(img), H, W, C, masks, S, L, stats, active);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }

@@ -94,6 +94,16 @@ struct ResBlock {
 
 std::string last_create_error;
 
+// contraction classes of the segmentation model, by the name their call site passes to gemm(): bit index of the
+// DZN_F16_KEEP2 mask (DZN_PREC_F16: classes whose bit is set keep two fp16 terms per operand)
+const char* const F16_CLASSES[] = {"conv gemm", "feature projection", "pos conv", "qkv", "out_proj", "ffn1", "ffn2", "proj",
+                                   "conf ffn w1", "conf ffn w2", "conf qkv", "conf out", "conf pw1", "conf pw2"};
+int f16_class(const char* what) {
+  for (int i = 0; i < (int)(sizeof(F16_CLASSES) / sizeof(F16_CLASSES[0])); ++i)
+    if (!strcmp(what, F16_CLASSES[i])) return i;
+  return -1;
+}
+
 }  // namespace
 
 struct dzn_handle {
@@ -177,13 +187,15 @@ struct dzn_handle {
   };
   std::map<int, EmbGeom> geoms;
   float *frames = nullptr, *spec = nullptr, *pw = nullptr, *fb = nullptr, *pool = nullptr;
-  // (r3) trunk skip for windows without any active speaker: flags / compaction index / position per window, the compact
-  // copies of the active windows' waveforms and masks, their compact embeddings
-  int *win_flag = nullptr, *win_idx = nullptr, *win_pos = nullptr;
-  float *wave_c = nullptr, *masks_c = nullptr, *emb_c = nullptr;
-  int64_t masks_c_per_window = 0;
-  std::vector<int> win_flag_host, win_idx_host, win_pos_host;
-  int64_t emb_windows = 0, emb_windows_skipped = 0;     // counters (dzn_debug / tests)
+  // trunk skip for windows without any active speaker (r3; r4: decided on the device): flag per window, the ascending
+  // list of active windows + its length, running totals (windows seen, windows skipped) for dzn_embed_skip_stats
+  int *win_flag = nullptr, *win_idx = nullptr, *win_cnt = nullptr;
+  long long* emb_totals = nullptr;
+  bool emb_skip = true;       // DZN_EMB_NO_SKIP (read once, at dzn_create) switches the subset off
+  // DZN_PREC_F16 (reduced precision): which contraction classes keep two fp16 terms (F16_CLASSES bit mask; bit 14 = the
+  // ResNet stages 2-4), and whether LayerNorm-folded single-term contractions subtract the row mean BEFORE rounding
+  unsigned f16_keep2 = 0;
+  bool f16_center = true;
 };
 
 namespace {
@@ -847,11 +859,8 @@ void finalize_emb(H* h) {
   h->pool = dalloc<float>(h, B * 8 * feat);
   h->win_flag = dalloc<int>(h, B);
   h->win_idx = dalloc<int>(h, B);
-  h->win_pos = dalloc<int>(h, B);
-  h->wave_c = dalloc<float>(h, B * (int64_t)c.max_samples);
-  h->masks_c_per_window = 8 * ((int64_t)c.max_samples / 160 + 2);     // S <= 8 masks of L <= N / 160 frames
-  h->masks_c = dalloc<float>(h, B * h->masks_c_per_window);
-  h->emb_c = dalloc<float>(h, B * 8 * c.embed_out_dim);
+  h->win_cnt = dalloc<int>(h, 1);
+  h->emb_totals = dalloc<long long>(h, 2);
 }
 
 // bake the geometry of T fbank frames into the row-offset tables and re-zero the image borders.
@@ -1012,9 +1021,16 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   if (L < 1) throw EngineError(DZN_E_INVALID, "window too short");
   const int D = h->D, A = h->A, Fh = h->Fh;
   const int64_t ML = (int64_t)B * L;
+  // DZN_PREC_F16: contraction classes that keep BOTH fp16 terms (three products) — f16_keep2 is a bit mask over
+  // F16_CLASSES below (dzn_handle::f16_keep2, default chosen from the measured sensitivity: profiles/r4_f16_sensitivity*)
   auto gemm = [&](dzn_gemm_desc& d, bool a16, bool c16, const char* what) {
     d.a_bf16 = a16;
     d.c_bf16 = c16;
+    if (c.precision == DZN_PREC_F16) {
+      const int cls = f16_class(what);
+      if (cls >= 0 && ((h->f16_keep2 >> cls) & 1)) d.precision = DZN_PREC_F32_H2;
+      else if (d.ln_stats && h->f16_center) d.ln_centered = 1;
+    }
     // |max| trackers are per window: rows of a [B*L, .] tensor belong to window m / L; z-batched launches
     // (conv stack: z = window) use the z index
     if (d.nz == 1 || (d.a_rowoff && d.a_rowoff == h->pos_rowoff)) d.amax_unit = L;
@@ -1378,8 +1394,13 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
 // ------------------------------------------------------------------ embedding forward
 // bf16 engine mode: the ResNet images are bf16 (operands, residuals and outputs of every conv);
 // fbank (DFT / mel), pooling statistics and seg_1 stay fp32.
-void emb_forward_dense(H* h, const float* wave, const float* masks, int B, int S, int N, int L, float* d_emb,
-                       hipStream_t st) {
+// `subset`: windows in which no speaker is active skip the trunk.  Zero weights pool to zero
+// (PA/models/blocks/pooling.py:44-131 with its 1e-8 guards), so every one of their embeddings is seg_1's bias (SURVEY a18;
+// tests/test_emb_gpu.py holds the device to that bit for bit).  The masks decide it and they only exist on the device, so
+// the subset is built there (window_active -> compact_active: ascending list + count) and every trunk kernel is launched
+// over all B grid rows with (count, list): surplus rows exit at once.  No flag is read back — the call only enqueues
+// (include/dzn.h), and it can be captured in a HIP graph.  The fbank (1 % of the stage) stays dense.
+void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int N, int L, float* d_emb, hipStream_t st) {
   const dzn_config& c = h->cfg;
   const bool lp = c.precision == DZN_PREC_BF16;
   const int flen = 400, fshift = 160, Kp = 416, NB = c.num_mel_bins;
@@ -1388,6 +1409,15 @@ void emb_forward_dense(H* h, const float* wave, const float* masks, int B, int S
   if (T > h->maxTf) throw EngineError(DZN_E_INVALID, "N exceeds max_samples");
   if (S < 1 || S > 8) throw EngineError(DZN_E_INVALID, "S must be in [1, 8]");
   emb_set_geometry(h, T, st);
+  const bool subset = h->emb_skip && !h->debug && !lp && h->seg1.b != nullptr;
+  const int *zc = nullptr, *zl = nullptr, *zflag = nullptr;
+  if (subset) {
+    chk(launch_window_active(masks, B, S * L, h->win_flag, st), "window_active");
+    chk(launch_compact_active(h->win_flag, B, h->win_cnt, h->win_idx, h->emb_totals, st), "compact_active");
+    zc = h->win_cnt;
+    zl = h->win_idx;
+    zflag = h->win_flag;
+  }
   const int64_t MT = (int64_t)B * T;
   // ---- kaldi fbank ----
   chk(launch_frame_prep(wave, B, N, T, flen, fshift, Kp, h->hamming, 0.97f, h->frames, st), "frame_prep");
@@ -1417,7 +1447,7 @@ void emb_forward_dense(H* h, const float* wave, const float* masks, int B, int S
         if (buf == h->sbuf[s2][k]) return h->amax + (dzn_handle::AM_IMG0 + 3 * s2 + k) * MB;
     return nullptr;
   };
-  chk(launch_stem_conv(h->fb, B, T, NB, h->sC[0], h->stem_w, h->stem_b, h->sbuf[0][0], lp, st, img_am(h->sbuf[0][0])),
+  chk(launch_stem_conv(h->fb, B, T, NB, h->sC[0], h->stem_w, h->stem_b, h->sbuf[0][0], lp, st, img_am(h->sbuf[0][0]), zc, zl),
       "stem");
   for (int s = 0; s < 4; ++s) {
     const int Hs = h->sH[s], Ws = h->sW[s], Cc = h->sC[s];
@@ -1430,7 +1460,7 @@ void emb_forward_dense(H* h, const float* wave, const float* masks, int B, int S
           (act == DZN_ACT_NONE || act == DZN_ACT_RELU)) {
         // first ResNet stage: dedicated kernel, every input pixel split once instead of once per tap
         chk(launch_conv3x3_c32_split(in, rc.l.W3, rc.l.b, R, out, B, Hs, Ws, act == DZN_ACT_RELU, post_relu, st,
-                                     img_am(out), rc.l.W2h, rc.l.wsc, img_am(in)),
+                                     img_am(out), rc.l.W2h, rc.l.wsc, img_am(in), zc, zl),
             "resnet conv3x3 c32");
         return;
       }
@@ -1449,6 +1479,9 @@ void emb_forward_dense(H* h, const float* wave, const float* masks, int B, int S
       d.a_bf16 = d.c_bf16 = d.r_bf16 = lp;
       d.a_amax = img_am(in);
       d.c_amax = img_am(out);
+      d.z_count = zc;
+      d.z_list = zl;
+      if (c.precision == DZN_PREC_F16 && ((h->f16_keep2 >> 14) & 1)) d.precision = DZN_PREC_F32_H2;
       chk(launch_gemm(d, st), "resnet conv3x3");
     };
     for (size_t j = 0; j < h->stages[s].size(); ++j) {
@@ -1472,6 +1505,9 @@ void emb_forward_dense(H* h, const float* wave, const float* masks, int B, int S
         d.a_bf16 = d.c_bf16 = lp;
         d.a_amax = img_am(prev);
         d.c_amax = img_am(midb);
+        d.z_count = zc;
+        d.z_list = zl;
+        if (c.precision == DZN_PREC_F16 && ((h->f16_keep2 >> 14) & 1)) d.precision = DZN_PREC_F32_H2;
         chk(launch_gemm(d, st), "resnet conv3x3 s2");
         dzn_gemm_desc e = gd(h, eoff(prev, ((int64_t)(Wp + 2) + 1) * Cpv, lp), rb.sc.l,
                              eoff(scb, interior, lp), M, 0, 0);
@@ -1483,6 +1519,9 @@ void emb_forward_dense(H* h, const float* wave, const float* masks, int B, int S
         e.a_bf16 = e.c_bf16 = lp;
         e.a_amax = img_am(prev);
         e.c_amax = img_am(scb);
+        e.z_count = zc;
+        e.z_list = zl;
+        if (c.precision == DZN_PREC_F16 && ((h->f16_keep2 >> 14) & 1)) e.precision = DZN_PREC_F32_H2;
         chk(launch_gemm(e, st), "resnet shortcut");
         conv3(midb, rb.c2, outb, scb, DZN_ACT_NONE, 1);
         cur = 1;
@@ -1499,54 +1538,13 @@ void emb_forward_dense(H* h, const float* wave, const float* masks, int B, int S
   }
   // ---- TSTP pooling for all S masks + seg_1 ----
   const int feat = h->sC[3] * h->sH[3];
-  chk(launch_stats_pool(prev, lp, B, h->sH[3], h->sW[3], h->sC[3], masks, S, L, h->pool, st), "stats_pool");
+  chk(launch_stats_pool(prev, lp, B, h->sH[3], h->sW[3], h->sC[3], masks, S, L, h->pool, st, zflag), "stats_pool");
   tap(h, "pool", h->pool, (int64_t)B * S, 2 * feat, 2 * feat, st);
   {
     dzn_gemm_desc d = gd(h, h->pool, h->seg1, d_emb, (int64_t)B * S, 2 * feat, c.embed_out_dim);
     d.precision = DZN_PREC_F32;
     chk(launch_gemm(d, st), "seg_1");
   }
-}
-
-// (r3) A window in which none of the S speakers is active needs no trunk: zero weights pool to zero
-// (PA/models/blocks/pooling.py:44-131 with its 1e-8 guards), so every one of its embeddings is seg_1's bias
-// (tests/test_emb_gpu.py holds the device to that bit for bit).  The masks decide it, and they only exist on
-// the device, so the call reads B flags back (one stream synchronisation, ~30 us against a ~50 ms trunk pass), runs the
-// trunk on a compact copy of the active windows and scatters the results.  A batch without silent windows takes the
-// dense path untouched.  DZN_EMB_NO_SKIP=1 switches the check off.
-void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int N, int L, float* d_emb, hipStream_t st) {
-  const dzn_config& c = h->cfg;
-  h->emb_windows += B;
-  if (B <= 0 || h->debug || getenv("DZN_EMB_NO_SKIP") || (int64_t)S * L > h->masks_c_per_window || N > c.max_samples ||
-      !h->seg1.b) {
-    emb_forward_dense(h, wave, masks, B, S, N, L, d_emb, st);
-    return;
-  }
-  chk(launch_window_active(masks, B, S * L, h->win_flag, st), "window_active");
-  h->win_flag_host.resize(B);
-  HIPCHK(hipMemcpyAsync(h->win_flag_host.data(), h->win_flag, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  h->win_idx_host.clear();
-  h->win_pos_host.assign(B, -1);
-  for (int b = 0; b < B; ++b)
-    if (h->win_flag_host[b]) {
-      h->win_pos_host[b] = (int)h->win_idx_host.size();
-      h->win_idx_host.push_back(b);
-    }
-  const int Bc = (int)h->win_idx_host.size();
-  if (Bc == B) {
-    emb_forward_dense(h, wave, masks, B, S, N, L, d_emb, st);
-    return;
-  }
-  h->emb_windows_skipped += B - Bc;
-  HIPCHK(hipMemcpyAsync(h->win_pos, h->win_pos_host.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
-  if (Bc > 0) {
-    HIPCHK(hipMemcpyAsync(h->win_idx, h->win_idx_host.data(), (size_t)Bc * sizeof(int), hipMemcpyHostToDevice, st));
-    chk(launch_gather_rows(wave, h->win_idx, Bc, N, h->wave_c, st), "gather waveforms");
-    chk(launch_gather_rows(masks, h->win_idx, Bc, (int64_t)S * L, h->masks_c, st), "gather masks");
-    emb_forward_dense(h, h->wave_c, h->masks_c, Bc, S, N, L, h->emb_c, st);
-  }
-  chk(launch_scatter_embeddings(h->emb_c, h->win_pos, h->seg1.b, B, S, c.embed_out_dim, d_emb, st), "scatter embeddings");
 }
 
 template <typename F>
@@ -1600,6 +1598,9 @@ int dzn_create(const dzn_config* cfg, dzn_handle** out) {
   if (!h) return DZN_E_NOMEM;
   h->cfg = *cfg;
   if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+  h->emb_skip = getenv("DZN_EMB_NO_SKIP") == nullptr;
+  if (const char* e = getenv("DZN_F16_KEEP2")) h->f16_keep2 = (unsigned)strtoul(e, nullptr, 0);
+  if (const char* e = getenv("DZN_F16_CENTER")) h->f16_center = e[0] != '0';
   const char* dbg = getenv("DZN_DEBUG_TAPS");
   h->debug = dbg && dbg[0] == '1';
   *out = h;
@@ -1738,8 +1739,15 @@ int dzn_debug_fetch(dzn_handle* h, const char* name, float* host_out, int64_t ca
 
 int dzn_embed_skip_stats(const dzn_handle* h, int64_t* windows, int64_t* skipped) {
   if (!h) return DZN_E_INVALID;
-  if (windows) *windows = h->emb_windows;
-  if (skipped) *skipped = h->emb_windows_skipped;
+  long long t[2] = {0, 0};
+  if (h->emb_totals) {      // the totals live on the device (the forward never reads them back): this call synchronises
+    DeviceGuard dg(h->device);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(t, h->emb_totals, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess)
+      return DZN_E_HIP;
+  }
+  if (windows) *windows = (int64_t)t[0];
+  if (skipped) *skipped = (int64_t)t[1];
   return DZN_OK;
 }
 

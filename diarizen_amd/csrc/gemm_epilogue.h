@@ -12,7 +12,10 @@ namespace {
 // General form: every feature test and every column guard sits inside the (i, j) block loop.  Correct for any N / stride,
 // but each block then is its own chain of load -> s_waitcnt vmcnt(0) -> use (col_scale, ln_colsum, bias, R, WS ...):
 // 16 blocks x 3-5 dependent round trips.  Kept for unaligned shapes only; gemm_epilogue() below is the one that runs.
-template <int BM, int BN, int TM, int TN, int MI, int NI>
+// RS / CS (r4): lane -> element map of the accumulator blocks.  16 / 16 = the 16x16 MFMA forms (lane (lr = l & 15, lq = l >> 4) of
+// block (i, j) holds row 16 i + lr, columns 16 j + 4 lq .. + 3); 32 / 8 = the 32x32x16 form viewed as 8-column blocks
+// (lane (lr = l & 31, lq = l >> 5) of block (i, j) holds row 32 i + lr, columns 8 j + 4 lq .. + 3).
+template <int BM, int BN, int TM, int TN, int MI, int NI, int RS = 16, int CS = 16>
 __device__ __forceinline__ void gemm_epilogue_general(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
                                               int wm, int wn, int lr, int lq, int64_t cz, int64_t bz, int z0 = 0,
                                               const float* row_inv = nullptr, const float* col_scale = nullptr) {
@@ -30,7 +33,7 @@ __device__ __forceinline__ void gemm_epilogue_general(const dzn_gemm_desc& d, f3
   const int boundary = two_unit ? (unit0 + 1) * d.amax_unit : 0;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = tm * BM + wm * TM + i * 16 + lr;
+    const int m = tm * BM + wm * TM + i * RS + lr;
     if (m >= d.M) continue;
     const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
     // LayerNorm folded into the weights: finish it with the row statistics (dzn_ops.h)
@@ -40,12 +43,12 @@ __device__ __forceinline__ void gemm_epilogue_general(const dzn_gemm_desc& d, f3
     float ln_mu = 0.f, ln_rs = 1.f;
     if (d.ln_stats) {
       const float2 st = *reinterpret_cast<const float2*>(d.ln_stats + 2 * (int64_t)m);
-      ln_mu = st.x;
+      ln_mu = d.ln_centered ? 0.f : st.x;      // centered: the kernel already multiplied (x - mean)
       ln_rs = st.y;
     }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int n0 = tn * BN + wn * TN + j * 16 + lq * 4;
+      const int n0 = tn * BN + wn * TN + j * CS + lq * 4;
       if (n0 >= d.N) continue;
       f32x4 v = acc[i][j];
       if (vec && n0 + 3 < d.N) {
@@ -110,7 +113,11 @@ __device__ __forceinline__ void gemm_epilogue_general(const dzn_gemm_desc& d, f3
       // leaves (sum, sum of squares) of its TN columns; stats_finalize_kernel adds the tilesN * (BN / TN) partials of a
       // row in a fixed order (deterministic) and turns them into (mean, rstd) — the separate row_stats pass over the
       // tensor disappears.  The row lives in lanes lr, lr + 16, lr + 32, lr + 48.
-      float s1 = st_s + __shfl_xor(st_s, 16, 64), q1 = st_q + __shfl_xor(st_q, 16, 64);
+      float s1 = st_s, q1 = st_q;
+      if constexpr (RS == 16) {
+        s1 += __shfl_xor(s1, 16, 64);
+        q1 += __shfl_xor(q1, 16, 64);
+      }
       s1 += __shfl_xor(s1, 32, 64);
       q1 += __shfl_xor(q1, 32, 64);
       if (lq == 0) {
@@ -124,7 +131,8 @@ __device__ __forceinline__ void gemm_epilogue_general(const dzn_gemm_desc& d, f3
         else amax_hi = fmaxf(amax_hi, amax_row);
       } else if (d.amax_unit > 0) {
         // the row lives in lanes lr, lr + 16, lr + 32, lr + 48 (all of them took this branch: m depends on lr only)
-        float r = fmaxf(amax_row, __shfl_xor(amax_row, 16, 64));
+        float r = amax_row;
+        if constexpr (RS == 16) r = fmaxf(r, __shfl_xor(r, 16, 64));
         r = fmaxf(r, __shfl_xor(r, 32, 64));
         if (lq == 0) track_amax_lane(d.c_amax + m / d.amax_unit, r);
       } else {
@@ -169,14 +177,14 @@ __device__ __forceinline__ float apply_act_c(float v) {
 //   * out-of-range rows / columns load from clamped (valid) addresses and only their STORES are predicated: no control
 //     flow between the loads; the activation is a template argument (one switch per wavefront).
 // Needs 4-element alignment of N and every stride (else the general form).
-template <int BM, int BN, int TM, int TN, int MI, int NI, bool LDSCOLS = false>
+template <int BM, int BN, int TM, int TN, int MI, int NI, bool LDSCOLS = false, int RS = 16, int CS = 16>
 __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
                                               int wm, int wn, int lr, int lq, int64_t cz, int64_t bz, int z0 = 0,
                                               const float* row_inv = nullptr, const float* col_scale = nullptr,
                                               float* lds_cols = nullptr) {
   const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0 && d.N >= 4;
   if (!vec) {
-    gemm_epilogue_general<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, col_scale);
+    gemm_epilogue_general<BM, BN, TM, TN, MI, NI, RS, CS>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, col_scale);
     return;
   }
   // column blocks per batch: 4 keeps acc + two residual batches + the hoisted column-vector reads inside 256 registers
@@ -186,11 +194,11 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
   constexpr int NJC = NI / JC, NB = MI * NJC;            // batch b = (row block b / NJC, column chunk b % NJC)
   constexpr bool REGCOLS = !LDSCOLS && NI <= 4;          // register column vectors need 12 NI registers
   const float* __restrict__ bias = d.bias ? d.bias + bz : nullptr;
-  const int ncol0 = tn * BN + wn * TN + lq * 4;          // column of block j: ncol0 + 16 j
+  const int ncol0 = tn * BN + wn * TN + lq * 4;          // column of block j: ncol0 + CS j
   // recomputed at every use rather than kept in 2 NI registers: N % 4 == 0, so a float4 is inside or outside as a whole
-  auto nok_ = [&](const int j) { return ncol0 + j * 16 < d.N; };
+  auto nok_ = [&](const int j) { return ncol0 + j * CS < d.N; };
   auto nc_ = [&](const int j) {                          // ... clamped for the loads
-    const int n0 = ncol0 + j * 16;
+    const int n0 = ncol0 + j * CS;
     return n0 < d.N ? n0 : d.N - 4;
   };
   int64_t crow[MI];
@@ -198,7 +206,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
   int mcl[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = tm * BM + wm * TM + i * 16 + lr;
+    const int m = tm * BM + wm * TM + i * RS + lr;
     mok[i] = m < d.M;
     mcl[i] = mok[i] ? m : d.M - 1;
     crow[i] = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[mcl[i]] : (int64_t)mcl[i] * d.ldc);
@@ -221,7 +229,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const float2 st = *reinterpret_cast<const float2*>(d.ln_stats + 2 * (int64_t)mcl[i]);
-      ln_mu[i] = st.x;
+      ln_mu[i] = d.ln_centered ? 0.f : st.x;   // centered (DZN_PREC_F16): the kernel already multiplied (x - mean)
       ln_rs[i] = st.y;
     }
   }
@@ -246,7 +254,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     }
   } else if constexpr (LDSCOLS) {
     // lane l < TN / 4 owns columns 4 l .. 4 l + 3 of the wavefront tile
-    const int lane = lq * 16 + lr;
+    const int lane = lq * RS + lr;
     if (lane < TN / 4) {
       int n = tn * BN + wn * TN + 4 * lane;
       n = n < d.N ? n : d.N - 4;
@@ -264,7 +272,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     if constexpr (REGCOLS) {
       c = cs4[j]; l = lc4[j]; bb = b4[j];
     } else if constexpr (LDSCOLS) {
-      const float* p = lds_cols + j * 16 + lq * 4;
+      const float* p = lds_cols + j * CS + lq * 4;
       c = *reinterpret_cast<const float4*>(p);
       l = *reinterpret_cast<const float4*>(p + TN);
       bb = *reinterpret_cast<const float4*>(p + 2 * TN);
@@ -371,12 +379,16 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
   const int boundary = two_unit ? (unit0 + 1) * d.amax_unit : 0;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = tm * BM + wm * TM + i * 16 + lr;
+    const int m = tm * BM + wm * TM + i * RS + lr;
     if (!mok[i]) continue;
     if (d.stat_partial) {
       // every wavefront leaves (sum, sum of squares) of its TN columns; stats_finalize_kernel adds the tilesN * (BN / TN)
       // partials of a row in a fixed order (deterministic).  The row lives in lanes lr, lr + 16, lr + 32, lr + 48.
-      float s1 = st_s[i] + __shfl_xor(st_s[i], 16, 64), q1 = st_q[i] + __shfl_xor(st_q[i], 16, 64);
+      float s1 = st_s[i], q1 = st_q[i];
+      if constexpr (RS == 16) {
+        s1 += __shfl_xor(s1, 16, 64);
+        q1 += __shfl_xor(q1, 16, 64);
+      }
       s1 += __shfl_xor(s1, 32, 64);
       q1 += __shfl_xor(q1, 32, 64);
       if (lq == 0) {
@@ -389,7 +401,8 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
         if (m < boundary) amax = fmaxf(amax, amax_row[i]);
         else amax_hi = fmaxf(amax_hi, amax_row[i]);
       } else if (d.amax_unit > 0) {
-        float r = fmaxf(amax_row[i], __shfl_xor(amax_row[i], 16, 64));
+        float r = amax_row[i];
+        if constexpr (RS == 16) r = fmaxf(r, __shfl_xor(r, 16, 64));
         r = fmaxf(r, __shfl_xor(r, 32, 64));
         if (lq == 0) track_amax_lane(d.c_amax + m / d.amax_unit, r);
       } else {

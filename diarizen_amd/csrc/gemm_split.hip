@@ -99,7 +99,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   }
   const int tm = t / tilesN, tn = t % tilesN;
   const int z = blockIdx.y;
-  const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
+  int z0 = z / d.zdiv;
+  const int z1 = z - z0 * d.zdiv;
+  if (d.z_list) {   // device-chosen subset of the batch (dzn_gemm_desc.z_count / z_list)
+    if (z0 >= d.z_count[0]) return;
+    z0 = d.z_list[z0];
+  }
   const float* __restrict__ A = d.A + z0 * d.a_z0 + z1 * d.a_z1;
   const u16* __restrict__ W3 =
       reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + SP * (z0 * d.w_z0 + z1 * d.w_z1);
@@ -115,6 +120,23 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
       int m = tm * BM + wm * TM + i * 16 + (lane & 15);
       m = m < d.M ? m : d.M - 1;
       h2_scale(d.a_amax[d.amax_unit > 0 ? m / d.amax_unit : z0], a_scale[i], row_inv[i]);
+    }
+  }
+  // NP = 1 with a folded LayerNorm (d.ln_centered): the row mean is subtracted before the fp16 rounding; |x - mean| <=
+  // 2 amax, so the scale gives up one bit of headroom
+  float a_mean[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a_mean[i] = 0.f;
+  if constexpr (NP == 1) {
+    if (d.ln_centered && d.ln_stats) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        int m = tm * BM + wm * TM + i * 16 + (lane & 15);
+        m = m < d.M ? m : d.M - 1;
+        a_mean[i] = d.ln_stats[2 * (int64_t)m];
+        a_scale[i] *= 0.5f;
+        row_inv[i] *= 2.f;
+      }
     }
   }
   const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
       for (int j = 0; j < NI; ++j) acc[i][j] = mfma_np<NP>(wf[j][0], af[0], acc[i][j]);
     }
   };
-  auto split = [&](const f32x4 (&a)[2], u32x4 (&af)[NP], float sc) {
+  auto split = [&](const f32x4 (&a)[2], u32x4 (&af)[NP], float sc, float mu = 0.f) {
     if constexpr (ABL == 1) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) af[p] = __builtin_bit_cast(u32x4, a[p & 1]);
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
     } else if constexpr (NP == 2) {
       split8_h2(a[0], a[1], sc, af[0], af[1]);
     } else {
-      cvt8_h1(a[0], a[1], sc, af[0]);
+      cvt8_h1(a[0] - mu, a[1] - mu, sc, af[0]);      // mu = 0 unless d.ln_centered (x - 0 is exact)
     }
   };
 
@@ -270,12 +292,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
 #pragma unroll
     for (int i = 0; i < MH; ++i) {
       u32x4 af[NP];
-      split(ar[i], af, a_scale[i]);
+      split(ar[i], af, a_scale[i], a_mean[i]);
       mma(i, wc, af);
     }
     u32x4 af2[MI - MH][NP];
 #pragma unroll
-    for (int i = MH; i < MI; ++i) split(ar[i], af2[i - MH], a_scale[i]);
+    for (int i = MH; i < MI; ++i) split(ar[i], af2[i - MH], a_scale[i], a_mean[i]);
     const int nstage = stage + 1 == S ? 0 : stage + 1;
     __builtin_amdgcn_sched_barrier(0);  // keep the second half of the MFMAs BEHIND the barrier block
     if (more) {
@@ -309,6 +331,285 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
     gemm_epilogue<BM, BN, TM, TN, MI, NI>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr);
   }
 }
+
+#ifdef DZN_TUNING
+// ---- (r4) the same contraction on 32x32x16 MFMA blocks: a MEASURED NEGATIVE, kept as a DZN_TUNING probe ------------------
+// VERDICT r3 item 4 asked for it.  Result (profiles/r4_gemm_m32_probe.txt, M = 149 226): 253-272 TFLOP/s where the
+// 16x16x32 tile below has 285-305 on the same shapes (N = K = 1024: 270 vs 305; N 1920: 272 vs 304; K = 256: 149 vs 170),
+// s_setprio around the MFMA cluster changes nothing, 2 x 2 / 256 x 128 wavefront layouts are slower still, and in the
+// pipeline the step loses 4 % (1160 vs 1116 ms).  Same LDS bytes, same DMA schedule, half the MFMA instructions: the
+// contraction is evidently not bound by MFMA issue or operand-register reads.  (Not isolated further: the form has 4
+// independent accumulator blocks per wavefront where the 16x16 form has 16, against a 16-pass dependent latency.)
+// v_mfma_f32_32x32x16_f16 does twice the flops of v_mfma_f32_16x16x32_f16 from the same 4 + 4 operand registers: half
+// the operand-register reads per flop, and the instruction retires 2 x 16 passes where two 16x16x32 need 2 x 8 + issue gaps
+// (guide: 2178 vs 1955 TFLOP/s fp16 micro-benchmark ceilings).  Same tile, same LDS images, same LDS-DMA schedule and the
+// same weight planes as gemm_split_kernel — only the lane -> element map changes:
+//   * lane (l31 = lane & 31, lh = lane >> 5) owns row / column l31 of a 32-wide block and the k subset of chunk
+//     c = 2 kh + lh of the 32-k tile, kh = 0, 1 being the two 16-k MFMAs of the tile.  The weight planes keep their k
+//     order (chunk c = k in {4c..4c+3} u {16+4c..16+4c+3}); the A fragment of chunk c is the fp32 slots c and 4 + c of the
+//     row — exactly what the 16x16 form reads for lq = c — so both operands of an MFMA cover the same 16 k.
+//   * ds_read_b128 stays conflict free: a 16-lane group of the instruction now holds 16 different rows of ONE chunk; the
+//     A swizzle (slot ^ (row >> 1) & 7) and the W swizzle (slot ^ g((row >> 2) & 3)) spread those over all 16 slots.
+//   * accumulators: lane holds row l31, columns 32 j + 8 g + 4 lh + (0..3) for g = 0..3: four float4 per block; the
+//     epilogue sees them as 8-column blocks (gemm_epilogue<..., RS = 32, CS = 8>).
+// The K tile is multiplied in its two 16-k halves with the barrier block between them (the 16x16 form splits by rows).
+// NP = 2 (f32h) and NP = 1 (f16) only.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int PRIO = 0>
+__global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split32_kernel(const dzn_gemm_desc d) {
+  static_assert(NP == 1 || NP == 2, "fp16 forms only");
+  constexpr int NW = WGM * WGN;
+  constexpr int BK = 32;
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MI = TM / 32, NJ = TN / 32;
+  constexpr int RB = NW * 1024;
+  constexpr int ACH = BM * 128 / RB;
+  constexpr int WROWS = NW * 16;
+  constexpr int WR = (BN + WROWS - 1) / WROWS;
+  constexpr int ABYTES = BM * 128, WPLANE = BN * 64, BUF = ABYTES + NP * WPLANE;
+  constexpr int LPT = ACH + NP * WR;
+  constexpr bool WPART = BN % WROWS != 0;
+  static_assert(BM * 128 % RB == 0 && TM % 32 == 0 && TN % 32 == 0, "tile geometry");
+  static_assert(S >= 2 && (S - 1) * LPT < 64, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tilesN = (d.N + BN - 1) / BN;
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = t / tilesN, tn = t % tilesN;
+  const int z = blockIdx.y;
+  int z0 = z / d.zdiv;
+  const int z1 = z - z0 * d.zdiv;
+  if (d.z_list) {
+    if (z0 >= d.z_count[0]) return;
+    z0 = d.z_list[z0];
+  }
+  const float* __restrict__ A = d.A + z0 * d.a_z0 + z1 * d.a_z1;
+  const u16* __restrict__ W2 = reinterpret_cast<const u16*>(d.W2h) + 2 * (z0 * d.w_z0 + z1 * d.w_z1);
+  const int l31 = lane & 31, lh = lane >> 5;
+  float a_scale[MI], row_inv[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    int m = tm * BM + wm * TM + i * 32 + l31;
+    m = m < d.M ? m : d.M - 1;
+    h2_scale(d.a_amax[d.amax_unit > 0 ? m / d.amax_unit : z0], a_scale[i], row_inv[i]);
+  }
+  const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
+  const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
+
+  // ---- LDS-DMA sources: identical to gemm_split_kernel ----
+  const int r0 = tid >> 3;
+  const int csw = (tid & 7) ^ ((r0 >> 1) & 7);
+  const float* aptr[ACH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    int m = tm * BM + r0 + 8 * NW * i;
+    m = m < d.M ? m : d.M - 1;
+    aptr[i] = A + (d.a_rowoff ? (int64_t)d.a_rowoff[m] : (int64_t)m * d.lda) + csw * 4;
+  }
+  const bool wfull = !WPART || (WR - 1) * WROWS + wave * 16 < BN;
+  const int wr0 = wave * 16 + (lane >> 2);
+  const int wsw = (lane & 3) ^ wswz(wr0);
+  const u16* wptr[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    int n = tn * BN + wr0 + WROWS * i;
+    n = n < d.N ? n : d.N - 1;
+    wptr[i] = W2 + (int64_t)n * 2 * d.ldw + wsw * 8;
+  }
+  int ik = 0, irem = 0;
+  int64_t ikoff = 0;
+  auto issue = [&](int stage) {
+    unsigned char* sA = smem + stage * BUF + wave * 1024;
+    unsigned char* sW = smem + stage * BUF + ABYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[i] + ikoff),
+                                       (__attribute__((address_space(3))) void*)(sA + i * RB), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int i = 0; i < WR; ++i)
+        if (i + 1 < WR || wfull)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(wptr[i] + 2 * ik + p * 32),
+              (__attribute__((address_space(3))) void*)(sW + p * WPLANE + i * RB), 16, 0, 0);
+    ik += BK;
+    irem += BK;
+    ikoff += BK;
+    if (irem == d.kc) { irem = 0; ikoff += d.ldk - d.kc; }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // per-lane LDS byte offsets: [block][k half]
+  int woff[NJ][2], aoff0[MI][2], aoff1[MI][2];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = wn * TN + j * 32 + l31;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) woff[j][kh] = ABYTES + row * 64 + (((2 * kh + lh) ^ wswz(row)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * TM + i * 32 + l31;
+    const int sw = (row >> 1) & 7;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const int c = 2 * kh + lh;
+      aoff0[i][kh] = row * 128 + ((c ^ sw) << 4);
+      aoff1[i][kh] = row * 128 + (((4 + c) ^ sw) << 4);
+    }
+  }
+  auto read_w = [&](int stage, u32x4 (&wf)[NJ][2][NP]) {
+    const unsigned char* base = smem + stage * BUF;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) wf[j][kh][p] = *reinterpret_cast<const u32x4*>(base + p * WPLANE + woff[j][kh]);
+  };
+  auto read_a = [&](int stage, f32x4 (&ar)[MI][2][2]) {
+    const unsigned char* base = smem + stage * BUF;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        ar[i][kh][0] = *reinterpret_cast<const f32x4*>(base + aoff0[i][kh]);
+        ar[i][kh][1] = *reinterpret_cast<const f32x4*>(base + aoff1[i][kh]);
+      }
+  };
+  auto mfma32 = [&](const u32x4& a, const u32x4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  };
+  // the products of row block i against all NJ column blocks for one 16-k half: smallest terms first, NJ independent
+  // accumulators between dependent MFMAs (32x32x16: 16 passes, the next MFMA on the same block is 4 instructions away)
+  auto mma = [&](int i, int kh, const u32x4 (&wf)[NJ][2][NP], const u32x4 (&af)[NP]) {
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+    if constexpr (NP == 2) {
+      constexpr int PW[3] = {1, 0, 0}, PA[3] = {0, 1, 0};                     // lo*hi hi*lo hi*hi
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(wf[j][kh][PW[t]], af[PA[t]], acc[i][j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(wf[j][kh][0], af[0], acc[i][j]);
+    }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  auto split = [&](const f32x4 (&a)[2], u32x4 (&af)[NP], float sc) {
+    if constexpr (NP == 2) split8_h2(a[0], a[1], sc, af[0], af[1]);
+    else cvt8_h1(a[0], a[1], sc, af[0]);
+  };
+
+  const int nk = d.K / BK;
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    if (s < nk) issue(s);
+  auto wait_tiles = [&](auto tiles) {
+    constexpr int T = decltype(tiles)::value;
+    if (wfull) wait_vm_lgkm0<T * LPT>();
+    else wait_vm_lgkm0<T * (LPT - NP)>();
+  };
+  if (nk >= S) wait_tiles(std::integral_constant<int, S - 1>{});
+  else wait_vm_lgkm0<0>();
+  __builtin_amdgcn_s_barrier();
+  u32x4 wfa[NJ][2][NP], wfb[NJ][2][NP];
+  f32x4 ar[MI][2][2];
+  read_w(0, wfa);
+  read_a(0, ar);
+  int stage = 0;
+
+  auto step = [&](int kt, const u32x4 (&wc)[NJ][2][NP], u32x4 (&wn_)[NJ][2][NP]) {
+    const bool more = kt + 1 < nk;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      u32x4 af[NP];
+      split(ar[i][0], af, a_scale[i]);
+      mma(i, 0, wc, af);
+    }
+    u32x4 af2[MI][NP];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) split(ar[i][1], af2[i], a_scale[i]);
+    const int nstage = stage + 1 == S ? 0 : stage + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      if (kt + S <= nk) wait_tiles(std::integral_constant<int, S - 2>{});
+      else wait_vm_lgkm0<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + S < nk) issue(stage);
+      read_w(nstage, wn_);
+      read_a(nstage, ar);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) mma(i, 1, wc, af2[i]);
+    stage = nstage;
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, wfa, wfb);
+    if (kt + 1 < nk) step(kt + 1, wfb, wfa);
+  }
+  __syncthreads();
+  // accumulators as 8-column blocks: block 4 j + g of lane (l31, lh) = columns 32 j + 8 g + 4 lh .. + 3 of row 32 i + l31
+  f32x4 accv[MI][4 * NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accv[i][4 * j + g][e] = acc[i][j][4 * g + e];
+  gemm_epilogue<BM, BN, TM, TN, MI, 4 * NJ, true, 32, 8>(d, accv, tm, tn, wm, wn, l31, lh, cz, bz, z0, row_inv, d.col_scale,
+                                                       reinterpret_cast<float*>(smem) + wave * 3 * TN);
+}
+
+template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int PRIO = 0>
+int launch_split32_cfg(const dzn_gemm_desc& d, hipStream_t s) {
+  const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+  const size_t lds = (size_t)S * (BM * 128 + NP * BN * 64);
+  auto kern = gemm_split32_kernel<BM, BN, WGM, WGN, S, NP, OCC, PRIO>;
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(attr_mask))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  dim3 grid(tilesM * tilesN, d.nz > 0 ? d.nz : 1, 1);
+  int pid = -1;
+  if (prof_enabled()) {
+    char cls[64];
+    static const bool by_shape = getenv("DZN_PROFILE_SHAPES") != nullptr;
+    if (by_shape)
+      snprintf(cls, sizeof(cls), "gemm_%s_%dx%d M%d N%d K%d z%d", NP == 2 ? "f32h" : "f16", BM, BN, d.M, d.N, d.K, d.nz);
+    else
+      snprintf(cls, sizeof(cls), "gemm_%s_%dx%d", NP == 2 ? "f32h" : "f16", BM, BN);
+    const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
+    pid = prof_begin(s, cls, fl, gemm_alg_bytes(d, NP * 2));
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, d);
+  prof_end(pid, s);
+  if (hipGetLastError() != hipSuccess) return DZN_E_HIP;
+  if (d.stat_partial && d.stat_final)
+    return launch_stats_finalize(d.stat_partial, d.M, tilesN * WGN, d.stat_C, d.stat_eps, d.stat_final, s);
+  return DZN_OK;
+}
+
+#endif  // DZN_TUNING (32x32x16 probe)
 
 template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0>
 int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
@@ -391,13 +692,22 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     if constexpr (NP == 1) {
       if (!strcmp(force, "256x128w8s3")) return launch_split_cfg<256, 128, 8, 1, 3, NP, 2>(d, s);
     }
-#ifdef DZN_TUNING   // probe / ablation instantiations (profiles/r2_gemm_cfg_probe.txt, r2_gemm_ablation.txt): build with
+#ifdef DZN_TUNING
+    if constexpr (NP <= 2) {    // (r4) 32x32x16 MFMA forms
+      if (!strcmp(force, "m32_128x128")) return launch_split32_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);
+      if (!strcmp(force, "m32_128x64")) return launch_split32_cfg<128, 64, 4, 1, 2, NP, 3>(d, s);
+    }   // probe / ablation instantiations (profiles/r2_gemm_cfg_probe.txt, r2_gemm_ablation.txt): build with
                     // DZN_TUNING=1 (diarizen_amd/build.py); they triple the compile time of this file
     if (!strcmp(force, "256x128")) return launch_split_cfg<256, 128, 4, 2, 2, NP>(d, s);
     if constexpr (NP != 3) {
       if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2, NP>(d, s);
     }
     if constexpr (NP <= 2) {
+      if (!strcmp(force, "m32_128x128p")) return launch_split32_cfg<128, 128, 4, 1, 2, NP, 2, 1>(d, s);   // + s_setprio around the MFMAs
+      if (!strcmp(force, "m32_128x128w22")) return launch_split32_cfg<128, 128, 2, 2, 2, NP, 2>(d, s);    // 2 x 2 wavefronts of 64 x 64
+      if (!strcmp(force, "m32_256x128")) return launch_split32_cfg<256, 128, 4, 2, 2, NP, 1>(d, s);       // 8 wavefronts of 64 x 64
+      if (!strcmp(force, "m32_256x128w8")) return launch_split32_cfg<256, 128, 8, 1, 2, NP, 1>(d, s);     // 8 wavefronts of 32 x 128
+      if (!strcmp(force, "m32_128x64p")) return launch_split32_cfg<128, 64, 4, 1, 2, NP, 3, 1>(d, s);
       // deeper LDS-DMA pipelines (more K tiles in flight per CU): probes of the load-latency bound.  (128x128 with
       // S = 3 / 4 were probed too — one wavefront per SIMD in the two-term kernel, 30 % slower)
       if (!strcmp(force, "256x128s3")) return launch_split_cfg<256, 128, 4, 2, 3, NP>(d, s);
@@ -414,6 +724,12 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   }
   // (r3's 8-wavefront ping-pong forms — gemm_pp.hip, 256 x 192 tiles — measured +0.5 % on the step and were removed in r4;
   // the A/B record is profiles/r3_gemm_pq_probe.txt, the source is in the history at 7bb9ad7)
+#ifdef DZN_TUNING
+  // (r4) DZN_GEMM_M32 (read once): bit 0 = the 128 x 128 class, bit 1 = the 128 x 64 class run on 32x32x16 MFMA blocks
+  static const int m32 = getenv("DZN_GEMM_M32") ? atoi(getenv("DZN_GEMM_M32")) : 0;
+#else
+  constexpr int m32 = 0;
+#endif
   // launch bounds pin the occupancy the tile was tuned at (r3: the pipelined epilogue gives the register allocator
   // room to trade occupancy for more loads in flight; 128x64 tiles want 3 workgroups per CU, 128x128 two)
   constexpr int OCC64 = NP <= 2 ? 3 : 2;
@@ -424,6 +740,11 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   // shapes now that the epilogue is pipelined — 424 vs 444 us at 149226 x 1024 x 256; in the pipeline the step time did
   // not move (1139 vs 1124-1142 ms), so the short-K launches stay on the narrow tile and the 128x128 symbol stays a
   // homogeneous K >= 768 class for the roofline line)
+#ifdef DZN_TUNING
+  if constexpr (NP <= 2) {
+    if ((m32 & 2) && d.N > 32 && (d.N <= 64 || d.K <= 512)) return launch_split32_cfg<128, 64, 4, 1, 2, NP, 3>(d, s);
+  }
+#endif
   if (d.N <= 64 || d.K <= 512) return launch_split_cfg<128, 64, 4, 1, 2, NP, OCC64>(d, s);
   // 128-wide column tiles unless 64-wide ones save more than ~1/8 of the (padded) columns; widths that
   // are multiples of 80 but not of 64 (conv1 of the extractor: 153 -> 160) get exact 80-wide tiles
@@ -439,7 +760,12 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   // NP = 1 (DZN_PREC_F16) is bound by the global -> LDS fill, not by MFMA / VALU (ablation: profiles/r2_gemm_ablation.txt):
   // 256 x 128 tiles halve the W bytes per flop and a third stage keeps two K tiles in flight: +7..13 % (r2_gemm_cfg_probe.txt)
   if constexpr (NP == 1) return launch_split_cfg<256, 128, 8, 1, 3, NP, 2>(d, s);
-  if constexpr (NP == 2) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);   // held to 2 wavefronts per SIMD
+  if constexpr (NP == 2) {
+#ifdef DZN_TUNING
+    if (m32 & 1) return launch_split32_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);
+#endif
+    return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);   // held to 2 wavefronts per SIMD
+  }
   return launch_split_cfg<128, 128, 2, 2, 2, NP, 2>(d, s);
 }
 

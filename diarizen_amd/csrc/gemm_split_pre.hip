@@ -59,7 +59,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
   }
   const int tm = t / tilesN, tn = t % tilesN;
   const int z = blockIdx.y;
-  const int z0 = z / d.zdiv, z1 = z - z0 * d.zdiv;
+  int z0 = z / d.zdiv;
+  const int z1 = z - z0 * d.zdiv;
+  if (d.z_list) {   // device-chosen subset of the batch (dzn_gemm_desc.z_count / z_list)
+    if (z0 >= d.z_count[0]) return;
+    z0 = d.z_list[z0];
+  }
   const u16* __restrict__ A3 = reinterpret_cast<const u16*>(d.A) + z0 * d.a_z0 + z1 * d.a_z1;
   const u16* __restrict__ W3 =
       reinterpret_cast<const u16*>(NP == 3 ? d.W3 : d.W2h) + SP * (z0 * d.w_z0 + z1 * d.w_z1);

@@ -202,9 +202,11 @@ int dzn_cluster_activations(const uint8_t* d_seg, const int8_t* d_hard, int32_t 
 int dzn_debug_fetch(dzn_handle* h, const char* name, float* host_out, int64_t cap,
                     int64_t* n_elems);
 
-/* (r3) dzn_embed_forward skips the ResNet trunk for windows in which no speaker is active (their embeddings are seg_1's
- * bias: zero weights pool to zero, PA/models/blocks/pooling.py:44-131).  Counters since dzn_create: windows seen by
- * dzn_embed_forward / windows whose trunk pass was skipped.  No reference counterpart (diagnostics). */
+/* dzn_embed_forward skips the ResNet trunk for windows in which no speaker is active (their embeddings are seg_1's
+ * bias: zero weights pool to zero, PA/models/blocks/pooling.py:44-131).  The subset is chosen ON THE DEVICE (r4): the
+ * forward reads nothing back and stays enqueue-only.  Counters since dzn_create: windows seen by dzn_embed_forward /
+ * windows whose trunk pass was skipped; they live on the device, so THIS call synchronises the device (diagnostics;
+ * no reference counterpart).  DZN_EMB_NO_SKIP in the environment at dzn_create switches the subset off. */
 int dzn_embed_skip_stats(const dzn_handle* h, int64_t* windows, int64_t* skipped);
 
 int dzn_num_ignored(const dzn_handle* h);

@@ -103,6 +103,15 @@ typedef struct dzn_gemm_desc {
   float* stat_final;
   int32_t stat_C;
   float stat_eps;
+  /* z-batched launches over a SUBSET of the z0 indices that is chosen ON THE DEVICE (the embedding trunk skips windows
+   * without an active speaker without a host round trip): the launch still has nz grid rows; grid row y works on
+   * z0 = z_list[y / zdiv] when y / zdiv < z_count[0] and exits otherwise.  NULL = every z0. */
+  const int32_t* z_count;
+  const int32_t* z_list;
+  /* DZN_PREC_F16 with ln_stats: the single-term kernel subtracts the row mean BEFORE it rounds A to fp16 and the epilogue
+   * only multiplies by rstd — C = rstd * ((x - mean) W'^T) + bias, LayerNorm as defined, instead of the folded form
+   * rstd * (x W'^T - mean colsum), whose two terms cancel to the size of the rounding error when |mean| >> std(x). */
+  int32_t ln_centered;
 } dzn_gemm_desc;
 
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
