@@ -72,6 +72,19 @@ PARITY_NOTE = {
     "unpinned": ["kaldi fbank vs torchaudio (absent offline; == transformers.audio_utils to 1e-6 in float64)",
                  "pyannote.core 5.0.0 frame arithmetic / RTTM writer (absent offline)"]}
 ALT_STEPS = 5          # timed steps of every comparison leg (other fp32 modes, reduced precision)
+# the reduced mode against SURVEY 8d's reduced bar (max |dlogp| <= 5e-2, argmax >= 99.5 %, cos >= 0.999, DER delta <= 0.1 abs),
+# stated as measured — it does NOT meet the log-prob / DER part on the non-degenerate stress weights
+F16_PARITY = {
+    "meets_survey_8d_reduced_bar": False,
+    "plain_seeded_goldens": "meets it: max |dlogp| 6e-3..1e-2, argmax 100 % (tests/test_seg_gpu.py::test_seg_f16_within_tolerance)",
+    "turn_taking_goldens": "FAILS the log-prob bar: max |dlogp| 0.15 (large-s80) / 0.18 (base-s80) vs 5e-2; argmax 99.50 % / 99.71 % vs "
+                           "99.5 % (test_seg_f16_on_the_turn_taking_fixtures_is_reported_against_the_reduced_bar)",
+    "der_vs_fp32_rttm": "0.73 % on EN2002a_30s with the seeded stress weights vs a bar of 0.1 abs (tests/test_pipeline_gpu.py::"
+                        "test_der_between_arithmetic_modes); no trained weights / AMI audio offline",
+    "embeddings": "cos >= 0.9999 vs the f32h embeddings (bar 0.999)",
+    "why": "profiles/r4_f16_sensitivity.json: the error of the single-term mode is spread over every contraction class — keeping two "
+           "terms in any ONE class leaves max |dlogp| at 0.13..0.26, in every class but the transformer linears at 0.10; only two terms "
+           "everywhere (= f32h) is under 5e-2.  The conv stack keeps two terms by default (70 % of the error variance, 4 % of the flops)."}
 
 
 from testkit.synth import synth_recording  # noqa: E402
@@ -465,6 +478,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (device + host AHC) leg")
     ap.add_argument("--e2e-steps", type=int, default=3, help="timed passes of the end-to-end leg (upload + device + host AHC)")
     ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE configs[1] leg (base-s80, 5 s x 32, segmentation only)")
+    ap.add_argument("--only-config1", action="store_true", help="run just the BASELINE configs[1] leg and print its object")
     ap.add_argument("--config1-steps", type=int, default=2)
     ap.add_argument("--config1-minutes", type=float, default=30.0)
     ap.add_argument("--config1-streams", type=int, default=2,
@@ -517,6 +531,9 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
+    if args.only_config1:
+        print(json.dumps(config1_leg(args, dev)))
+        return
     from diarizen_amd import _lib
     from diarizen_amd.configs import RESNET34, get_seg_config
     from diarizen_amd.dist import gather_windows
@@ -737,9 +754,7 @@ def main():
             out["reduced_precision_mode"] = {"f16": {"value": round(audio_s / dt2, 2), "unit": "audio-seconds/s",
                                                      "ms_per_step": round(dt2 * 1e3, 2), "steps": ALT_STEPS,
                                                      "dtype": DTYPE_NOTE["f16"],
-                                                     "parity": "reduced-precision bar (tests/test_seg_gpu.py::"
-                                                               "test_seg_f16_within_tolerance: max |dlogp| <= 5e-2, "
-                                                               "argmax >= 99.5 %; embeddings cos >= 0.999)"}}
+                                                     "parity": F16_PARITY}}
         if world == 1 and full and not args.no_e2e and args.minutes <= 60:
             eng = None
             torch.cuda.empty_cache()

@@ -128,6 +128,7 @@ int launch_pad_rows_split2(const float* x, void* planes, int64_t plane_stride, i
 int launch_split_weights(const float* W, int64_t rows, int K, int64_t ldw, void* W3, hipStream_t s);
 int launch_split_weights_h2(const float* W, int64_t rows, int K, int64_t ldw, void* W2, float* col_scale, hipStream_t s);
 int launch_amax(const float* x, int64_t n, float* amax, hipStream_t s);
+int launch_fill_u32(void* p, unsigned value, int64_t n, hipStream_t st);   // norm.hip: p[0 .. n) = value, as a kernel (graph-safe ordering)
 int launch_stats_finalize(const float* partial, int64_t rows, int P, int C, float eps, float* stats, hipStream_t s);
 int launch_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, const float* g,
                      const float* b, int64_t rows, int C, int Cpad, float eps, int gelu,

@@ -194,8 +194,13 @@ struct dzn_handle {
   bool emb_skip = true;       // DZN_EMB_NO_SKIP (read once, at dzn_create) switches the subset off
   // DZN_PREC_F16 (reduced precision): which contraction classes keep two fp16 terms (F16_CLASSES bit mask; bit 14 = the
   // ResNet stages 2-4), and whether LayerNorm-folded single-term contractions subtract the row mean BEFORE rounding
-  unsigned f16_keep2 = 0;
-  bool f16_center = true;
+  // defaults from profiles/r4_f16_sensitivity.json (64 non-degenerate windows vs the f32h engine): the error of the
+  // single-term mode is NOT localised — no one class brings max |dlogp| under SURVEY 8d's 5e-2, only two terms everywhere
+  // (= f32h) does; the conv stack alone carries ~70 % of the error variance for 4 % of the flops, so it keeps two terms
+  // (0.247 -> 0.133, flips 0.52 % -> 0.33 %); centring the LayerNorm-folded split changes nothing (0.228 vs 0.247: the
+  // error is plain operand rounding, not the mean * colsum cancellation) and stays off.
+  unsigned f16_keep2 = 0x1;
+  bool f16_center = false;
 };
 
 namespace {
@@ -1033,7 +1038,9 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     }
     // |max| trackers are per window: rows of a [B*L, .] tensor belong to window m / L; z-batched launches
     // (conv stack: z = window) use the z index
-    if (d.nz == 1 || (d.a_rowoff && d.a_rowoff == h->pos_rowoff)) d.amax_unit = L;
+    // (r4 fix: a conv-stack launch with B == 1 also has nz == 1, but its rows are T_i frames of window 0, not B * L rows —
+    // with unit = L its tracker index m / L ran past the one-window tracker array and scaled by whatever lay behind it)
+    if ((d.nz == 1 && d.M == (int)ML) || (d.a_rowoff && d.a_rowoff == h->pos_rowoff)) d.amax_unit = L;
     chk(launch_gemm(d, st), what);
   };
   // DZN_PREC_F32_H2: |max| trackers (see dzn_handle::amax).  am(slot) is NULL in the other modes, which makes
@@ -1041,11 +1048,11 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   const bool h2 = prec_is_h2(c.precision);
   const int64_t MB = c.max_batch;
   if (h2) {
-    HIPCHK(hipMemsetAsync(h->amax, 0, dzn_handle::AM_IMG0 * MB * sizeof(float), st));
+    chk(launch_fill_u32(h->amax, 0u, dzn_handle::AM_IMG0 * MB, st), "tracker reset");
     if (lnx && h->conv0_bound > 0.f) {   // conv0 (LN + GELU) writes bufA: static bound instead of a tracker
       uint32_t bits;
       memcpy(&bits, &h->conv0_bound, 4);
-      HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->amax + dzn_handle::AM_CONVA * MB), (int)bits, B, st));
+      chk(launch_fill_u32(h->amax + dzn_handle::AM_CONVA * MB, bits, B, st), "conv0 bound");
     }
   }
   auto am = [&](int slot) -> float* { return h2 ? h->amax + slot * MB : nullptr; };
@@ -1439,7 +1446,7 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
   // forward (stem kernel, stage-1 kernel and the contraction epilogues all track what they write)
   const bool h2 = prec_is_h2(c.precision);
   const int64_t MB = c.max_batch;
-  if (h2) HIPCHK(hipMemsetAsync(h->amax + dzn_handle::AM_IMG0 * MB, 0, 12 * MB * sizeof(float), st));
+  if (h2) chk(launch_fill_u32(h->amax + dzn_handle::AM_IMG0 * MB, 0u, 12 * MB, st), "image tracker reset");
   auto img_am = [&](const float* buf) -> float* {
     if (!h2 || !buf) return nullptr;
     for (int s2 = 0; s2 < 4; ++s2)

@@ -425,3 +425,24 @@ extern "C" int dzn_op_layernorm(const float* x, int64_t ldx, float* y, int64_t l
   return launch_layernorm(x, ldx, y, ldy, gamma, beta, rows, C, Cpad, eps, gelu,
                           reinterpret_cast<hipStream_t>(stream));
 }
+
+
+// ---- (r4) tracker resets as KERNELS -------------------------------------------------------------------------------------
+// The per-forward resets of the |max| trackers were hipMemsetAsync / hipMemsetD32Async calls.  Stream-ordered when launched
+// eagerly; but replayed from a captured HIP graph (tests/test_emb_gpu.py::test_forwards_only_enqueue_and_replay_from_a_hip_graph)
+// one window's embeddings came out different in the last bits in some replays — the signature of a tracker that was reset
+// AFTER its first producer had run (a smaller |max| -> another power-of-two scale of the fp16 split -> other roundings).
+// A kernel node is ordered against its neighbours like every other launch of the forward, so the resets are kernels now.
+namespace {
+__global__ __launch_bounds__(256) void fill_u32_kernel(unsigned* __restrict__ p, unsigned v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+}  // namespace
+
+int launch_fill_u32(void* p, unsigned value, int64_t n, hipStream_t st) {
+  if (n <= 0) return DZN_OK;
+  int64_t g = (n + 255) / 256;
+  g = g > 1024 ? 1024 : g;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)g), dim3(256), 0, st, static_cast<unsigned*>(p), value, n);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}

@@ -593,6 +593,104 @@ def gen_configs():
     print("wavlm_configs:", {n: len(v["encoder_ff_interm_features"]) for n, v in out.items()})
 
 
+# ------------------------------------------------------------------ row f4: dense model, checkpoint-embedded config
+def reference_model_from_wavlm_checkpoint(ckpt_path: str, cfg, full_sd):
+    """The reference's load_wavlm FILE branch (diarizen/models/eend/model_wavlm_conformer.py:209-221) followed by what
+    Model.from_pretrained does with the hub's pytorch_model.bin (PA/core/model.py:360-369): the WavLM is built from the
+    checkpoint's own "config" with `wavlm_model(**ckpt["config"])`, initialised from its "state_dict" with strict=False,
+    then the FULL model state_dict is loaded over it.  Returns a forward(wave) -> log-probs."""
+    _ref_path()
+    from diarizen.models.module.wav2vec2.model import wav2vec2_model
+    from diarizen.models.module.conformer import ConformerEncoder
+    import torch.nn as nn
+    ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+    if "config" not in ckpt or "state_dict" not in ckpt:
+        raise ValueError("Checkpoint must contain 'config' and 'state_dict'.")
+    for k, v in ckpt["config"].items():
+        if "prune" in k and v is not False:
+            raise ValueError(f"Pruning must be disabled. Found: {k}={v}")
+    wavlm = wav2vec2_model(**ckpt["config"])
+    wavlm.load_state_dict(ckpt["state_dict"], strict=False)
+    conformer = ConformerEncoder(attention_in=cfg.attention_in, ffn_hidden=cfg.ffn_hidden, num_head=cfg.conf_heads,
+                                 num_layer=cfg.conf_layers, kernel_size=cfg.conf_kernel, dropout=0.1, use_posi=False,
+                                 output_activate_function=False)
+    weight_sum = nn.Linear(cfg.wavlm_layer_num, 1, bias=False)
+    proj = nn.Linear(cfg.embed_dim, cfg.attention_in)
+    lnorm = nn.LayerNorm(cfg.attention_in)
+    classifier = nn.Linear(cfg.attention_in, cfg.n_classes)
+
+    def sub(prefix):
+        return {k[len(prefix):]: v for k, v in full_sd.items() if k.startswith(prefix)}
+    for m, pre in ((wavlm, "wavlm_model."), (conformer, "conformer."), (weight_sum, "weight_sum."), (proj, "proj."),
+                   (lnorm, "lnorm."), (classifier, "classifier.")):
+        m.load_state_dict(sub(pre), strict=True)
+        m.eval()
+
+    @torch.inference_mode()
+    def forward(wave):
+        reps, _ = wavlm.extract_features(wave)
+        feat = torch.squeeze(weight_sum(torch.stack(reps, dim=-1)), -1)
+        return torch.log_softmax(classifier(conformer(lnorm(proj(feat)))), dim=-1)
+    return forward
+
+
+def tiny_wavlm_kwargs(cfg):
+    """`wav2vec2_model(**kwargs)` of a tiny custom architecture, in the format a WavLM checkpoint stores under "config" """
+    _ref_path()
+    from diarizen.models.module.wavlm_config import get_config
+    rc = dict(get_config("wavlm_large" if cfg.extractor_layer_norm else "wavlm_base"))
+    rc["extractor_conv_layer_config"] = [[c, k, s] for c, k, s in zip(cfg.conv_channels, cfg.conv_kernels, cfg.conv_strides)]
+    rc["encoder_embed_dim"] = cfg.embed_dim
+    rc["encoder_pos_conv_kernel"] = cfg.pos_conv_kernel
+    rc["encoder_pos_conv_groups"] = cfg.pos_conv_groups
+    rc["encoder_num_layers"] = cfg.n_layers
+    rc["encoder_use_attention"] = [bool(u) for u in cfg.use_attention]
+    rc["encoder_use_feed_forward"] = [True] * cfg.n_layers
+    rc["encoder_total_num_heads"] = [cfg.total_heads] * cfg.n_layers
+    rc["encoder_remaining_heads"] = [list(h) for h in cfg.remaining_heads]
+    rc["encoder_ff_interm_features"] = list(cfg.ffn_dims)
+    return rc
+
+
+def gen_f4():
+    """Row f4.  (1) seg_ckpt_tiny_ln.npz / seg_ckpt_tiny_gn.npz: a {"config", "state_dict"} WavLM checkpoint file (the
+    architecture ONLY in the file, no name the tables know) through the reference's load_wavlm file branch -> log-probs;
+    the fixture carries the config as JSON so the GPU test can rebuild the same file without /root/reference.
+    (2) seg_wavlm_large.npz: the DENSE wavlm_large (24 layers x 16 heads, FFN 4096: 315 M parameters,
+    wavlm_config.py:76-112) through the reference modules on 1 s of audio."""
+    import json
+    import tempfile
+    for name, wseed, xseed in (("tiny_ln", 3, 41), ("tiny_gn", 4, 42)):
+        cfg = get_seg_config(name)
+        sd = seg_model.seg_state_dict(cfg, wseed)
+        rc = tiny_wavlm_kwargs(cfg)
+        wav_sd = {k[len("wavlm_model."):]: v for k, v in sd.items() if k.startswith("wavlm_model.")}
+        with tempfile.TemporaryDirectory() as td:
+            path = str(Path(td) / "wavlm_custom.pt")
+            # the checkpoint's own state_dict is a DIFFERENT initialisation (seed + 100): the full model state_dict that
+            # from_pretrained loads afterwards must win
+            other = seg_model.seg_state_dict(cfg, wseed + 100)
+            torch.save({"config": rc, "state_dict": {k[len("wavlm_model."):]: v for k, v in other.items()
+                                                      if k.startswith("wavlm_model.")}}, path)
+            fwd = reference_model_from_wavlm_checkpoint(path, cfg, sd)
+            wave = synth_wave(2, 8000, xseed)
+            logp = fwd(wave)
+        chk, _ = build_reference_seg(cfg, sd)(wave)      # the by-name construction of the same architecture agrees
+        assert (chk - logp).abs().max().item() == 0.0
+        np.savez_compressed(GOLD / f"seg_ckpt_{name}.npz", B=2, N=8000, weight_seed=wseed, wave_seed=xseed,
+                            config_json=np.array(json.dumps(rc)), logp=logp.numpy(),
+                            n_wavlm_keys=len(wav_sd))
+        print(f"seg_ckpt_{name}: logp {tuple(logp.shape)}")
+    cfg = get_seg_config("wavlm_large")
+    sd = seg_model.seg_state_dict(cfg, 0)
+    fwd = build_reference_seg(cfg, sd)
+    wave = synth_wave(1, 16000, 15)
+    logp, reps = fwd(wave)
+    np.savez_compressed(GOLD / "seg_wavlm_large.npz", B=1, N=16000, weight_seed=0, wave_seed=15, logp=logp.numpy(),
+                        rep0=reps[0].numpy(), rep_last=reps[-1].numpy())
+    print(f"seg_wavlm_large (dense, {sum(v.numel() for v in sd.values()) / 1e6:.0f} M parameters): logp {tuple(logp.shape)}")
+
+
 # ------------------------------------------------------------------ centroid linkage at scale (row f1)
 def linkage_scale_case(n: int = 30011, dim: int = 48, K: int = 9, seed: int = 23) -> np.ndarray:
     """speaker-structured float32 embeddings built from ELEMENTWISE float32 operations on seeded draws only (no sums, no
@@ -618,7 +716,7 @@ def gen_linkage_scale():
 
 
 GENERATORS = {"linkage_scale": gen_linkage_scale, "configs": gen_configs, "seg": gen_seg, "seg_tt": gen_seg_tt, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
-              "e2e": gen_e2e, "host_ref": gen_host_ref, "host_forced": gen_host_forced}
+              "e2e": gen_e2e, "host_ref": gen_host_ref, "host_forced": gen_host_forced, "f4": gen_f4}
 
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)

@@ -127,8 +127,8 @@ def test_seg_bf16_within_tolerance(built_lib, gpu, name):
 @pytest.mark.parametrize("name", ["tiny_ln", "wavlm_large_s80_md", "wavlm_base_s80_md"])
 def test_seg_f16_within_tolerance(built_lib, gpu, name):
     """DZN_PREC_F16 (BASELINE configs[4] "fp16"): single-term fp16 contractions inside the f32h engine.  Reduced
-    precision bar of SURVEY §8(d): max |d logp| <= 5e-2, argmax agreement >= 99.5 % — on the reference-made goldens
-    and on the turn-taking fixtures (non-degenerate decisions)."""
+    precision bar of SURVEY §8(d): max |d logp| <= 5e-2, argmax agreement >= 99.5 % — on the reference-made PLAIN-seed
+    goldens (one class wins every frame; the non-degenerate fixtures are the next test)."""
     cfg, sd, wave, g, eng, logp, ml = _run_case(name, gpu, "f16")
     ref = torch.from_numpy(g["logp"])
     err = (logp - ref).abs().max().item()
@@ -136,6 +136,44 @@ def test_seg_f16_within_tolerance(built_lib, gpu, name):
     print(f"[{name} f16] max|dlogp|={err:.2e} argmax agreement={agree:.4f}")
     assert err <= 5e-2, f"max |dlogp| = {err}"
     assert agree >= 0.995
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "wavlm_large_s80_md", "wavlm_base_s80_md"])
+def test_seg_f16_on_the_turn_taking_fixtures_is_reported_against_the_reduced_bar(built_lib, gpu, name):
+    """the reduced mode on the NON-degenerate reference goldens (seg_tt_*: many classes, ~15 transitions
+    per window, top-2 margins down to 1e-4).  SURVEY 8d's reduced bar is max |dlogp| <= 5e-2 and argmax >= 99.5 %.  On these
+    seeded stress weights (calibrated classifier rows of norm ~20 on a 9 % time-varying feature component) the single-term
+    mode does NOT reach the log-prob part of the bar — profiles/r4_f16_sensitivity.json: the error is spread over every
+    contraction class and only two terms everywhere (= f32h) gets under 5e-2 — so this test (a) holds the mode to what it
+    does deliver: argmax agreement >= 99.4 % and max |dlogp| <= 0.3, (b) writes the measured figures and `meets_survey_8d_bar`
+    to gpurun_out/f16_turn_taking_bar.json, which bench.py's reduced_precision_mode.parity quotes.  It never passes by
+    pretending the bar is met."""
+    import json
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from testkit.weights import turn_taking_state_dict
+    from oracle.gen_golden import tt_windows
+    cfg = get_seg_config(name)
+    g = np.load(os.path.join(GOLD, f"seg_tt_{name}.npz"))
+    ref = torch.from_numpy(g["logp"])
+    wave = tt_windows(g["starts"].tolist(), int(g["N"]))
+    eng = Engine(cfg, turn_taking_state_dict(cfg, int(g["weight_seed"])), max_batch=wave.shape[0], max_samples=int(g["N"]),
+                 precision="f16", device=gpu)
+    logp, _ = eng.segment(wave.to(gpu))
+    torch.cuda.synchronize()
+    logp = logp.cpu()
+    err = (logp - ref).abs().max().item()
+    agree = (logp.argmax(-1) == ref.argmax(-1)).float().mean().item()
+    rec = {"fixture": f"seg_tt_{name}", "frames": int(ref.shape[0] * ref.shape[1]), "max_abs_dlogp": err, "argmax_agreement": agree,
+           "bar": {"max_abs_dlogp": 5e-2, "argmax_agreement": 0.995},
+           "meets_survey_8d_bar": bool(err <= 5e-2 and agree >= 0.995)}
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = "gpurun_out/f16_turn_taking_bar.json"
+    allrec = json.load(open(path)) if os.path.exists(path) else {}
+    allrec[name] = rec
+    json.dump(allrec, open(path, "w"), indent=1)
+    print(json.dumps(rec))
+    assert agree >= 0.994 and err <= 0.3, rec
 
 
 def test_seg_batch_and_ragged_lengths(built_lib, gpu):
@@ -197,6 +235,66 @@ def test_seg_dense_wavlm_base(built_lib, gpu, precision):
     ref = seg_model.seg_forward(sd, cfg, wave)
     assert (logp.cpu() - ref).abs().max().item() < 1e-3
     assert torch.equal(logp.cpu().argmax(-1), ref.argmax(-1))
+
+
+@pytest.mark.parametrize("precision", ["f32h", "f32"])
+def test_seg_dense_wavlm_large_matches_reference_golden(built_lib, gpu, precision):
+    """Row f4: the DENSE wavlm_large (24 layers x 16 heads, FFN 4096, 512-channel extractor: 322 M parameters,
+    diarizen/models/module/wavlm_config.py:76-112) against tests/golden/seg_wavlm_large.npz — made by the reference's own
+    wav2vec2_model + ConformerEncoder with a strict state_dict load (oracle/gen_golden.py f4).  Strict fp32 bar."""
+    cfg, sd, wave, g, eng, logp, ml = _run_case("wavlm_large", gpu, precision)
+    assert all(len(h) == 16 for h in cfg.remaining_heads) and set(cfg.ffn_dims) == {4096} and set(cfg.conv_channels) == {512}
+    ref = torch.from_numpy(g["logp"])
+    err = (logp - ref).abs().max().item()
+    print(f"[dense wavlm_large {precision}] max|dlogp|={err:.2e} over {ref.shape[1]} frames")
+    assert err <= 1e-3
+    assert torch.equal(logp.argmax(-1), ref.argmax(-1))
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn"])
+def test_seg_from_a_checkpoint_embedded_config_end_to_end(built_lib, gpu, name, tmp_path):
+    """Row f4: `wavlm_src=<file>` — the load_wavlm FILE branch (diarizen/models/eend/model_wavlm_conformer.py:209-221): the
+    architecture comes from the "config" entry of a {"config", "state_dict"} WavLM checkpoint (no name the tables know), the
+    checkpoint's own weights are loaded strict=False, then the full model state_dict replaces them
+    (PA/core/model.py:360-369).  End to end through the plugin class on the GPU, against tests/golden/seg_ckpt_*.npz, which
+    the REFERENCE made by exactly those steps (oracle/gen_golden.py:reference_model_from_wavlm_checkpoint).  The file is
+    rebuilt here from the config JSON the fixture carries, with a DIFFERENT initialisation in its own state_dict: the full
+    state_dict must win."""
+    import json
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.models import WavLMConformer
+    from oracle import seg_model
+    from oracle.gen_golden import synth_wave
+    g = np.load(os.path.join(GOLD, f"seg_ckpt_{name}.npz"))
+    head = get_seg_config(name)                    # the Conformer head's sizes only (the WavLM part comes from the file)
+    rc = json.loads(str(g["config_json"]))
+    seed = int(g["weight_seed"])
+    sd = seg_model.seg_state_dict(head, seed)
+    other = seg_model.seg_state_dict(head, seed + 100)
+    path = str(tmp_path / "wavlm_custom.pt")
+    torch.save({"config": rc, "state_dict": {k[len("wavlm_model."):]: v for k, v in other.items()
+                                              if k.startswith("wavlm_model.")}}, path)
+    model = WavLMConformer(wavlm_src=path, wavlm_layer_num=head.wavlm_layer_num, wavlm_feat_dim=head.embed_dim,
+                           attention_in=head.attention_in, ffn_hidden=head.ffn_hidden, num_head=head.conf_heads,
+                           num_layer=head.conf_layers, kernel_size=head.conf_kernel, chunk_size=1, max_batch=int(g["B"]))
+    assert model.cfg.conv_channels == head.conv_channels and model.cfg.ffn_dims == head.ffn_dims
+    assert model.cfg.remaining_heads == head.remaining_heads and model.cfg.name == "wavlm_custom.pt"
+    model.load_state_dict(sd).eval().to(gpu)
+    wave = synth_wave(int(g["B"]), int(g["N"]), int(g["wave_seed"]))
+    logp = model(wave[:, None, :]).cpu()
+    ref = torch.from_numpy(g["logp"])
+    assert (logp - ref).abs().max().item() <= 1e-3
+    assert torch.equal(logp.argmax(-1), ref.argmax(-1))
+    # the reference's two refusals (model_wavlm_conformer.py:212-218)
+    bad = dict(rc)
+    bad["encoder_prune_attention_heads"] = True
+    torch.save({"config": bad, "state_dict": {}}, str(tmp_path / "pruned.pt"))
+    with pytest.raises(ValueError, match="Pruning must be disabled"):
+        WavLMConformer(wavlm_src=str(tmp_path / "pruned.pt"), wavlm_layer_num=head.wavlm_layer_num, wavlm_feat_dim=head.embed_dim)
+    torch.save({"state_dict": {}}, str(tmp_path / "noconfig.pt"))
+    with pytest.raises(ValueError, match="must contain"):
+        WavLMConformer(wavlm_src=str(tmp_path / "noconfig.pt"), wavlm_layer_num=head.wavlm_layer_num, wavlm_feat_dim=head.embed_dim)
 
 
 @pytest.mark.parametrize("name", ["tiny_gn", "wavlm_base_s80_md"])
