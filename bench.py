@@ -272,7 +272,7 @@ def e2e_leg(args, dev, wave_host, sd, esd):
 def config1_leg(args, dev):
     """BASELINE configs[1]: wavlm-base-s80, segmentation only, 5 s windows, ONE batch of 32 at a time (the reference's own
     configuration for that line), driver-timed beside the headline.  A pass = the 3591 windows of a 30-min recording
-    in 113 launches of <= 32; `streams` > 1 (default 2) runs consecutive batches on separate engine handles / HIP streams,
+    in 113 launches of <= 32; `streams` > 1 (default 3: 3205 / 4192 / 4623 / 4167 audio-s/s at 1 / 2 / 3 / 4, gpurun r4f) runs consecutive batches on separate engine handles / HIP streams,
     because a 32-window launch (7968 rows) under-fills 256 CUs and its 113 kernels are launch-granularity bound."""
     from diarizen_amd.configs import RESNET34, get_seg_config
     from diarizen_amd.engine import Engine
@@ -464,6 +464,10 @@ def main():
     ap.add_argument("--window", type=float, default=8.0)
     ap.add_argument("--batch", type=int, default=384,
                     help="maximum windows per launch (the runner balances: 2241 windows -> 6 launches of 374)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="engine handles / HIP streams that consecutive batches of a step alternate over (WindowRunner "
+                         "extra_engines); the in-situ per-kernel profiler needs 1 (kernel durations are not separable when "
+                         "two streams share the device)")
     ap.add_argument("--model", default="wavlm_large_s80_md")
     ap.add_argument("--stage", default="full", choices=["full", "seg"],
                     help="seg = segmentation-only (BASELINE configs[1]: --model wavlm_base_s80_md --window 5 "
@@ -481,7 +485,7 @@ def main():
     ap.add_argument("--only-config1", action="store_true", help="run just the BASELINE configs[1] leg and print its object")
     ap.add_argument("--config1-steps", type=int, default=2)
     ap.add_argument("--config1-minutes", type=float, default=30.0)
-    ap.add_argument("--config1-streams", type=int, default=2,
+    ap.add_argument("--config1-streams", type=int, default=3,
                     help="engine handles / HIP streams that consecutive 32-window batches of the configs[1] leg alternate over")
     ap.add_argument("--weights", default="turn_taking", choices=["turn_taking", "plain"],
                     help="turn_taking (default): seeded weights whose decisions look like turn taking (both mask branches of "
@@ -552,7 +556,11 @@ def main():
     window = int(args.window * sr)
     eng = Engine(cfg, sd, RESNET34, esd, max_batch=args.batch, max_samples=window,
                  precision=args.precision, device=dev)
-    runner = WindowRunner(eng, args.window, 0.1, args.batch)
+    extra = tuple(Engine(cfg, sd, RESNET34, esd, max_batch=args.batch, max_samples=window, precision=args.precision, device=dev)
+                  for _ in range(max(0, args.streams - 1)))
+    runner = WindowRunner(eng, args.window, 0.1, args.batch, extra_engines=extra)
+    if args.streams > 1:
+        args.no_profile = True
     num_samples = int(args.minutes * 60 * sr)
     audio_s = num_samples / sr
     strong = args.scaling == "strong" and world > 1

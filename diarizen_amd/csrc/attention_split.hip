@@ -26,12 +26,8 @@ constexpr int ATT_OCC = 3;           // wavefronts per SIMD the register budget 
 //   the scores come out of the MFMA times s^2 and are multiplied back (exactly) before bias / softmax;
 //   the probabilities are produced as p' = 2^14 p (one exp2 with +14 in the exponent, p' <= 2^14 fits fp16) and the
 //   final normalisation divides by s * sum p', so neither scale costs an instruction in the inner loops.
-// QW (r4) = wavefronts per workgroup = 16-query blocks that share one staged K / V tile: 4 (64 queries, r1-r3), 8 or 16.
-// Every thread of the workgroup takes part in the staging (fetch + split + LDS store of the 64-key tile), so the split
-// of a K / V element — the VALU work the tile costs besides its MFMAs — is done by 1 / (QW / 4) as many instructions per
-// query, and the tile is fetched from L2 / HBM that many times less often (r3 PMC: 2.79 GB per launch for 0.70 GB).
-template <bool BIAS, int NP, int QW>
-__global__ __launch_bounds__(64 * QW, (QW == 4 ? ATT_OCC : QW == 8 ? 4 : 4)) void attn_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+template <bool BIAS, int NP>
+__global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                          const float* __restrict__ gate,
                                                          const float* __restrict__ table,
                                                          const int32_t* __restrict__ head_idx, int B, int L,
@@ -42,9 +38,7 @@ __global__ __launch_bounds__(64 * QW, (QW == 4 ? ATT_OCC : QW == 8 ? 4 : 4)) voi
   unsigned char* sV = smem + NP * ATT_PLANE;    // NP planes [64 d][64 keys in MFMA order]
   float* sT = reinterpret_cast<float*>(smem + 2 * NP * ATT_PLANE);  // [2L-1] bias table of this head
 
-  constexpr int NT = 64 * QW;                    // threads per workgroup
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int qt = blockIdx.x, j = blockIdx.y, b = blockIdx.z;
   const int64_t rowbase = (int64_t)b * L;
@@ -55,7 +49,7 @@ __global__ __launch_bounds__(64 * QW, (QW == 4 ? ATT_OCC : QW == 8 ? 4 : 4)) voi
   int H = 0;
   if constexpr (BIAS) {
     H = head_idx[j];
-    for (int i = tid; i < 2 * L - 1; i += NT) sT[i] = table[(int64_t)H * (2 * L - 1) + i];
+    for (int i = tid; i < 2 * L - 1; i += 256) sT[i] = table[(int64_t)H * (2 * L - 1) + i];
   }
 
   // scores are kept in the log2 domain (q and the bias gate carry a factor log2 e), so the softmax
@@ -67,7 +61,7 @@ __global__ __launch_bounds__(64 * QW, (QW == 4 ? ATT_OCC : QW == 8 ? 4 : 4)) voi
   const float s_inv = op_inv * op_inv;          // scores leave the MFMA scaled by op_scale^2
   constexpr float PSHIFT = NP == 2 ? 14.0f : 0.0f;   // p' = 2^PSHIFT p
   // ---- Q fragments (B operand of S^T = K Q^T): lane (query lr, group lq) holds d = 32 half + 8 lq .. +7 ----
-  const int q_row = qt * (16 * QW) + wave * 16 + lr;
+  const int q_row = qt * 64 + wave * 16 + lr;
   const bool q_ok = q_row < L;
   u32x4 qf[2][NP];
 #pragma unroll
@@ -93,69 +87,68 @@ __global__ __launch_bounds__(64 * QW, (QW == 4 ? ATT_OCC : QW == 8 ? 4 : 4)) voi
   for (int i = 0; i < 4; ++i) O[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- staging assignment ----
-  // A 64-key tile is 512 K items (key = item / 8, 8-d chunk = item % 8: 32 contiguous bytes) and 512 V items
-  // (d = item % 64, group = item / 64: the 8 keys (2 mm + e/4) * 16 + 4 lq' + e%4 that lane group lq' = group % 4 feeds to
-  // P.V MFMA mm = group / 4).  NT <= 512 threads: thread t takes K items and V items t + NT i, i < 512 / NT;
-  // NT = 1024: wavefronts 0-7 stage K (item = t), wavefronts 8-15 stage V (item = t - 512) — wave-uniform roles.
+  // K: item = tid + 256 i -> (key = tid / 8 + 32 i, 8-d chunk = tid % 8): 32 contiguous bytes per thread
+  // V: item = tid + 256 i -> (d = tid % 64, group = wave + 4 i, i.e. MFMA mm = i, lane group lq' = wave):
+  //    the 8 keys (2 mm + e/4) * 16 + 4 lq' + e%4 that lane group lq' feeds to P.V MFMA mm.
   // Rows past L are clamped to row L-1: their scores are masked to -inf (p = 0), so any finite data do.
   const int nkt = (L + 63) / 64;
-  constexpr int SN = NT < 512 ? NT : 512;        // staging threads per operand
-  constexpr int KI = 512 / SN;                   // items per staging thread and operand
-  const bool doK = NT <= 512 || wave < 8, doV = NT <= 512 || wave >= 8;    // wave-uniform
-  const int st = tid & (SN - 1);
-  f32x4 rk[KI][2], rv[KI][2];
+  const int koff = (tid >> 3) * ldqkv + (tid & 7) * 8;   // + (64 kt + 32 i) ldqkv
+  const int voff = wave * 4 * ldqkv + (tid & 63);        // + (64 kt + const(i, e)) ldqkv
+  f32x4 rk[2][2], rv[2][2];
   auto fetch = [&](int kt) {
     const int64_t trow = rowbase + kt * 64;               // wave-uniform
     const bool full = kt * 64 + 64 <= L;
     const float* kt_base = Kp + trow * ldqkv;
     const float* vt_base = Vp + trow * ldqkv;
 #pragma unroll
-    for (int i = 0; i < KI; ++i) {
-      const int item = st + SN * i;
-      if (doK) {
-        int key = item >> 3;
-        if (!full && kt * 64 + key >= L) key = L - 1 - kt * 64;
-        const float* src = kt_base + (int64_t)key * ldqkv + (item & 7) * 8;
-        const float4 a = *reinterpret_cast<const float4*>(src);
-        const float4 c = *reinterpret_cast<const float4*>(src + 4);
-        rk[i][0] = (f32x4){a.x, a.y, a.z, a.w};
-        rk[i][1] = (f32x4){c.x, c.y, c.z, c.w};
+    for (int i = 0; i < 2; ++i) {
+      int ko = koff + 32 * i * ldqkv;
+      if (!full) {
+        const int key = (tid >> 3) + 32 * i;
+        if (kt * 64 + key >= L) ko += (L - 1 - kt * 64 - key) * ldqkv;
       }
-      if (doV) {
-        const int grp = item >> 6;                          // wave-uniform (64 consecutive items per wavefront)
-        const int key0 = (grp >> 2) * 32 + (grp & 3) * 4;
-        const float* src = vt_base + (item & 63);
+      const float4 a = *reinterpret_cast<const float4*>(kt_base + ko);
+      const float4 c = *reinterpret_cast<const float4*>(kt_base + ko + 4);
+      rk[i][0] = (f32x4){a.x, a.y, a.z, a.w};
+      rk[i][1] = (f32x4){c.x, c.y, c.z, c.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          int key = key0 + (e >> 2) * 16 + (e & 3);
-          if (!full && kt * 64 + key >= L) key = L - 1 - kt * 64;
-          const float x = src[(int64_t)key * ldqkv];
-          if (e < 4) rv[i][0][e] = x;
-          else rv[i][1][e - 4] = x;
+      for (int e = 0; e < 8; ++e) {
+        const int ce = (2 * i + (e >> 2)) * 16 + (e & 3);   // compile-time part of the key index
+        int vo = voff + ce * ldqkv;
+        if (!full) {
+          const int key = ce + wave * 4;
+          if (kt * 64 + key >= L) vo += (L - 1 - kt * 64 - key) * ldqkv;
         }
+        const float x = vt_base[vo];
+        if (e < 4) rv[i][0][e] = x;
+        else rv[i][1][e - 4] = x;
       }
     }
   };
-  // a wavefront whose 16 queries all lie past L only stages (wave-uniform; its MFMAs and softmax are skipped)
-  const bool wave_live = qt * (16 * QW) + wave * 16 < L;
 
-  // no register prefetch across the tile: the resident workgroups of a CU hide the global-load latency
-  // better than 32 more live registers do — measured 91 -> 102 TFLOP/s (r1)
+  // no register prefetch across the tile: 3 resident workgroups per CU hide the global-load latency
+  // better than 32 more live registers (2 workgroups) do — measured 91 -> 102 TFLOP/s
+  // (r4) The K / V tile is staged — fetched, split, stored — once per 64 queries, i.e. 7 times per
+  // (window, head), and the r3 PMC pass counts 2.79 GB per launch for 0.70 GB algorithmic.  Sharing a staged tile between
+  // 128 or 256 queries (8 / 16 wavefronts per workgroup, every thread staging half / a quarter as much) was built and
+  // measured: 132 / 134 TFLOP/s against 138 for this form in the same run (profiles/r4_attention_qw_probe.txt; the
+  // templated kernel is in the history at 2ee-series commit "attention: query blocks per workgroup templated"), step
+  // unchanged.  The re-reads are L2 / MALL hits and the split is not what the loop waits for; the kernel stays as it was.
   for (int kt = 0; kt < nkt; ++kt) {
     fetch(kt);
     __syncthreads();  // previous tile fully consumed
 #pragma unroll
-    for (int i = 0; i < KI; ++i) {
-      const int item = st + SN * i;
+    for (int i = 0; i < 2; ++i) {
+      const int item = tid + 256 * i;
       u32x4 pf[NP];
-      if (doK) {
+      {
         const int key = item >> 3, slot = item & 7;
         const int off = key * 128 + ((slot ^ ((key >> 1) & 7)) << 4);
         split_np(rk[i][0], rk[i][1], op_scale, pf);
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(sK + p * ATT_PLANE + off) = pf[p];
       }
-      if (doV) {
+      {
         const int d = item & 63, grp = item >> 6;
         const int off = d * 128 + ((grp ^ ((d >> 1) & 7)) << 4);
         split_np(rv[i][0], rv[i][1], op_scale, pf);
@@ -164,7 +157,6 @@ __global__ __launch_bounds__(64 * QW, (QW == 4 ? ATT_OCC : QW == 8 ? 4 : 4)) voi
       }
     }
     __syncthreads();
-    if (!wave_live) continue;
 
     // ---- S^T = K Q^T : 4 key blocks x 2 halves of d, six products each ----
     f32x4 s[4];
@@ -270,7 +262,7 @@ __global__ __launch_bounds__(64 * QW, (QW == 4 ? ATT_OCC : QW == 8 ? 4 : 4)) voi
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
     const float lt = __shfl(l_tot, lq * 4 + rg, 64);
-    const int q = qt * (16 * QW) + wave * 16 + lq * 4 + rg;
+    const int q = qt * 64 + wave * 16 + lq * 4 + rg;
     if (q < L) {
       const float inv = op_inv / lt;      // NP = 2: lt = 2^14 sum p and O carries 2^14 op_scale
       float* op = out + (rowbase + q) * ldo + j * 64 + lr;
@@ -293,36 +285,21 @@ int launch_attention_split(const float* qkv, float* out, const float* gate, cons
   if (lds > 160 * 1024) return DZN_E_INVALID;
   static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
   if (first_use_on_device(attr_mask)) {
-    const void* ks[12] = {
-        reinterpret_cast<const void*>(attn_split_kernel<true, 3, 4>), reinterpret_cast<const void*>(attn_split_kernel<false, 3, 4>),
-        reinterpret_cast<const void*>(attn_split_kernel<true, 2, 4>), reinterpret_cast<const void*>(attn_split_kernel<false, 2, 4>),
-        reinterpret_cast<const void*>(attn_split_kernel<true, 3, 8>), reinterpret_cast<const void*>(attn_split_kernel<false, 3, 8>),
-        reinterpret_cast<const void*>(attn_split_kernel<true, 2, 8>), reinterpret_cast<const void*>(attn_split_kernel<false, 2, 8>),
-        reinterpret_cast<const void*>(attn_split_kernel<true, 3, 16>), reinterpret_cast<const void*>(attn_split_kernel<false, 3, 16>),
-        reinterpret_cast<const void*>(attn_split_kernel<true, 2, 16>), reinterpret_cast<const void*>(attn_split_kernel<false, 2, 16>)};
+    const void* ks[4] = {reinterpret_cast<const void*>(attn_split_kernel<true, 3>), reinterpret_cast<const void*>(attn_split_kernel<false, 3>),
+                         reinterpret_cast<const void*>(attn_split_kernel<true, 2>), reinterpret_cast<const void*>(attn_split_kernel<false, 2>)};
     for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  // query blocks per workgroup (DZN_ATT_QW = 4 / 8 / 16 overrides; read once).  r4 default: 8 wavefronts = 128 queries
-  static const int qw_env = getenv("DZN_ATT_QW") ? atoi(getenv("DZN_ATT_QW")) : 0;
-  const int qw = (qw_env == 4 || qw_env == 8 || qw_env == 16) ? qw_env : 8;
-  dim3 grid((L + 16 * qw - 1) / (16 * qw), h, B);
+  dim3 grid((L + 63) / 64, h, B);
   const int pid = prof_begin(s, bias ? (amax ? "attention_relpos_f32h" : "attention_relpos_f32s") : (amax ? "attention_f32h" : "attention_f32s"),
                              4.0 * B * h * (double)L * L * 64.0,
                              (double)B * L * h * 64.0 * 4.0 * 4.0 + (gate ? (double)B * L * Htot * 4.0 : 0.0));   // q, k, v in + out, once
-#define DZN_ATT(BV, NPV, QWV)                                                                                             \
-  hipLaunchKernelGGL((attn_split_kernel<BV, NPV, QWV>), grid, dim3(64 * QWV), lds, s, qkv, out, gate, table, head_idx, B, \
-                     L, h, Htot, ldqkv, ldo, scale, amax)
-#define DZN_ATT_Q(BV, NPV)                \
-  do {                                    \
-    if (qw == 4) DZN_ATT(BV, NPV, 4);     \
-    else if (qw == 8) DZN_ATT(BV, NPV, 8); \
-    else DZN_ATT(BV, NPV, 16);            \
-  } while (0)
-  if (bias && amax) DZN_ATT_Q(true, 2);
-  else if (bias) DZN_ATT_Q(true, 3);
-  else if (amax) DZN_ATT_Q(false, 2);
-  else DZN_ATT_Q(false, 3);
-#undef DZN_ATT_Q
+#define DZN_ATT(BV, NPV)                                                                                            \
+  hipLaunchKernelGGL((attn_split_kernel<BV, NPV>), grid, dim3(256), lds, s, qkv, out, gate, table, head_idx, B, L, h, \
+                     Htot, ldqkv, ldo, scale, amax)
+  if (bias && amax) DZN_ATT(true, 2);
+  else if (bias) DZN_ATT(true, 3);
+  else if (amax) DZN_ATT(false, 2);
+  else DZN_ATT(false, 3);
 #undef DZN_ATT
   prof_end(pid, s);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;

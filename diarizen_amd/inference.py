@@ -21,6 +21,8 @@ from typing import Optional, Tuple
 
 import torch
 
+from contextlib import nullcontext as _nullcontext
+
 from .engine import Engine
 
 
@@ -46,8 +48,16 @@ class SlideResult:
 
 class WindowRunner:
     def __init__(self, engine: Engine, duration: float, step_ratio: float = 0.1, batch_size: int = 32,
-                 median_size: int = 11, exclude_overlap: bool = True, sample_rate: int = 16000):
+                 median_size: int = 11, exclude_overlap: bool = True, sample_rate: int = 16000,
+                 extra_engines: Tuple[Engine, ...] = ()):
+        """extra_engines (r4): further handles with the SAME weights (one workspace each).  Consecutive batches then
+        alternate over [engine, *extra_engines], each on its own HIP stream, so that independent batches overlap on the
+        device — a batch's HBM-bound kernels run beside another batch's matrix-bound ones, launch tails fill, and at small
+        batches (BASELINE configs[1]: 32 windows) the under-filled chip takes two launches at once.  Results are the same
+        bits: a window's result does not depend on the batch or the handle it runs in."""
         self.engine = engine
+        self.engines = (engine,) + tuple(extra_engines)
+        self._streams = None
         self.sample_rate = sample_rate
         self.duration = duration
         self.window = int(math.floor(duration * sample_rate))               # inference.py:265
@@ -104,17 +114,30 @@ class WindowRunner:
         bs = max(1, -(-C // nb))
         if hook is not None:
             hook(completed=0, total=C)
-        for s0 in range(c0, c1, bs):
+        multi = len(self.engines) > 1 and hook is None and nb > 1
+        cur = torch.cuda.current_stream(wave.device)
+        if multi:
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=wave.device) for _ in self.engines]
+            for st in self._streams:
+                st.wait_stream(cur)                 # inputs / output buffers were produced on the caller's stream
+        for bi, s0 in enumerate(range(c0, c1, bs)):
             s1 = min(s0 + bs, c1)
-            chunk = views[s0:s1].contiguous()
-            _, ml = eng.segment(chunk, want_logp=False)
-            filt, masks = eng.prepare_masks(ml, self.median_size, self.exclude_overlap,
-                                            self.min_num_frames if self.exclude_overlap else -1,
-                                            want_masks=with_embeddings)
-            seg[s0 - c0:s1 - c0] = filt
-            if with_embeddings:
-                emb[s0 - c0:s1 - c0] = eng.embed(chunk, masks)
+            k = bi % len(self.engines) if multi else 0
+            e = self.engines[k]
+            with torch.cuda.stream(self._streams[k]) if multi else _nullcontext():
+                chunk = views[s0:s1].contiguous()
+                _, ml = e.segment(chunk, want_logp=False)
+                filt, masks = e.prepare_masks(ml, self.median_size, self.exclude_overlap,
+                                              self.min_num_frames if self.exclude_overlap else -1,
+                                              want_masks=with_embeddings)
+                seg[s0 - c0:s1 - c0] = filt
+                if with_embeddings:
+                    emb[s0 - c0:s1 - c0] = e.embed(chunk, masks)
             if hook is not None:
                 torch.cuda.current_stream(wave.device).synchronize()
                 hook(completed=s1 - c0, total=C)
+        if multi:
+            for st in self._streams:
+                cur.wait_stream(st)                 # the caller's stream sees every batch's results
         return SlideResult(seg, emb, self.window, self.step, self.num_frames)

@@ -1,0 +1,52 @@
+# Round-4 measurement set (MI355X, 1 GPU).  Outputs under gpurun_out/final_r4/, copied to profiles/r4_* afterwards.
+# PART=a : the PMC passes of the headline command (FETCH_SIZE, WRITE_SIZE, MfmaUtil, clock / MFMA-busy), the headline
+#          line (+ other modes, e2e, cpu baseline), rocprofv3 kernel stats of the same command, the driver's command
+# PART=b : BASELINE configs[1] (base-s80 5 s x 32, segmentation only), configs[3] 4 h on one GPU (pipeline timing + the
+#          bench's strong-scaling e2e leg at world size 1), decision parity on 256 windows
+set -x
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/final_r4
+mkdir -p $O
+cd $R
+if [ "${PART:-a}" = "a" ]; then
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE MfmaUtil "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
+T=$(echo $C | cut -d' ' -f1)
+timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$T -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-e2e --no-config1 --no-profile > /dev/null 2> $O/pmc_$T.err
+done
+cd $R
+cc() { find $O/pmc_$1 -name '*counter_collection.csv' | head -1; }
+python scripts/pmc_summary.py $O/pmc_f32h_30min_b384.json $(cc FETCH_SIZE) $(cc WRITE_SIZE) $(cc MfmaUtil) $(cc GRBM_GUI_ACTIVE)
+cp $O/pmc_f32h_30min_b384.json $R/profiles/r4_pmc_f32h_30min_b384.json
+timeout 900 python bench.py > $O/bench_f32h.json 2> $O/bench.err
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-e2e --no-config1 > $O/bench_under_rocprof.json 2> $O/kt.err
+cd $R
+cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*counter_collection.csv' -delete; find $O -name '*agent_info.csv' -delete
+( time timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver_style.json 2> $O/bench_driver_style.err
+DZN_PROFILE_SHAPES=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-e2e --no-config1 > $O/bench_shapes.json 2> $O/bench_shapes.err
+python - <<PY
+import json
+d=json.loads(open("$O/bench_shapes.json").read().strip().splitlines()[-1])
+tot=sum(k["ms_total"] for k in d["kernels"])
+with open("$O/kernel_shapes.txt","w") as f:
+    f.write(f"{d['value']} {d['ms_per_step']}\n")
+    for k in d["kernels"]:
+        f.write(f"{k['kernel']:64s} launches={k['launches']:4d} ms={k['ms_total']:8.2f} share={k['ms_total']/tot:.4f} tflops={k.get('tflops','-')} alg_gbs={k.get('gbs','-')}\n")
+PY
+( time DZN_BENCH_ONE_DEVICE=1 timeout 500 python bench.py --gpus 2 --steps 2 --warmup 1 --strong-minutes 30 --batch 192 ) > $O/bench_gpus2_one_device.json 2> $O/bench_gpus2.err
+head -14 $O/kernel_stats.csv
+cut -c1-2200 $O/bench_f32h.json
+tail -4 $O/bench_driver_style.err; cut -c1-300 $O/bench_driver_style.json
+else
+timeout 600 python bench.py --model wavlm_base_s80_md --window 5 --batch 32 --stage seg --minutes 30 --steps 3 --warmup 1 --no-alt > $O/bench_base_s80_5s_b32.json 2> $O/bench_base.err
+cut -c1-1200 $O/bench_base_s80_5s_b32.json
+DZN_LINKAGE_DEBUG=1 timeout 600 python scripts/e2e_timing.py 240 384 > $O/e2e_4h.log 2>&1; grep -m1 "^timings" $O/e2e_4h.log; grep -m1 "^E2E_JSON" $O/e2e_4h.log | cut -c10- > $O/e2e_4h_1gpu.json
+timeout 600 python bench.py --steps 1 --warmup 1 --no-alt --no-cpu-baseline --strong-minutes 240 > $O/bench_with_strong_4h_leg.json 2> $O/bench_strong.err; python - <<PY
+import json
+d=json.loads(open("$O/bench_with_strong_4h_leg.json").read().strip().splitlines()[-1]); print(d.get("strong_scaling_e2e"))
+PY
+DZN_DECISION_WINDOWS=256 timeout 900 python -m pytest tests/test_decisions_gpu.py -m gpu -q 2>&1 | tail -3; cp gpurun_out/decision_parity.json $O/decision_parity_256.json
+fi

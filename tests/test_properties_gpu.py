@@ -53,6 +53,32 @@ def test_batch_composition_and_sharding_are_bit_invariant(engine, gpu):
     assert torch.equal(torch.cat([p.embeddings for p in parts]), full.embeddings)
 
 
+def test_two_handles_on_two_streams_give_the_same_bits(built_lib, gpu):
+    """(r4) WindowRunner(extra_engines=...): consecutive batches alternate over two handles with the same weights, each on
+    its own HIP stream, so that independent batches overlap on the device.  Decisions and embeddings must be the bits of
+    the one-handle, one-stream run (a window's result depends neither on its batch nor on the handle), also when the
+    caller's stream still has the upload queued and when the number of batches is odd."""
+    from diarizen_amd.configs import RESNET34, get_seg_config
+    from diarizen_amd.engine import Engine
+    from diarizen_amd.inference import WindowRunner
+    from testkit.weights import emb_state_dict, turn_taking_state_dict
+    cfg = get_seg_config("tiny_ln")
+    engine, second = (Engine(cfg, turn_taking_state_dict(cfg, 0), RESNET34, emb_state_dict(0), max_batch=16, max_samples=16000,
+                             precision="f32h", device=gpu) for _ in range(2))
+    one = WindowRunner(engine, 1.0, 0.1, 16)
+    two = WindowRunner(engine, 1.0, 0.1, 7, extra_engines=(second,))       # 7-window batches: odd batch count below
+    host = _recording(6.3)
+    for _ in range(2):
+        wave = host.to(gpu, non_blocking=True)                              # the upload is still in flight on this stream
+        b = two.run(wave)
+        a = one.run(wave)
+        torch.cuda.synchronize()
+        assert a.segmentations.shape[0] == 54
+        assert torch.equal(a.segmentations, b.segmentations) and torch.equal(a.embeddings, b.embeddings)
+    engine.close()
+    second.close()
+
+
 def test_outputs_are_well_formed_at_full_size(engine, gpu):
     wave = _recording(8.0 + 0.8 * 31, seed=9).to(gpu)
     from diarizen_amd.inference import WindowRunner
