@@ -763,6 +763,30 @@ def main():
                                                      "ms_per_step": round(dt2 * 1e3, 2), "steps": ALT_STEPS,
                                                      "dtype": DTYPE_NOTE["f16"],
                                                      "parity": F16_PARITY}}
+        if world == 1 and not args.no_alt and args.streams == 1:
+            # the same steps with consecutive batches alternating over TWO engine handles / HIP streams (what DiariZenPipeline
+            # does by default, num_streams = 2): reported beside the headline, whose steps stay on one stream because the
+            # per-kernel event timing behind `roofline` is only meaningful there
+            e2 = Engine(cfg, sd, RESNET34, esd, max_batch=args.batch, max_samples=window, precision=args.precision, device=dev)
+            e3 = Engine(cfg, sd, RESNET34, esd, max_batch=args.batch, max_samples=window, precision=args.precision, device=dev)
+            r2 = WindowRunner(e2, args.window, 0.1, args.batch, extra_engines=(e3,))
+
+            def one2():
+                res = r2.run(wave, with_embeddings=full)
+                _ = (res.segmentations.cpu(), res.embeddings.cpu()) if full else res.segmentations.cpu()
+            one2()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(ALT_STEPS):
+                one2()
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t2) / ALT_STEPS
+            e2.close()
+            e3.close()
+            out["two_streams"] = {"value": round(audio_s / dt2, 2), "unit": "audio-seconds/s", "ms_per_step": round(dt2 * 1e3, 2),
+                                  "steps": ALT_STEPS, "note": "consecutive batches alternate over two engine handles on two HIP "
+                                  "streams (inference.WindowRunner extra_engines; the pipeline's default): same results bit "
+                                  "for bit, independent batches overlap on the device; unprofiled"}
         if world == 1 and full and not args.no_e2e and args.minutes <= 60:
             eng = None
             torch.cuda.empty_cache()

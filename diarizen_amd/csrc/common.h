@@ -200,6 +200,12 @@ int launch_conv3x3_c32_split(const float* in, const void* W3, const float* bias,
                              const void* W2h = nullptr, const float* col_scale = nullptr, const float* amax_in = nullptr,
                              const int* z_count = nullptr, const int* z_list = nullptr);
 
+// resblock_fused.hip (r4): one BasicBlock of the 32-channel ResNet stage, intermediate kept in LDS (fp16 two-term modes)
+int launch_resblock32_fused(const float* in, float* out, const void* W1, const float* cs1, const float* b1, const void* W2,
+                            const float* cs2, const float* b2, const float* amax_in, float* amax_out, float l1max1,
+                            float bmax1, int B, int Hs, int Ws, int np, hipStream_t s, const int* z_count = nullptr,
+                            const int* z_list = nullptr);
+
 // post.hip
 int launch_prepare_masks(const uint8_t* ml, int B, int L, int S, int median, int exclude_overlap,
                          int min_num_frames, uint8_t* filtered, float* masks, hipStream_t st);

@@ -86,6 +86,7 @@ struct ConfLayer {
 struct ResConv {
   Lin l;
   int cin = 0, cout = 0, ksz = 3, stride = 1;
+  float l1max = 0.f, bmax = 0.f;   // max_oc sum_k |W[oc][k]| and max_oc |shift[oc]| of the folded conv: |out| <= amax(in) l1max + bmax
 };
 struct ResBlock {
   ResConv c1, c2, sc;
@@ -199,6 +200,7 @@ struct dzn_handle {
   // (= f32h) does; the conv stack alone carries ~70 % of the error variance for 4 % of the flops, so it keeps two terms
   // (0.247 -> 0.133, flips 0.52 % -> 0.33 %); centring the LayerNorm-folded split changes nothing (0.228 vs 0.247: the
   // error is plain operand rounding, not the mean * colsum cancellation) and stays off.
+  bool fuse_resblock = true;  // DZN_NO_RESBLOCK_FUSION (read once, at dzn_create)
   unsigned f16_keep2 = 0x1;
   bool f16_center = false;
 };
@@ -767,6 +769,12 @@ ResConv make_resconv(H* h, const std::string& conv, const std::string& bn, int c
   r.ksz = ksz;
   r.stride = stride;
   r.l = make_lin(h, wp, sh.data(), cout, K, cout, K);
+  for (int o = 0; o < cout; ++o) {
+    double l1 = 0.0;
+    for (int k = 0; k < K; ++k) l1 += std::fabs((double)wp[(size_t)o * K + k]);
+    r.l1max = std::max(r.l1max, (float)(l1 * (1.0 + 1e-6)));
+    r.bmax = std::max(r.bmax, std::fabs(sh[o]));
+  }
   return r;
 }
 
@@ -1536,8 +1544,17 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
         float* inb = h->sbuf[s][cur];
         float* midb = h->sbuf[s][(cur + 1) % 3];
         float* outb = h->sbuf[s][(cur + 2) % 3];
-        conv3(inb, rb.c1, midb, nullptr, DZN_ACT_RELU, 0);
-        conv3(midb, rb.c2, outb, inb, DZN_ACT_NONE, 1);
+        // (r4) 32-channel blocks in the two-term fp16 modes: both convolutions in one kernel, the intermediate image
+        // stays in LDS (resblock_fused.hip); DZN_NO_RESBLOCK_FUSION=1 (read at dzn_create) keeps the per-conv kernels
+        if (h->fuse_resblock && prec_is_h2(c.precision) && rb.c1.cin == 32 && rb.c1.cout == 32 && rb.c1.l.W2h && rb.c2.l.W2h &&
+            img_am(inb)) {
+          chk(launch_resblock32_fused(inb, outb, rb.c1.l.W2h, rb.c1.l.wsc, rb.c1.l.b, rb.c2.l.W2h, rb.c2.l.wsc, rb.c2.l.b,
+                                      img_am(inb), img_am(outb), rb.c1.l1max, rb.c1.bmax, B, Hs, Ws, 2, st, zc, zl),
+              "resblock32 fused");
+        } else {
+          conv3(inb, rb.c1, midb, nullptr, DZN_ACT_RELU, 0);
+          conv3(midb, rb.c2, outb, inb, DZN_ACT_NONE, 1);
+        }
         cur = (cur + 2) % 3;
       }
     }
@@ -1606,6 +1623,7 @@ int dzn_create(const dzn_config* cfg, dzn_handle** out) {
   h->cfg = *cfg;
   if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
   h->emb_skip = getenv("DZN_EMB_NO_SKIP") == nullptr;
+  h->fuse_resblock = getenv("DZN_NO_RESBLOCK_FUSION") == nullptr;
   if (const char* e = getenv("DZN_F16_KEEP2")) h->f16_keep2 = (unsigned)strtoul(e, nullptr, 0);
   if (const char* e = getenv("DZN_F16_CENTER")) h->f16_center = e[0] != '0';
   const char* dbg = getenv("DZN_DEBUG_TAPS");

@@ -149,6 +149,23 @@ def conv3x3_c32(img, W3, bias, R=None, relu=False, post_relu=False, out=None, h2
     return out
 
 
+def resblock32_fused(img, h2_w1, b1, h2_w2, b2, l1max1: float, bmax1: float, out=None):
+    """one 32-channel BasicBlock, out = relu(conv2(relu(conv1(img) + b1)) + b2 + img), in ONE kernel
+    (csrc/resblock_fused.hip): zero-bordered NHWC fp32 images [B, H+2, W+2, 32]; h2_w = split_weights_h2(W[32, 288])
+    = (planes, inverse row scales); l1max1 / bmax1 bound the intermediate: max_oc sum_k |W1[oc][k]|, max_oc |b1[oc]|."""
+    lib = _lib.load()
+    assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and img.shape[-1] == 32
+    B, Hp, Wp, _ = img.shape
+    if out is None:
+        out = torch.zeros_like(img)
+    am = img.reshape(B, -1).abs().amax(dim=1).float().contiguous()
+    (W1, cs1), (W2, cs2) = h2_w1, h2_w2
+    check(lib.dzn_op_resblock32_fused(_p(img), _p(out), _p(W1), _p(cs1), _p(b1), _p(W2), _p(cs2), _p(b2), _p(am),
+                                      float(l1max1), float(bmax1), B, Hp - 2, Wp - 2, _stream()),
+          what="dzn_op_resblock32_fused")
+    return out
+
+
 def linkage_centroid(emb, device: int = -1):
     """scipy.cluster.hierarchy.linkage(emb, "centroid", "euclidean") on the device (csrc/linkage.hip):
     emb = host float32 [n, dim] (numpy), returns the dendrogram float64 [n - 1, 4]."""

@@ -114,6 +114,14 @@ typedef struct dzn_gemm_desc {
   int32_t ln_centered;
 } dzn_gemm_desc;
 
+/* (r4) One BasicBlock of the 32-channel ResNet stage in one kernel (csrc/resblock_fused.hip):
+ * out = relu(conv2(relu(conv1(in) + b1)) + b2 + in) over zero-bordered NHWC fp32 images [B][Hs+2][Ws+2][32]; W1 / W2 = fp16
+ * two-term planes of the folded [32][288] weights (dzn_op_split_weights_h2), cs = their inverse row scales, amax_in f32 [B]
+ * = per-image max |in|, l1max1 = max_oc sum_k |W1[oc][k]|, bmax1 = max_oc |b1[oc]| (bound of the intermediate). */
+int dzn_op_resblock32_fused(const float* in, float* out, const void* W1, const float* cs1, const float* b1, const void* W2,
+                            const float* cs2, const float* b2, const float* amax_in, float l1max1, float bmax1, int32_t B,
+                            int32_t Hs, int32_t Ws, void* stream);
+
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
 
 /* Exact 3-way bf16 split of fp32 weights for DZN_PREC_F32_SPLIT (csrc/gemm_split.hip):

@@ -563,6 +563,46 @@ def test_conv3x3_c32_split(built_lib, gpu, H, W, B):
         assert out2[:, 0].abs().max() == 0 and out2[:, :, 0].abs().max() == 0
 
 
+@pytest.mark.parametrize("H,W,B", [(5, 37, 2), (80, 798, 2), (12, 126, 3), (3, 60, 1), (7, 61, 2), (1, 1, 1)])
+def test_resblock32_fused_equals_two_convs(built_lib, gpu, H, W, B):
+    """(r4) csrc/resblock_fused.hip — both convolutions of a 32-channel BasicBlock in one kernel, the intermediate image kept
+    in LDS line buffers — against (a) the block evaluated by torch in float64 (wespeaker/resnet.py:139-144 with folded
+    BatchNorm: relu(conv2(relu(conv1(x) + b1)) + b2 + x)) and (b) the same block as TWO launches of the per-conv kernel
+    (conv_split.hip, fp16 two-term variant).  conv1 is bit-identical by construction; the only difference is the
+    power-of-two scale of the intermediate's fp16 split (a-priori bound instead of the tracked |max|), i.e. last-bit
+    differences.  Strips of 60 columns: widths around the strip boundary (60, 61), one strip narrower than a block, a
+    one-pixel image, the real stage-1 geometry (80 x 798).  Borders of the output stay exactly zero."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(H * 1000 + W + 7)
+    x = torch.randn(B, 32, H, W, generator=g) * torch.exp(0.5 * torch.randn(B, 1, 1, 1, generator=g))
+    w1 = torch.randn(32, 32, 3, 3, generator=g) * 0.08
+    w2 = torch.randn(32, 32, 3, 3, generator=g) * 0.08
+    b1, b2 = torch.randn(32, generator=g) * 0.3, torch.randn(32, generator=g) * 0.3
+
+    def padded(t):
+        o = torch.zeros(B, H + 2, W + 2, 32)
+        o[:, 1:-1, 1:-1] = t.permute(0, 2, 3, 1)
+        return o.contiguous()
+    wp1 = w1.permute(0, 2, 3, 1).reshape(32, 288).contiguous()          # k = (dh*3 + dw)*32 + ci
+    wp2 = w2.permute(0, 2, 3, 1).reshape(32, 288).contiguous()
+    h1, h2 = ops.split_weights_h2(wp1.to(gpu)), ops.split_weights_h2(wp2.to(gpu))
+    W31, W32 = ops.split_weights(wp1.to(gpu)), ops.split_weights(wp2.to(gpu))
+    xin = padded(x).to(gpu)
+    fused = ops.resblock32_fused(xin, h1, b1.to(gpu), h2, b2.to(gpu), float(wp1.abs().sum(1).max()) * (1 + 1e-6),
+                                 float(b1.abs().max())).cpu()
+    mid = ops.conv3x3_c32(xin, W31, b1.to(gpu), relu=True, h2_weights=h1)
+    two = ops.conv3x3_c32(mid, W32, b2.to(gpu), R=xin, post_relu=True, h2_weights=h2).cpu()
+    F = torch.nn.functional
+    ref = torch.relu(F.conv2d(torch.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1)), w2.double(), b2.double(),
+                              padding=1) + x.double())
+    got = fused[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double()
+    assert _rel_err(got, ref) < 1e-5
+    scale = two.abs().max().item()
+    assert (fused - two).abs().max().item() <= 2e-6 * scale, ((fused - two).abs().max().item(), scale)
+    assert fused[:, 0].abs().max() == 0 and fused[:, -1].abs().max() == 0
+    assert fused[:, :, 0].abs().max() == 0 and fused[:, :, -1].abs().max() == 0
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 64, 256), (1000, 200, 1024), (257, 1024, 96)])
 def test_gemm_presplit_operand(built_lib, gpu, M, N, K):
     """gemm_split_pre.hip: A handed over as three bf16 planes (dzn_op_split_rows) gives the same result as the
