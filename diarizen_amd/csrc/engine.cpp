@@ -201,6 +201,7 @@ struct dzn_handle {
   // (0.247 -> 0.133, flips 0.52 % -> 0.33 %); centring the LayerNorm-folded split changes nothing (0.228 vs 0.247: the
   // error is plain operand rounding, not the mean * colsum cancellation) and stays off.
   bool fuse_resblock = true;  // DZN_NO_RESBLOCK_FUSION (read once, at dzn_create)
+  int resblock_ws = 2;        // DZN_RESBLOCK_WS bit mask: 1 = 32-plane blocks, 2 = 64-plane blocks on the producer / consumer form
   unsigned f16_keep2 = 0x1;
   bool f16_center = false;
 };
@@ -1546,11 +1547,17 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
         float* outb = h->sbuf[s][(cur + 2) % 3];
         // (r4) 32-channel blocks in the two-term fp16 modes: both convolutions in one kernel, the intermediate image
         // stays in LDS (resblock_fused.hip); DZN_NO_RESBLOCK_FUSION=1 (read at dzn_create) keeps the per-conv kernels
-        if (h->fuse_resblock && prec_is_h2(c.precision) && rb.c1.cin == 32 && rb.c1.cout == 32 && rb.c1.l.W2h && rb.c2.l.W2h &&
-            img_am(inb)) {
+        const bool fusable = h->fuse_resblock && prec_is_h2(c.precision) && rb.c1.cin == rb.c1.cout && rb.c1.l.W2h &&
+                             rb.c2.l.W2h && img_am(inb) != nullptr;
+        if (fusable && rb.c1.cin == 32 && !(h->resblock_ws & 1)) {
           chk(launch_resblock32_fused(inb, outb, rb.c1.l.W2h, rb.c1.l.wsc, rb.c1.l.b, rb.c2.l.W2h, rb.c2.l.wsc, rb.c2.l.b,
                                       img_am(inb), img_am(outb), rb.c1.l1max, rb.c1.bmax, B, Hs, Ws, 2, st, zc, zl),
               "resblock32 fused");
+        } else if (fusable && ((rb.c1.cin == 32 && (h->resblock_ws & 1)) || (rb.c1.cin == 64 && (h->resblock_ws & 2)))) {
+          // producer / consumer wavefronts (resblock_ws.hip): the only fused form for the 64-plane stage
+          chk(launch_resblock_ws(inb, outb, rb.c1.l.W2h, rb.c1.l.wsc, rb.c1.l.b, rb.c2.l.W2h, rb.c2.l.wsc, rb.c2.l.b, img_am(inb),
+                                 img_am(outb), rb.c1.l1max, rb.c1.bmax, B, Hs, Ws, rb.c1.cin, st, zc, zl),
+              "resblock ws");
         } else {
           conv3(inb, rb.c1, midb, nullptr, DZN_ACT_RELU, 0);
           conv3(midb, rb.c2, outb, inb, DZN_ACT_NONE, 1);
@@ -1624,6 +1631,7 @@ int dzn_create(const dzn_config* cfg, dzn_handle** out) {
   if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
   h->emb_skip = getenv("DZN_EMB_NO_SKIP") == nullptr;
   h->fuse_resblock = getenv("DZN_NO_RESBLOCK_FUSION") == nullptr;
+  if (const char* e = getenv("DZN_RESBLOCK_WS")) h->resblock_ws = atoi(e);
   if (const char* e = getenv("DZN_F16_KEEP2")) h->f16_keep2 = (unsigned)strtoul(e, nullptr, 0);
   if (const char* e = getenv("DZN_F16_CENTER")) h->f16_center = e[0] != '0';
   const char* dbg = getenv("DZN_DEBUG_TAPS");

@@ -166,6 +166,21 @@ def resblock32_fused(img, h2_w1, b1, h2_w2, b2, l1max1: float, bmax1: float, out
     return out
 
 
+def resblock_ws(img, h2_w1, b1, h2_w2, b2, l1max1: float, bmax1: float, out=None):
+    """the same block with producer / consumer wavefronts (csrc/resblock_ws.hip), C = img.shape[-1] in (32, 64);
+    h2_w = split_weights_h2(W[C, 9 C]) with k = (dh*3 + dw) * C + ci"""
+    lib = _lib.load()
+    assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and img.shape[-1] in (32, 64)
+    B, Hp, Wp, Cn = img.shape
+    if out is None:
+        out = torch.zeros_like(img)
+    am = img.reshape(B, -1).abs().amax(dim=1).float().contiguous()
+    (W1, cs1), (W2, cs2) = h2_w1, h2_w2
+    check(lib.dzn_op_resblock_ws(_p(img), _p(out), _p(W1), _p(cs1), _p(b1), _p(W2), _p(cs2), _p(b2), _p(am), float(l1max1),
+                                 float(bmax1), B, Hp - 2, Wp - 2, Cn, _stream()), what="dzn_op_resblock_ws")
+    return out
+
+
 def linkage_centroid(emb, device: int = -1):
     """scipy.cluster.hierarchy.linkage(emb, "centroid", "euclidean") on the device (csrc/linkage.hip):
     emb = host float32 [n, dim] (numpy), returns the dendrogram float64 [n - 1, 4]."""

@@ -122,6 +122,12 @@ int dzn_op_resblock32_fused(const float* in, float* out, const void* W1, const f
                             const float* cs2, const float* b2, const float* amax_in, float l1max1, float bmax1, int32_t B,
                             int32_t Hs, int32_t Ws, void* stream);
 
+/* (r4) The same block with producer / consumer wavefronts (csrc/resblock_ws.hip), C = 32 or 64 planes: images
+ * [B][Hs+2][Ws+2][C], W = planes of the folded [C][9 C] weights with k = (dh*3 + dw) * C + ci. */
+int dzn_op_resblock_ws(const float* in, float* out, const void* W1, const float* cs1, const float* b1, const void* W2,
+                       const float* cs2, const float* b2, const float* amax_in, float l1max1, float bmax1, int32_t B,
+                       int32_t Hs, int32_t Ws, int32_t C, void* stream);
+
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
 
 /* Exact 3-way bf16 split of fp32 weights for DZN_PREC_F32_SPLIT (csrc/gemm_split.hip):

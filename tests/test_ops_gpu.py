@@ -603,6 +603,41 @@ def test_resblock32_fused_equals_two_convs(built_lib, gpu, H, W, B):
     assert fused[:, :, 0].abs().max() == 0 and fused[:, :, -1].abs().max() == 0
 
 
+@pytest.mark.parametrize("C,H,W,B", [(32, 5, 37, 2), (32, 80, 798, 1), (32, 7, 61, 2), (32, 1, 1, 1), (64, 5, 37, 2), (64, 40, 399, 2),
+                                     (64, 3, 60, 1), (64, 7, 121, 3), (64, 2, 1, 1)])
+def test_resblock_ws_matches_float64_and_the_fused_form(built_lib, gpu, C, H, W, B):
+    """(r4) csrc/resblock_ws.hip — the BasicBlock with producer / consumer wavefronts (conv1 and conv2 run concurrently, one
+    row apart, through LDS line buffers), C = 32 and C = 64 planes (ResNet stages 1 and 2) — against the block evaluated by
+    torch in float64; for C = 32 also against resblock_fused.hip, which performs the same arithmetic in alternating phases
+    (identical bits expected: same planes, same scales, same product order)."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(C * 100000 + H * 1000 + W)
+    x = torch.randn(B, C, H, W, generator=g) * torch.exp(0.5 * torch.randn(B, 1, 1, 1, generator=g))
+    w1 = torch.randn(C, C, 3, 3, generator=g) * (0.08 * (32 / C) ** 0.5)
+    w2 = torch.randn(C, C, 3, 3, generator=g) * (0.08 * (32 / C) ** 0.5)
+    b1, b2 = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+
+    def padded(t):
+        o = torch.zeros(B, H + 2, W + 2, C)
+        o[:, 1:-1, 1:-1] = t.permute(0, 2, 3, 1)
+        return o.contiguous()
+    wp1 = w1.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()          # k = (dh*3 + dw)*C + ci
+    wp2 = w2.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()
+    h1, h2 = ops.split_weights_h2(wp1.to(gpu)), ops.split_weights_h2(wp2.to(gpu))
+    xin = padded(x).to(gpu)
+    l1, bm = float(wp1.abs().sum(1).max()) * (1 + 1e-6), float(b1.abs().max())
+    out = ops.resblock_ws(xin, h1, b1.to(gpu), h2, b2.to(gpu), l1, bm).cpu()
+    F = torch.nn.functional
+    ref = torch.relu(F.conv2d(torch.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1)), w2.double(), b2.double(),
+                              padding=1) + x.double())
+    assert _rel_err(out[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double(), ref) < 1e-5
+    assert out[:, 0].abs().max() == 0 and out[:, -1].abs().max() == 0
+    assert out[:, :, 0].abs().max() == 0 and out[:, :, -1].abs().max() == 0
+    if C == 32:
+        fused = ops.resblock32_fused(xin, h1, b1.to(gpu), h2, b2.to(gpu), l1, bm).cpu()
+        assert torch.equal(out, fused)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 64, 256), (1000, 200, 1024), (257, 1024, 96)])
 def test_gemm_presplit_operand(built_lib, gpu, M, N, K):
     """gemm_split_pre.hip: A handed over as three bf16 planes (dzn_op_split_rows) gives the same result as the
