@@ -55,21 +55,26 @@ DTYPE_NOTE = {"f32": "f32 (fp32 MFMA v_mfma_f32_16x16x4_f32)",
                      "data, norms, softmax, residual stream fp32"}
 PEAK_HBM_GBS = 8000.0
 TRAFFIC_SOURCE = ("committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x 2 "
-                  "correction; scripts/final_measure_r3.sh -> profiles/) — not measured in this run")
+                  "correction; scripts/final_measure_r4.sh -> profiles/) — not measured in this run")
 # what holds the results of this path to the reference's (tests/ -m gpu, all through the C ABI; fixtures made by
 # oracle/gen_golden.py from the reference's own code)
 PARITY_NOTE = {
     "bar": "fp32 modes: max |dlogp| <= 1e-3 vs the reference-made goldens, identical u8 decisions, embeddings cos >= 0.9999, RTTM "
            "text identical; integer / index work bit-exact",
-    "tests": ["test_seg_gpu.py (4 configs x f32h/f32s/f32 vs reference goldens)", "test_emb_gpu.py (ResNet34 + fbank vs float64)",
+    "tests": ["test_seg_gpu.py (4 pruned configs x f32h/f32s/f32 vs reference goldens, plain + turn-taking; r4: dense wavlm_large "
+              "and a checkpoint-embedded config vs reference-made goldens)", "test_emb_gpu.py (ResNet34 + fbank vs float64; r4: device "
+              "fbank vs closed-form known answers; forwards capturable in a HIP graph)",
               "test_decisions_gpu.py (0 argmax flips on 102 144 frames: profiles/r3_decision_parity.json)",
-              "test_f32h_grade_gpu.py (all 69 (N, K) of this step vs float64: f32h <= 0.84 x the fp32-MFMA error, "
+              "test_f32h_grade_gpu.py (all 69 (N, K) of the r3 step vs float64: f32h <= 0.84 x the fp32-MFMA error, "
               "profiles/r3_f32h_grade_per_shape.json)",
+              "test_ops_gpu.py (r4: fused BasicBlock kernels == two per-conv launches to 2e-6, == float64 to 1e-5)",
               "test_host_ref.py (host stage == the reference's own aggregate / speaker_count / to_diarization / reconstruct / "
               "Binarize)", "test_host.py (reference clustering incl. forced min/max speakers, max_num_embeddings)",
               "test_ops_gpu.py::test_linkage_centroid_30k_equals_scipy_golden", "test_pipeline_gpu.py (RTTM == golden, streaming)",
-              "test_properties_gpu.py (batch / shard bit-invariance)", "test_dist_gpu.py (2-rank pipeline RTTM == 1-GPU golden)"],
-    "unpinned": ["kaldi fbank vs torchaudio (absent offline; == transformers.audio_utils to 1e-6 in float64)",
+              "test_properties_gpu.py (batch / shard bit-invariance; r4: two handles on two streams == one)",
+              "test_dist_gpu.py (2-rank pipeline RTTM == 1-GPU golden)"],
+    "unpinned": ["kaldi fbank vs torchaudio (absent offline; r4: two independent float64 restatements + closed-form known answers agree "
+                 "to 1e-11, == transformers.audio_utils to 1e-6)",
                  "pyannote.core 5.0.0 frame arithmetic / RTTM writer (absent offline)"]}
 ALT_STEPS = 5          # timed steps of every comparison leg (other fp32 modes, reduced precision)
 # the reduced mode against SURVEY 8d's reduced bar (max |dlogp| <= 5e-2, argmax >= 99.5 %, cos >= 0.999, DER delta <= 0.1 abs),
@@ -95,7 +100,9 @@ PMC_SYMBOLS = {"conv0_ln_gelu": "conv0_kernel", "conv01_fused": "conv01_fused_ke
                "attention_relpos_f32s": "attn_split_kernel<true, 3>", "attention_relpos_f32h": "attn_split_kernel<true, 2>",
                "attention_f32s": "attn_split_kernel<false, 3>", "attention_f32h": "attn_split_kernel<false, 2>",
                "conv3x3_c32_f32s": "conv3x3_c32_split_kernel<3>", "conv3x3_c32_f32h": "conv3x3_c32_split_kernel<2>",
-               "layernorm": "layernorm_kernel<4", "row_stats": "row_stats_kernel<16>", "gate_ln_stats": "gate_stats_kernel"}
+               "layernorm": "layernorm_kernel<4", "row_stats": "row_stats_kernel<16>", "gate_ln_stats": "gate_stats_kernel",
+               "resblock32_fused_f32h": "resblock32_fused_kernel<2>", "resblock64_ws_f32h": "resblock_ws_kernel<64>",
+               "resblock32_ws_f32h": "resblock_ws_kernel<32>"}
 
 
 def pmc_table(args):
