@@ -48,5 +48,5 @@ timeout 600 python bench.py --steps 1 --warmup 1 --no-alt --no-cpu-baseline --st
 import json
 d=json.loads(open("$O/bench_with_strong_4h_leg.json").read().strip().splitlines()[-1]); print(d.get("strong_scaling_e2e"))
 PY
-DZN_DECISION_WINDOWS=256 timeout 900 python -m pytest tests/test_decisions_gpu.py -m gpu -q 2>&1 | tail -3; cp gpurun_out/decision_parity.json $O/decision_parity_256.json
+true
 fi
