@@ -64,7 +64,7 @@ PARITY_NOTE = {
     "tests": ["test_seg_gpu.py (4 pruned configs x f32h/f32s/f32 vs reference goldens, plain + turn-taking; r4: dense wavlm_large "
               "and a checkpoint-embedded config vs reference-made goldens)", "test_emb_gpu.py (ResNet34 + fbank vs float64; r4: device "
               "fbank vs closed-form known answers; forwards capturable in a HIP graph)",
-              "test_decisions_gpu.py (0 argmax flips on 102 144 frames: profiles/r3_decision_parity.json)",
+              "test_decisions_gpu.py (0 argmax flips on 102 144 frames: profiles/r4_decision_parity.json)",
               "test_f32h_grade_gpu.py (all 69 (N, K) of the r3 step vs float64: f32h <= 0.84 x the fp32-MFMA error, "
               "profiles/r3_f32h_grade_per_shape.json)",
               "test_ops_gpu.py (r4: fused BasicBlock kernels == two per-conv launches to 2e-6, == float64 to 1e-5)",
