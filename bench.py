@@ -11,7 +11,7 @@ through gloo, because RCCL refuses duplicate devices.
 
 One "step" = one pass of the device hot path over ONE synthetic recording per rank
 (BASELINE.json configs[2]: wavlm-large-s80, 30 min of 16 kHz mono, window 8 s, step 0.8 s ->
-2241 windows in 6 balanced launches of 374 (--batch 384 is the maximum): windows are independent, results do not depend
+2241 windows in 4 balanced launches of 561 (--batch 576 is the maximum): windows are independent, results do not depend
 on the batch): for every batch of windows  segmentation (WavLM + Conformer + powerset)
 -> median filter + overlap-excluded masks -> ResNet34 embeddings (trunk shared by the 4 local
 speakers), all through the C ABI of libdzn_hip.so, the recording already resident in HBM.  The
@@ -469,8 +469,10 @@ def main():
                          "f32 = the fp32 MFMA instruction")
     ap.add_argument("--minutes", type=float, default=30.0)
     ap.add_argument("--window", type=float, default=8.0)
-    ap.add_argument("--batch", type=int, default=384,
-                    help="maximum windows per launch (the runner balances: 2241 windows -> 6 launches of 374)")
+    ap.add_argument("--batch", type=int, default=576,
+                    help="maximum windows per launch (the runner balances: 2241 windows -> 4 launches of 561; r4 sweep on one box: "
+                         "384 / 576 / 768 / 1152 -> 1062 / 1043 / 1042 / 1036 ms per step; 576 keeps two handles of 68 GB each "
+                         "and an even number of launches for the two-stream pipeline)")
     ap.add_argument("--streams", type=int, default=1,
                     help="engine handles / HIP streams that consecutive batches of a step alternate over (WindowRunner "
                          "extra_engines); the in-situ per-kernel profiler needs 1 (kernel durations are not separable when "
@@ -775,8 +777,7 @@ def main():
             # does by default, num_streams = 2): reported beside the headline, whose steps stay on one stream because the
             # per-kernel event timing behind `roofline` is only meaningful there
             e2 = Engine(cfg, sd, RESNET34, esd, max_batch=args.batch, max_samples=window, precision=args.precision, device=dev)
-            e3 = Engine(cfg, sd, RESNET34, esd, max_batch=args.batch, max_samples=window, precision=args.precision, device=dev)
-            r2 = WindowRunner(e2, args.window, 0.1, args.batch, extra_engines=(e3,))
+            r2 = WindowRunner(eng, args.window, 0.1, args.batch, extra_engines=(e2,))     # the headline's handle + one more
 
             def one2():
                 res = r2.run(wave, with_embeddings=full)
@@ -789,7 +790,6 @@ def main():
             torch.cuda.synchronize()
             dt2 = (time.perf_counter() - t2) / ALT_STEPS
             e2.close()
-            e3.close()
             out["two_streams"] = {"value": round(audio_s / dt2, 2), "unit": "audio-seconds/s", "ms_per_step": round(dt2 * 1e3, 2),
                                   "steps": ALT_STEPS, "note": "consecutive batches alternate over two engine handles on two HIP "
                                   "streams (inference.WindowRunner extra_engines; the pipeline's default): same results bit "

@@ -17,8 +17,8 @@ timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$T -
 done
 cd $R
 cc() { find $O/pmc_$1 -name '*counter_collection.csv' | head -1; }
-python scripts/pmc_summary.py $O/pmc_f32h_30min_b384.json $(cc FETCH_SIZE) $(cc WRITE_SIZE) $(cc MfmaUtil) $(cc GRBM_GUI_ACTIVE)
-cp $O/pmc_f32h_30min_b384.json $R/profiles/r4_pmc_f32h_30min_b384.json
+python scripts/pmc_summary.py $O/pmc_f32h_30min_b576.json $(cc FETCH_SIZE) $(cc WRITE_SIZE) $(cc MfmaUtil) $(cc GRBM_GUI_ACTIVE)
+cp $O/pmc_f32h_30min_b576.json $R/profiles/r4_pmc_f32h_30min_b576.json
 timeout 900 python bench.py > $O/bench_f32h.json 2> $O/bench.err
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-e2e --no-config1 > $O/bench_under_rocprof.json 2> $O/kt.err
@@ -43,7 +43,7 @@ tail -4 $O/bench_driver_style.err; cut -c1-300 $O/bench_driver_style.json
 else
 timeout 600 python bench.py --model wavlm_base_s80_md --window 5 --batch 32 --stage seg --minutes 30 --steps 3 --warmup 1 --no-alt > $O/bench_base_s80_5s_b32.json 2> $O/bench_base.err
 cut -c1-1200 $O/bench_base_s80_5s_b32.json
-DZN_LINKAGE_DEBUG=1 timeout 600 python scripts/e2e_timing.py 240 384 > $O/e2e_4h.log 2>&1; grep -m1 "^timings" $O/e2e_4h.log; grep -m1 "^E2E_JSON" $O/e2e_4h.log | cut -c10- > $O/e2e_4h_1gpu.json
+DZN_LINKAGE_DEBUG=1 timeout 600 python scripts/e2e_timing.py 240 576 > $O/e2e_4h.log 2>&1; grep -m1 "^timings" $O/e2e_4h.log; grep -m1 "^E2E_JSON" $O/e2e_4h.log | cut -c10- > $O/e2e_4h_1gpu.json
 timeout 600 python bench.py --steps 1 --warmup 1 --no-alt --no-cpu-baseline --strong-minutes 240 > $O/bench_with_strong_4h_leg.json 2> $O/bench_strong.err; python - <<PY
 import json
 d=json.loads(open("$O/bench_with_strong_4h_leg.json").read().strip().splitlines()[-1]); print(d.get("strong_scaling_e2e"))

@@ -1,4 +1,8 @@
 # r4 GEMM probe: 32x32x16 MFMA forms vs the 16x16x32 production tiles (one process per shape set), then the pipeline A/B
+# needs a DZN_TUNING build of gemm_split.hip linked as diarizen_amd/lib/libdzn_hip_tuning.so:
+#   hipcc <FLAGS of diarizen_amd/build.py> -DDZN_TUNING -c diarizen_amd/csrc/gemm_split.hip -o /tmp/gs_tuning.o
+#   hipcc -shared -fPIC --offload-arch=gfx950 -o diarizen_amd/lib/libdzn_hip_tuning.so $(ls diarizen_amd/build/*.o | grep -v gemm_split.hip.o) /tmp/gs_tuning.o
+# (DZN_TUNING=1 python -m diarizen_amd.build builds the whole library that way)
 set -x
 O=gpurun_out/${1:-r4b}; mkdir -p $O
 export DZN_HIP_LIB=$PWD/diarizen_amd/lib/libdzn_hip_tuning.so
