@@ -444,6 +444,9 @@ def rendezvous_check(args, rank: int, world: int):
     to an all-reduce, rank 0 prints what came up."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")          # only reached without a launcher at --gpus 1
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
     dist.init_process_group(backend="gloo")
     if dist.get_world_size() != args.gpus:
         raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")

@@ -4,10 +4,12 @@
 // Same rolling line buffers as resblock_fused.hip (an X ring of input rows and an M ring of intermediate rows in LDS, both
 // as two fp16 planes; a workgroup marches down a 60-column strip of one image; the intermediate image never reaches HBM),
 // but the two convolutions run CONCURRENTLY instead of in alternating phases:
-//   * wavefronts 0 .. C/16 - 1 (producers) hold conv1's weight fragments for 16 output channels each, stage the x rows
-//     (fetch, split, store) and, in step r, multiply intermediate row r + 1 for all 64 pixels of the strip;
+//   * wavefronts 0 .. C/16 - 1 (producers) hold conv1's weight fragments for 16 output channels each and, in step r,
+//     multiply intermediate row r + 1 for all 64 pixels of the strip, then split it and store its two planes in the M ring;
 //   * wavefronts C/16 .. 2 C/16 - 1 (consumers) hold conv2's fragments and, in the SAME step, multiply output row r - 1
-//     from intermediate rows r - 2, r - 1, r (one step behind the producers), add bias + residual, ReLU, store.
+//     from intermediate rows r - 2, r - 1, r (one step behind the producers), add bias + residual, ReLU, store — and stage
+//     the x rows for the producers (fetch x row r + 3 before their multiply phase, split + store it after): the staging
+//     registers fit the consumers' budget, the producers' epilogue (split of the intermediate row) is the heavier one.
 // One s_barrier per row step instead of two; each wavefront keeps ONE weight set in registers (72 C/32 instead of
 // 144 C/32), which is what makes C = 64 possible at all (stage 2: 18 k-blocks x 2 planes x 4 registers = 144); and while a
 // producer waits for its x row, the consumers' MFMAs keep the matrix pipe busy.

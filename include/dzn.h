@@ -29,7 +29,12 @@
  *
  * Threading: one handle per device; calls on one handle are not re-entrant.  Calls
  * only ENQUEUE work on the given HIP stream; the caller synchronises (matching the
- * reference's single-threaded, one-stream use).
+ * reference's single-threaded, one-stream use).  One exception, once per geometry: the
+ * FIRST forward at a new window length builds that length's index tables (relative-position
+ * bias table, positional-conv and ResNet row-offset tables) with synchronous uploads; every
+ * later call at that length enqueues only — dzn_segment_forward -> dzn_prepare_masks ->
+ * dzn_embed_forward can then be captured in a HIP graph and replayed (r4:
+ * tests/test_emb_gpu.py::test_forwards_only_enqueue_and_replay_from_a_hip_graph).
  */
 #ifndef DZN_H_
 #define DZN_H_

@@ -255,6 +255,39 @@ def test_trunk_skipped_for_windows_without_active_speaker(built_lib, gpu, monkey
     eng_dense.close()
 
 
+def test_trunk_subset_with_more_windows_than_one_scan_block(built_lib, gpu):
+    """compact_active_kernel builds the list of active windows with one 256-thread workgroup that scans the flags in
+    blocks of 256: B = 600 (the bench's launches hold 561) crosses two block boundaries.  Every third window is silent, plus
+    runs of silent windows around the boundaries (254 .. 258, 510 .. 513): the embeddings must be bit-identical to the dense
+    engine's, the silent windows must be the bias, and the counter must say how many were skipped."""
+    from oracle import emb_model
+    from oracle.gen_golden import synth_wave
+    B, N, L = 600, 8000, 24
+    eng = _engine(gpu, B, N, precision="f32h")
+    import os
+    os.environ["DZN_EMB_NO_SKIP"] = "1"
+    try:
+        dense_eng = _engine(gpu, B, N, precision="f32h")
+    finally:
+        os.environ.pop("DZN_EMB_NO_SKIP", None)
+    wave = synth_wave(8, N, 23).repeat(75, 1)[:B].contiguous()
+    wave = (wave * torch.linspace(0.5, 1.5, B)[:, None]).to(gpu)
+    r = np.random.default_rng(11)
+    masks = torch.from_numpy((r.random((B, 4, L)) < 0.5).astype(np.float32))
+    silent = sorted(set(range(0, B, 3)) | set(range(254, 259)) | set(range(510, 514)))
+    masks[silent] = 0.0
+    masks = masks.to(gpu)
+    emb = eng.embed(wave, masks)
+    dense = dense_eng.embed(wave, masks)
+    torch.cuda.synchronize()
+    assert torch.equal(emb, dense)
+    bias = emb_model.emb_state_dict(0)["resnet.seg_1.bias"].to(gpu)
+    assert torch.equal(emb[silent], bias.expand(len(silent), 4, -1))
+    assert eng.embed_skip_stats() == (B, len(silent))
+    eng.close()
+    dense_eng.close()
+
+
 def test_forwards_only_enqueue_and_replay_from_a_hip_graph(built_lib, gpu):
     """include/dzn.h: "calls only ENQUEUE work on the given HIP stream".  Once the per-geometry tables exist (first call),
     dzn_segment_forward -> dzn_prepare_masks -> dzn_embed_forward must be capturable in a HIP graph — a stream
