@@ -5,8 +5,8 @@
 // Why.  conv3x3_c32_split_kernel (conv_split.hip) runs the stage's six convolutions one launch each: 8.6 % of the
 // 30-min step at 162 TFLOP/s with `MfmaUtil` ~22 %.  It is bound by bytes, not by the matrix pipe: per launch it moves
 // 11.9 GB through the fabric (PMC, x2 correction calibrated in profiles/r4_fetch_size_calibration.txt) for 7.6 GB
-// algorithmic — every input row is fetched about twice for the 3-row halo of the flat 128-pixel tiles — at 4.4 TB/s,
-// and each CU's vector-memory path carries ~80 KB per 128 output pixels.  The intermediate image of a block (3.1 GB at
+// algorithmic — every input row is fetched about twice for the 3-row halo of the flat 128-pixel tiles — at 4.4 TB/s of a
+// ~6.2 TB/s HBM stream (scripts/ubench/lds_fill_rate.hip), ~80 KB per 128 output pixels.  The intermediate image of a block (3.1 GB at
 // 374 windows) is written by conv1 and read back — twice — by conv2, and conv2 re-reads x as its residual.
 //
 // Here a workgroup owns a COLUMN STRIP of one image and marches down its rows with two rolling line buffers in LDS:
