@@ -10,6 +10,7 @@
    group reads.
 """
 import numpy as np
+import pytest
 
 
 # ----------------------------------------------------------------------------- 1. split arithmetic
@@ -328,3 +329,71 @@ def test_linkage_algorithm_model_equals_scipy():
         assert np.array_equal(Z[:, [0, 1, 3]], Zs[:, [0, 1, 3]]), (n, K, BLK)
         assert np.abs(Z[:, 2] - Zs[:, 2]).max() < 1e-12
         assert rescans < 2 * n                          # stale bounds are the exception, not the rule
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (r4) Ring schedules of the fused BasicBlock kernels (csrc/resblock_fused.hip, csrc/resblock_ws.hip): a host model of
+# WHICH ring slot every phase reads and writes and WHERE the barriers sit, checked for (a) every read finds the row it
+# wants, (b) no slot is overwritten between a barrier-free pair of (read, write) by different wavefronts.
+def _run_intervals(intervals, X, M, x_slot, m_slot):
+    for iv in intervals:
+        reads = [(ring, row) for _, kind, ring, row in iv if kind == "r"]
+        writes = [(ring, row) for _, kind, ring, row in iv if kind == "w"]
+        for ring, row in reads:                       # (a) the wanted row is resident
+            store, sl = (X, x_slot(row)) if ring == "X" else (M, m_slot(row))
+            assert store.get(sl) == row, (ring, row, sl, store.get(sl))
+        for ring, row in writes:                      # (b) nothing read in this interval lives in the slot being written
+            sl = x_slot(row) if ring == "X" else m_slot(row)
+            for ring2, row2 in reads:
+                if ring2 == ring:
+                    sl2 = x_slot(row2) if ring == "X" else m_slot(row2)
+                    assert sl2 != sl, f"{ring} slot {sl}: row {row} written while row {row2} is read in the same interval"
+        for ring, row in writes:
+            (X if ring == "X" else M)[x_slot(row) if ring == "X" else m_slot(row)] = row
+
+
+@pytest.mark.parametrize("H", [1, 2, 3, 5, 40, 80])
+def test_resblock_fused_ring_schedule(H):
+    """resblock_fused.hip: X ring of 4 slots (row q at (q + 1) & 3), M ring of 3 slots (row m at (m + 1) % 3).  Step r, r = -1 .. H - 1:
+    [phase A reads x rows r, r + 1, r + 2] | barrier | [store intermediate row r + 1; store x row r + 3] | barrier |
+    [phase B reads intermediate rows r - 1, r, r + 1 (r >= 0)]."""
+    x_slot, m_slot = (lambda q: (q + 1) & 3), (lambda m: (m + 1) % 3)
+    X, M = {}, {}
+    _run_intervals([[("all", "w", "X", q) for q in (-1, 0, 1)] + [("all", "w", "M", -1)]], X, M, x_slot, m_slot)    # prologue
+    for r in range(-1, H):
+        ivs = []
+        a = [("all", "r", "X", q) for q in (r, r + 1, r + 2)] if r + 1 < H else []
+        ivs.append(a)
+        w = [("all", "w", "M", r + 1)]
+        if r + 3 <= H:
+            w.append(("all", "w", "X", r + 3))
+        ivs.append(w)
+        ivs.append([("all", "r", "M", m) for m in (r - 1, r, r + 1)] if r >= 0 else [])
+        # phase B of step r and phase A of step r + 1 are NOT separated by a barrier: merge them into one interval
+        _run_intervals(ivs[:2], X, M, x_slot, m_slot)
+        nxt = [("all", "r", "X", q) for q in (r + 1, r + 2, r + 3)] if (r + 1 < H and r + 2 < H) else []
+        _run_intervals([ivs[2] + nxt], X, M, x_slot, m_slot)
+
+
+@pytest.mark.parametrize("H", [1, 2, 3, 5, 40, 80])
+def test_resblock_ws_ring_schedule(H):
+    """resblock_ws.hip: both rings have 4 slots (row at (row + 1) & 3); ONE barrier per step; in step r (r = -1 .. H) the producers
+    read x rows r, r + 1, r + 2 and write intermediate row r + 1 (if r + 1 <= H) while — in the same interval — the consumers
+    read intermediate rows r - 2, r - 1, r for output row r - 1 (if 0 <= r - 1 < H) and write x row r + 3 (if r + 3 <= H)."""
+    sl = lambda q: (q + 1) & 3      # noqa: E731
+    X, M = {}, {}
+    _run_intervals([[("cons", "w", "X", q) for q in (-1, 0, 1)] + [("prod", "w", "M", -1)]], X, M, sl, sl)
+    outputs = []
+    for r in range(-1, H + 1):
+        iv = []
+        if r + 1 <= H:
+            if r + 1 < H:
+                iv += [("prod", "r", "X", q) for q in (r, r + 1, r + 2)]
+            iv.append(("prod", "w", "M", r + 1))
+        if r + 3 <= H:
+            iv.append(("cons", "w", "X", r + 3))
+        if 0 <= r - 1 < H:
+            iv += [("cons", "r", "M", m) for m in (r - 2, r - 1, r)]
+            outputs.append(r - 1)
+        _run_intervals([iv], X, M, sl, sl)
+    assert outputs == list(range(H))
