@@ -67,13 +67,7 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 // ABL != 0: ABLATION probes for scripts/bench_gemm_cfgs.py (wrong results on purpose; never launched by the engines):
 //   1 = no operand split (raw bits as fragments), 2 = no MFMAs, 3 = no steady-state LDS-DMA refills, 4 = no barrier,
 //   5 = no fragment reads after the first tile
-// SA (r4) > 0: the A tiles get their OWN ring of SA stages next to the S stages of the weight planes (SA = 0: one ring of S
-// combined stages, r1-r3).  profiles/r4_lds_fill_rate.txt: the pipeline reaches no bandwidth ceiling, it is short of bytes in
-// flight against the latency of the A rows that miss L2 (the weight planes are L2 hits).  With SA = 3, S = 2 a 128 x 128
-// workgroup holds 3 x 16 + 2 x 16 = 80 KB — two workgroups fill the CU's 160 KB exactly — and the A tile of K tile kt + 2 stays
-// in flight across the barrier of tile kt + 1: issue order per step is [W(kt + 2), A(kt + 3)], so the counted wait of the next
-// step, vmcnt(ACH), retires W(kt + 2) and A(kt + 2) and leaves only the youngest A tile outstanding.
-template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0, int SA = 0>
+template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0>
 __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const dzn_gemm_desc d) {
   constexpr int NW = WGM * WGN;           // wavefronts per workgroup
   constexpr int BK = 32;
@@ -85,8 +79,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   constexpr int WR = (BN + WROWS - 1) / WROWS;
   constexpr int SP = NP == 3 ? 3 : 2;     // planes STORED per weight row (NP = 1 reads the leading one of two)
   constexpr int ABYTES = BM * 128, WPLANE = BN * 64, BUF = ABYTES + NP * WPLANE;
-  constexpr int WBASE = SA * ABYTES;      // SA > 0: [SA stages of A][S stages of the NP weight planes]
-  constexpr int WSTG = NP * WPLANE;
   constexpr int LPT = ACH + NP * WR;      // LDS-DMA instructions per thread per tile (NP fewer for the
                                           // wavefronts that sit out a partial last W round)
   constexpr bool WPART = BN % WROWS != 0;
@@ -177,29 +169,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   // incrementally on the scalar unit
   int ik = 0, irem = 0;
   int64_t ikoff = 0;
-  int ikw = 0;                            // SA > 0: the W ring runs on its own k counter (it is one tile behind the A ring)
-  auto issue_a = [&](int stage) {         // SA > 0
-    unsigned char* sA = smem + stage * ABYTES + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < ACH; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[i] + ikoff),
-                                       (__attribute__((address_space(3))) void*)(sA + i * RB), 16, 0, 0);
-    irem += BK;
-    ikoff += BK;
-    if (irem == d.kc) { irem = 0; ikoff += d.ldk - d.kc; }
-  };
-  auto issue_w = [&](int stage) {         // SA > 0
-    unsigned char* sW = smem + WBASE + stage * WSTG + wave * 1024;
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-      for (int i = 0; i < WR; ++i)
-        if (i + 1 < WR || wfull)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(wptr[i] + SP * ikw + p * 32),
-              (__attribute__((address_space(3))) void*)(sW + p * WPLANE + i * RB), 16, 0, 0);
-    ikw += BK;
-  };
   auto issue = [&](int stage) {
     unsigned char* sA = smem + stage * BUF + wave * 1024;
     unsigned char* sW = smem + stage * BUF + ABYTES + wave * 1024;
@@ -233,7 +202,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int row = wn * TN + j * 16 + lr;
-    woff[j] = (SA > 0 ? 0 : ABYTES) + row * 64 + ((lq ^ wswz(row)) << 4);
+    woff[j] = ABYTES + row * 64 + ((lq ^ wswz(row)) << 4);
   }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -243,14 +212,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
     aoff1[i] = row * 128 + (((4 + lq) ^ sw) << 4);
   }
   auto read_w = [&](int stage, u32x4 (&wf)[NI][NP]) {
-    const unsigned char* base = SA > 0 ? smem + WBASE + stage * WSTG : smem + stage * BUF;
+    const unsigned char* base = smem + stage * BUF;
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int p = 0; p < NP; ++p) wf[j][p] = *reinterpret_cast<const u32x4*>(base + p * WPLANE + woff[j]);
   };
   auto read_a = [&](int stage, f32x4 (&ar)[MI][2]) {
-    const unsigned char* base = SA > 0 ? smem + stage * ABYTES : smem + stage * BUF;
+    const unsigned char* base = smem + stage * BUF;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       ar[i][0] = *reinterpret_cast<const f32x4*>(base + aoff0[i]);
@@ -298,38 +267,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   };
 
   const int nk = d.K / BK;
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    if (s < nk) issue(s);
   // wait until all but the `T` youngest tiles of this wavefront's LDS-DMA have landed
   auto wait_tiles = [&](auto tiles) {
     constexpr int T = decltype(tiles)::value;
     if (wfull) wait_vm_lgkm0<T * LPT>();
     else wait_vm_lgkm0<T * (LPT - NP)>();
   };
-  if constexpr (SA > 0) {
-    static_assert(SA == 3 && S == 2, "A ring of three, W ring of two");
-    // queue (oldest first): W0 A0 W1 A1 A2 — tile 0 is complete when only W1, A1, A2 are outstanding
-    issue_w(0);
-    issue_a(0);
-    if (nk > 1) {
-      issue_w(1);
-      issue_a(1);
-    }
-    if (nk > 2) issue_a(2);
-    if (nk > 2) {
-      if (wfull) wait_vm_lgkm0<NP * WR + 2 * ACH>();
-      else wait_vm_lgkm0<NP * (WR - 1) + 2 * ACH>();
-    } else if (nk > 1) {
-      if (wfull) wait_vm_lgkm0<NP * WR + ACH>();
-      else wait_vm_lgkm0<NP * (WR - 1) + ACH>();
-    } else {
-      wait_vm_lgkm0<0>();
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-      if (s < nk) issue(s);
-    if (nk >= S) wait_tiles(std::integral_constant<int, S - 1>{});
-    else wait_vm_lgkm0<0>();
-  }
+  if (nk >= S) wait_tiles(std::integral_constant<int, S - 1>{});
+  else wait_vm_lgkm0<0>();
   __builtin_amdgcn_s_barrier();
   u32x4 wfa[NI][NP], wfb[NI][NP];
   f32x4 ar[MI][2];
@@ -337,7 +285,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   read_a(0, ar);
   if constexpr (ABL == 5) read_w(0, wfb);
   int stage = 0;
-  int astage = 0;                          // SA > 0: A stage of tile kt (kt % SA); `stage` is the W stage (kt % S)
 
   // one K tile: `wc` holds its W fragments, `ar` its raw A fragments; leaves tile kt+1 in (wn_, ar)
   auto step = [&](int kt, const u32x4 (&wc)[NI][NP], u32x4 (&wn_)[NI][NP]) {
@@ -352,36 +299,23 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
 #pragma unroll
     for (int i = MH; i < MI; ++i) split(ar[i], af2[i - MH], a_scale[i], a_mean[i]);
     const int nstage = stage + 1 == S ? 0 : stage + 1;
-    const int nastage = SA > 0 ? (astage + 1 == SA ? 0 : astage + 1) : 0;
     __builtin_amdgcn_sched_barrier(0);  // keep the second half of the MFMAs BEHIND the barrier block
     if (more) {
-      if constexpr (SA > 0) {
-        // W(kt+1) and A(kt+1) landed; A(kt+2) — the youngest ACH loads — may stay in flight; all my reads of tile kt retired
-        if (kt + 2 < nk) wait_vm_lgkm0<ACH>();
-        else wait_vm_lgkm0<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue_w(stage);      // W(kt+2) into tile kt's W stage, BEFORE A(kt+3): the next wait counts on that order
-        if (kt + 3 < nk) issue_a(astage);     // A(kt+3) into tile kt's A stage
+      // tile kt+1 landed (tiles kt+2 .. kt+S-1 may stay in flight); all my reads of tile kt retired
+      if (kt + S <= nk) wait_tiles(std::integral_constant<int, S - 2>{});
+      else wait_vm_lgkm0<0>();
+      if constexpr (ABL != 4) __builtin_amdgcn_s_barrier();
+      if constexpr (ABL != 3)
+        if (kt + S < nk) issue(stage);  // every wave is past its reads of tile kt
+      if constexpr (ABL != 5) {
         read_w(nstage, wn_);
-        read_a(nastage, ar);
-      } else {
-        // tile kt+1 landed (tiles kt+2 .. kt+S-1 may stay in flight); all my reads of tile kt retired
-        if (kt + S <= nk) wait_tiles(std::integral_constant<int, S - 2>{});
-        else wait_vm_lgkm0<0>();
-        if constexpr (ABL != 4) __builtin_amdgcn_s_barrier();
-        if constexpr (ABL != 3)
-          if (kt + S < nk) issue(stage);  // every wave is past its reads of tile kt
-        if constexpr (ABL != 5) {
-          read_w(nstage, wn_);
-          read_a(nstage, ar);
-        }
+        read_a(nstage, ar);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = MH; i < MI; ++i) mma(i, wc, af2[i - MH]);
     stage = nstage;
-    astage = nastage;
   };
   for (int kt = 0; kt < nk; kt += 2) {
     step(kt, wfa, wfb);
@@ -677,11 +611,11 @@ int launch_split32_cfg(const dzn_gemm_desc& d, hipStream_t s) {
 
 #endif  // DZN_TUNING (32x32x16 probe)
 
-template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0, int SA = 0>
+template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0>
 int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-  const size_t lds = SA > 0 ? (size_t)SA * BM * 128 + (size_t)S * NP * BN * 64 : (size_t)S * (BM * 128 + NP * BN * 64);
-  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, NP, OCC, ABL, SA>;
+  const size_t lds = (size_t)S * (BM * 128 + NP * BN * 64);
+  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, NP, OCC, ABL>;
   static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
   if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -758,8 +692,8 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     if constexpr (NP == 1) {
       if (!strcmp(force, "256x128w8s3")) return launch_split_cfg<256, 128, 8, 1, 3, NP, 2>(d, s);
     }
-    if constexpr (NP == 2) {   // (r4) separate A ring of three stages
-      if (!strcmp(force, "128x128a3")) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2, 0, 3>(d, s);
+    if constexpr (NP == 2) {
+      if (!strcmp(force, "persist") && d.K >= 64) return launch_gemm_persist(d, s);
     }
 #ifdef DZN_TUNING
     if constexpr (NP <= 2) {    // (r4) 32x32x16 MFMA forms
@@ -833,8 +767,8 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
 #ifdef DZN_TUNING
     if (m32 & 1) return launch_split32_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);
 #endif
-    static const bool a3 = getenv("DZN_GEMM_A3") != nullptr;
-    if (a3) return launch_split_cfg<128, 128, 4, 1, 2, NP, 2, 0, 3>(d, s);
+    static const bool persist = getenv("DZN_GEMM_PERSIST") != nullptr;
+    if (persist) return launch_gemm_persist(d, s);
     return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);   // held to 2 wavefronts per SIMD
   }
   return launch_split_cfg<128, 128, 2, 2, 2, NP, 2>(d, s);
