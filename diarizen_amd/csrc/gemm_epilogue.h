@@ -180,7 +180,7 @@ __device__ __forceinline__ float apply_act_c(float v) {
 //   * out-of-range rows / columns load from clamped (valid) addresses and only their STORES are predicated: no control
 //     flow between the loads; the activation is a template argument (one switch per wavefront).
 // Needs 4-element alignment of N and every stride (else the general form).
-template <int BM, int BN, int TM, int TN, int MI, int NI, bool LDSCOLS = false, int RS = 16, int CS = 16, int JCM = 0>
+template <int BM, int BN, int TM, int TN, int MI, int NI, bool LDSCOLS = false, int RS = 16, int CS = 16>
 __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
                                               int wm, int wn, int lr, int lq, int64_t cz, int64_t bz, int z0 = 0,
                                               const float* row_inv = nullptr, const float* col_scale = nullptr,
@@ -191,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     return;
   }
   // column blocks per batch: 4 keeps acc + two residual batches + the hoisted column-vector reads inside 256 registers
-  constexpr int JCMAX = JCM > 0 ? JCM : MI * NI > 16 ? 4 : 8;          // wide tiles: 128 accumulator registers leave room for 2 x 4 float4s
+  constexpr int JCMAX = MI * NI > 16 ? 4 : 8;          // wide tiles: 128 accumulator registers leave room for 2 x 4 float4s
   constexpr int JC = epi_chunk(NI, JCMAX);
   static_assert(NI % JC == 0, "column chunks tile the wavefront tile");
   constexpr int NJC = NI / JC, NB = MI * NJC;            // batch b = (row block b / NJC, column chunk b % NJC)
