@@ -120,7 +120,6 @@ int launch_gemm(const dzn_gemm_desc& d, hipStream_t s);
 int launch_gemm_lowp(const dzn_gemm_desc& d, hipStream_t s);  // gemm_lowp.hip: A and W both bf16 (bf16 engine mode: DZN_TUNING builds only)
 #endif
 int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s); // gemm_split.hip: fp32 via 3-way bf16 split
-int launch_gemm_wide(const dzn_gemm_desc& d, hipStream_t s);  // gemm_wide.hip (r4): f32h on 256 x 256 tiles, one wavefront per SIMD
 int launch_gemm_split_pre(const dzn_gemm_desc& d, hipStream_t s);  // gemm_split_pre.hip: A pre-split planes
 int launch_pad_rows_split3(const float* x, void* planes, int64_t plane_stride, int B, int L, int Lp, int pad, int D,
                            hipStream_t st, int cg = 0, int cgp = 0);   // D = plane row width (groups padded from cg to cgp channels)

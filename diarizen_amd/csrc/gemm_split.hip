@@ -692,9 +692,6 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     if constexpr (NP == 1) {
       if (!strcmp(force, "256x128w8s3")) return launch_split_cfg<256, 128, 8, 1, 3, NP, 2>(d, s);
     }
-    if constexpr (NP == 2) {
-      if (!strcmp(force, "wide") && !d.a_rowoff) return launch_gemm_wide(d, s);
-    }
 #ifdef DZN_TUNING
     if constexpr (NP <= 2) {    // (r4) 32x32x16 MFMA forms
       if (!strcmp(force, "m32_128x128")) return launch_split32_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);
@@ -727,9 +724,10 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
   }
   // (r3's 8-wavefront ping-pong forms — gemm_pp.hip, 256 x 192 tiles — measured +0.5 % on the step and were removed in r4;
   // the A/B record is profiles/r3_gemm_pq_probe.txt, the source is in the history at 7bb9ad7)
-  // (r4, both bit-identical, both measured negatives, sources in the history: a separate three-stage A ring — aea83fd,
+  // (r4, all bit-identical, all measured neutral or negative, sources in the history: a separate three-stage A ring — aea83fd,
   // profiles/r4_gemm_a3_probe.txt; persistent workgroups with the next tile's prologue fill under the epilogue — 6ff2eda,
-  // profiles/r4_gemm_persist_probe.txt)
+  // profiles/r4_gemm_persist_probe.txt; 256 x 256 tiles at one wavefront per SIMD — e863011, profiles/r4_gemm_wide_probe.txt,
+  // whose PMC pass shows clock x matrix-pipe-busy constant across both forms: the K loop sits on a power-limited MFMA rate)
 #ifdef DZN_TUNING
   // (r4) DZN_GEMM_M32 (read once): bit 0 = the 128 x 128 class, bit 1 = the 128 x 64 class run on 32x32x16 MFMA blocks
   static const int m32 = getenv("DZN_GEMM_M32") ? atoi(getenv("DZN_GEMM_M32")) : 0;
@@ -770,8 +768,6 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
 #ifdef DZN_TUNING
     if (m32 & 1) return launch_split32_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);
 #endif
-    static const bool wide = getenv("DZN_GEMM_WIDE") != nullptr;
-    if (wide && !d.a_rowoff) return launch_gemm_wide(d, s);
     return launch_split_cfg<128, 128, 4, 1, 2, NP, 2>(d, s);   // held to 2 wavefronts per SIMD
   }
   return launch_split_cfg<128, 128, 2, 2, 2, NP, 2>(d, s);
