@@ -159,6 +159,9 @@ constexpr int epi_chunk(int ni, int cap) {
 // (r4) Write-through (`sc1`) stores for C and the layer-weighted sum — so that the outputs, which nothing re-reads before
 // they have left the 4 MB L2, stop evicting the operand tiles — were built and measured: step 1063-1065 ms against
 // 1053-1055 ms with plain stores (gpurun r4j, DZN_GEMM_WT probe; profiles/r4_gemm_wt_probe.txt).  Plain stores stay.
+// Likewise NON-TEMPORAL loads of the residual / layer-weighted sum and non-temporal stores of C / WS (`__builtin_nontemporal_*`,
+// the `nt` cache policy): step 1076 ms against 1053-1057, both contraction classes 3-4 % slower (profiles/r4_epilogue_nt_probe.txt)
+// — the next kernel re-reads C, and what it finds in the Infinity Cache today it then fetches from HBM.
 template <int ACT>
 __device__ __forceinline__ float apply_act_c(float v) {
   if constexpr (ACT == DZN_ACT_GELU) return gelu_erf(v);
