@@ -167,6 +167,15 @@ int64_t gn_stats_floats(int B, int T, int C, int Cp);   // size of launch_groupn
 int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int Lp, int pad, int D,
                     hipStream_t st);
 int launch_ws_accum(const float* x, float* ws, float w, int init, int64_t n, hipStream_t st);
+// ws = ((0 + w[0] x[0]) + w[1] x[1]) + ... in that order, element-wise over n floats: the layer-weighted sum in ONE pass over
+// the per-layer buffers (the same additions, in the same order, as n ws_accum / epilogue read-modify-writes)
+constexpr int WS_SUM_MAX = 40;
+struct WsSumArgs {
+  const float* x[WS_SUM_MAX];
+  float w[WS_SUM_MAX];
+  int n;
+};
+int launch_ws_sum(const WsSumArgs& a, float* ws, int64_t n, hipStream_t st);
 int launch_col_scale(void* x, int x_bf16, int64_t rows, int C, int64_t ld, const float* scale,
                      hipStream_t st);
 // frontend_fused.hip (DZN_PREC_F32_H2): conv0 + LN + GELU + conv1 in one kernel

@@ -158,6 +158,11 @@ struct dzn_handle {
   float *x = nullptr, *xpad = nullptr, *y = nullptr, *ws = nullptr, *qkv = nullptr, *ao = nullptr,
         *gate = nullptr, *mid = nullptr;
   float *hz = nullptr, *ht = nullptr, *hmid = nullptr, *hv = nullptr;
+  // (r4) pre-norm encoders: every layer writes its output rows into ITS OWN buffer (xl + layer * rows * D) and the
+  // layer-weighted sum (model_wavlm_conformer.py:236,253-254) is ONE pass over those buffers after the last layer, instead of
+  // a read-modify-write of `ws` in every FFN-output epilogue: 25 reads + 1 write of [rows, D] where there were 25 reads and
+  // 25 writes.  nullptr: the fused read-modify-write (post-norm encoders, DZN_NO_WS_DEFER, not enough free memory).
+  float* xl = nullptr;
   float* spart = nullptr;   // [max_batch * maxL][32][2] per-row partial sums left by a producing epilogue (stat_partial)
   float* rstat = nullptr;   // [max_batch * maxL][2] (mean, rstd) of the LayerNorm folded into the next contraction
   // |max| trackers of activation tensors (DZN_PREC_F32_H2), ONE PER WINDOW of the batch (slot * max_batch + b): written
@@ -722,6 +727,13 @@ void finalize_seg(H* h) {
   }
   h->y = dalloc<float>(h, ML * D);
   h->ws = dalloc<float>(h, ML * D);
+  if (c.layer_norm_first && h->fold_ln && c.n_layers > 0 && c.n_layers < WS_SUM_MAX && !getenv("DZN_NO_WS_DEFER")) {
+    size_t free_b = 0, total_b = 0;
+    const int64_t need = (int64_t)c.n_layers * ML * D * (int64_t)sizeof(float);
+    // taken only when it leaves more than half of what is free now to everything allocated after it
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < (int64_t)(free_b / 2))
+      h->xl = dalloc<float>(h, (int64_t)c.n_layers * ML * D, false);
+  }
   h->qkv = dalloc<float>(h, ML * 3 * maxQ);
   h->ao = dalloc<float>(h, ML * maxQ);
   h->gate = dalloc<float>(h, ML * h->H);
@@ -1204,7 +1216,18 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     gemm(d, pc16, false, "pos conv");
   }
   if (!c.layer_norm_first) ln_t(h->x, false, D, h->x, false, D, h->enc_ln, ML, D, 0, st, nullptr, am(dzn_handle::AM_X), L);
-  chk(launch_ws_accum(h->x, h->ws, h->wsum_w[0], 1, ML * D, st), "ws_accum");
+  // the residual stream: `xr` = rows of the representation the next operation reads.  With the deferred layer-weighted sum
+  // every layer moves it into its own buffer (the first residual update of layer i reads xr and writes xl[i], the second
+  // one works in place there) and (xr, weight) is noted per layer; else xr == h->x throughout.
+  const bool defer = h->xl != nullptr;
+  float* xr = h->x;
+  WsSumArgs wsum{};
+  if (defer) {
+    wsum.x[wsum.n] = xr;
+    wsum.w[wsum.n++] = h->wsum_w[0];
+  } else {
+    chk(launch_ws_accum(h->x, h->ws, h->wsum_w[0], 1, ML * D, st), "ws_accum");
+  }
   tap(h, "rep0", h->x, ML, D, D, st);
 
   // ---- transformer layers (components.py:920-942) ----
@@ -1213,22 +1236,23 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
   for (int i = 0; i < c.n_layers; ++i) {
     EncLayer& Ly = h->layers[i];
     const float wl = h->wsum_w[i + 1];
+    float* const own = defer ? h->xl + (int64_t)i * ML * D : xr;   // where this layer's output rows live
     bool have_stats = false;   // LN2's statistics already left in rstat by the out_proj epilogue
     if (Ly.attn) {
-      const float* yin = h->x;
+      const float* yin = xr;
       bool y16 = false;
       const bool fold1 = fold && c.layer_norm_first;
       if (fold1) {
         // one pass over x: LN statistics for the folded q/k/v contraction + the gate on LN(x) (never written)
-        chk(launch_gate_stats(h->x, D, Ly.ln1.g, Ly.ln1.b, Ly.Wg, Ly.bg, Ly.cst, h->gate, h->rstat, ML, h->H, 1e-5f,
+        chk(launch_gate_stats(xr, D, Ly.ln1.g, Ly.ln1.b, Ly.Wg, Ly.bg, Ly.cst, h->gate, h->rstat, ML, h->H, 1e-5f,
                               st),
             "gate_stats");
       } else if (c.layer_norm_first) {
-        ln_t(h->x, false, D, h->y, lp, D, Ly.ln1, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y), L);
+        ln_t(xr, false, D, h->y, lp, D, Ly.ln1, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y), L);
         yin = h->y;
         y16 = lp;
       } else if (lp) {
-        chk(launch_cast_bf16(h->x, h->y, ML * D, st), "cast");
+        chk(launch_cast_bf16(xr, h->y, ML * D, st), "cast");
         yin = h->y;
         y16 = true;
       }
@@ -1236,7 +1260,7 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       const int hd = Ly.h * 64;
       dzn_gemm_desc d = gd(h, yin, Ly.qkv, h->qkv, ML, D, 3 * hd);
       if (fold1) folded(d, Ly.qkv);
-      d.a_amax = am(yin == h->x ? dzn_handle::AM_X : dzn_handle::AM_Y);
+      d.a_amax = am(yin == xr ? dzn_handle::AM_X : dzn_handle::AM_Y);
       d.c_amax = am(dzn_handle::AM_QKV);
       gemm(d, y16, false, "qkv");
       if (prec_is_split(c.precision))
@@ -1247,8 +1271,8 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
         chk(launch_attention_t(h->qkv, h->ao, lp, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd,
                                hd, 0.125f, st),
             "attention");
-      dzn_gemm_desc o = gd(h, h->ao, Ly.out, h->x, ML, hd, D);
-      o.R = h->x;
+      dzn_gemm_desc o = gd(h, h->ao, Ly.out, own, ML, hd, D);
+      o.R = xr;
       o.a_amax = am(dzn_handle::AM_QKV);   // rows of ao are convex combinations of v rows: |ao| <= max |qkv|
       o.c_amax = am(dzn_handle::AM_X);
       if (fold && c.layer_norm_first && Ly.ffn && stats_from_epilogue) {
@@ -1260,39 +1284,47 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
         have_stats = true;
       }
       gemm(o, lp, false, "out_proj");
+      xr = own;
     }
     if (c.layer_norm_first) {
       if (Ly.ffn) {
         const float* fin = h->y;
         if (fold) {
-          if (!have_stats) chk(launch_row_stats(h->x, D, ML, D, 1e-5f, h->rstat, st), "row_stats");
-          fin = h->x;
+          if (!have_stats) chk(launch_row_stats(xr, D, ML, D, 1e-5f, h->rstat, st), "row_stats");
+          fin = xr;
         } else {
-          ln_t(h->x, false, D, h->y, lp, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y), L);
+          ln_t(xr, false, D, h->y, lp, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_Y), L);
         }
         dzn_gemm_desc f1 = gd(h, fin, Ly.f1, h->mid, ML, D, Ly.Fp);
         if (fold) folded(f1, Ly.f1);
         f1.act = DZN_ACT_GELU;
-        f1.a_amax = am(fin == h->x ? dzn_handle::AM_X : dzn_handle::AM_Y);
+        f1.a_amax = am(fin == xr ? dzn_handle::AM_X : dzn_handle::AM_Y);
         f1.c_amax = am(dzn_handle::AM_MID);
         gemm(f1, lp, lp, "ffn1");
-        dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, h->x, ML, Ly.Fp, D);
-        f2.R = h->x;
-        f2.WS = h->ws;
-        f2.ldws = D;
-        f2.ws_w = wl;
+        dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, own, ML, Ly.Fp, D);
+        f2.R = xr;
+        if (!defer) {
+          f2.WS = h->ws;
+          f2.ldws = D;
+          f2.ws_w = wl;
+        }
         f2.a_amax = am(dzn_handle::AM_MID);
         f2.c_amax = am(dzn_handle::AM_X);
         gemm(f2, lp, false, "ffn2");
-      } else {
-        chk(launch_ws_accum(h->x, h->ws, wl, 0, ML * D, st), "ws_accum");
+        xr = own;
+      } else if (!defer) {
+        chk(launch_ws_accum(xr, h->ws, wl, 0, ML * D, st), "ws_accum");
+      }
+      if (defer) {   // a layer pruned to nothing leaves xr where it was: the same rows enter the sum again with this weight
+        wsum.x[wsum.n] = xr;
+        wsum.w[wsum.n++] = wl;
       }
     } else {
-      ln_t(h->x, false, D, h->x, false, D, Ly.ln1, ML, D, 0, st, nullptr, am(dzn_handle::AM_X), L);
+      ln_t(xr, false, D, xr, false, D, Ly.ln1, ML, D, 0, st, nullptr, am(dzn_handle::AM_X), L);
       if (Ly.ffn) {
-        const float* fin = h->x;
+        const float* fin = xr;
         if (lp) {
-          chk(launch_cast_bf16(h->x, h->y, ML * D, st), "cast");
+          chk(launch_cast_bf16(xr, h->y, ML * D, st), "cast");
           fin = h->y;
         }
         dzn_gemm_desc f1 = gd(h, fin, Ly.f1, h->mid, ML, D, Ly.Fp);
@@ -1300,20 +1332,21 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
         f1.a_amax = am(dzn_handle::AM_X);
         f1.c_amax = am(dzn_handle::AM_MID);
         gemm(f1, lp, lp, "ffn1");
-        dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, h->x, ML, Ly.Fp, D);
-        f2.R = h->x;
+        dzn_gemm_desc f2 = gd(h, h->mid, Ly.f2, xr, ML, Ly.Fp, D);
+        f2.R = xr;
         f2.a_amax = am(dzn_handle::AM_MID);
         f2.c_amax = am(dzn_handle::AM_X);
         gemm(f2, lp, false, "ffn2");
       }
-      ln_t(h->x, false, D, h->x, false, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_X), L);
-      chk(launch_ws_accum(h->x, h->ws, wl, 0, ML * D, st), "ws_accum");
+      ln_t(xr, false, D, xr, false, D, Ly.ln2, ML, D, 0, st, nullptr, am(dzn_handle::AM_X), L);
+      chk(launch_ws_accum(xr, h->ws, wl, 0, ML * D, st), "ws_accum");
     }
     if (h->debug) {
       const std::string nm = "layer" + std::to_string(i);
-      tap(h, nm.c_str(), h->x, ML, D, D, st);
+      tap(h, nm.c_str(), xr, ML, D, D, st);
     }
   }
+  if (defer) chk(launch_ws_sum(wsum, h->ws, ML * D, st), "ws_sum");
   tap(h, "wsum", h->ws, ML, D, D, st);
 
   // ---- head: proj + LN, Conformer x conf_layers, classifier (model_wavlm_conformer.py:256-262) ----

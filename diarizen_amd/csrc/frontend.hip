@@ -284,6 +284,32 @@ __global__ __launch_bounds__(256) void ws_accum_kernel(const float* __restrict__
   }
 }
 
+// ws = sum_k w[k] x[k] with the additions in list order, starting from 0 (bit-identical to ws_accum(init) followed by
+// ws_accum / epilogue read-modify-writes in the same order; -ffp-contract=off: multiply, then add)
+__global__ __launch_bounds__(256) void ws_sum_kernel(const WsSumArgs a, float* __restrict__ ws, int64_t n4) {
+  float4* wd = reinterpret_cast<float4*>(ws);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= a.n; k += 4) {      // four independent loads in flight per thread
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4*>(a.x[k + u])[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float w = a.w[k + u];
+        acc.x += w * v[u].x; acc.y += w * v[u].y; acc.z += w * v[u].z; acc.w += w * v[u].w;
+      }
+    }
+    for (; k < a.n; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(a.x[k])[i];
+      const float w = a.w[k];
+      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    }
+    wd[i] = acc;
+  }
+}
+
 // x[r, c] *= scale[c]  (dummy_weight, components.py:208), columns >= C untouched
 template <typename T>
 __global__ __launch_bounds__(256) void col_scale_kernel(T* __restrict__ x, int64_t rows, int C,
@@ -382,6 +408,13 @@ int launch_pad_rows(const float* x, void* xpad, int out_bf16, int B, int L, int 
 int launch_ws_accum(const float* x, float* ws, float w, int init, int64_t n, hipStream_t st) {
   ProfScope prof_scope_(st, "ws_accum", 0.0, (double)n * (init ? 8.0 : 12.0));
   hipLaunchKernelGGL(ws_accum_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, ws, w, init, n / 4);
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+int launch_ws_sum(const WsSumArgs& a, float* ws, int64_t n, hipStream_t st) {
+  if (a.n <= 0 || a.n > WS_SUM_MAX || (n & 3)) return DZN_E_INVALID;
+  ProfScope prof_scope_(st, "ws_sum", 0.0, (double)n * 4.0 * (a.n + 1));
+  hipLaunchKernelGGL(ws_sum_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, a, ws, n / 4);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 

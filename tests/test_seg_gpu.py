@@ -397,3 +397,32 @@ def test_conv0_layernorm_statistics_survive_band_pass_taps_on_low_frequency_audi
     print(f"max |dlogp| vs oracle: factored quadratic form {dq:.2e}, two-pass {dt:.2e}")
     assert dq <= 1e-3 and dt <= 1e-3
     assert dq <= 3.0 * dt + 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32h", "f32"])
+def test_deferred_layer_weighted_sum_gives_the_same_bits(built_lib, gpu, monkeypatch, precision):
+    """(r4) pre-norm encoders keep every layer's output rows in the layer's own buffer and form the layer-weighted sum
+    (model_wavlm_conformer.py:236,253-254) in ONE pass after the last layer (frontend.hip:ws_sum_kernel), instead of a
+    read-modify-write of the sum in every FFN-output epilogue.  Same additions in the same order: the log-probabilities must be
+    the bits of the engine with DZN_NO_WS_DEFER=1 (read at dzn_create) — on the pruned large model (layers without attention /
+    without FFN) and on a dense tiny one, ragged batch included."""
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from testkit.weights import turn_taking_state_dict
+    from oracle.gen_golden import tt_windows
+    for name, N in (("wavlm_large_s80_md", 40000), ("tiny_ln", 16000)):
+        cfg = get_seg_config(name)
+        sd = turn_taking_state_dict(cfg, 0)
+        wave = tt_windows([0, 100000, 250000], N).to(gpu)
+        deferred = Engine(cfg, sd, max_batch=3, max_samples=N, precision=precision, device=gpu)
+        monkeypatch.setenv("DZN_NO_WS_DEFER", "1")
+        fused = Engine(cfg, sd, max_batch=3, max_samples=N, precision=precision, device=gpu)
+        monkeypatch.delenv("DZN_NO_WS_DEFER")
+        for w in (wave, wave[:2, : N - 4321].contiguous()):
+            a, ma = deferred.segment(w)
+            b, mb = fused.segment(w)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b) and torch.equal(ma, mb), (name, (a - b).abs().max().item())
+        deferred.close()
+        fused.close()
