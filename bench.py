@@ -55,7 +55,7 @@ DTYPE_NOTE = {"f32": "f32 (fp32 MFMA v_mfma_f32_16x16x4_f32)",
                      "data, norms, softmax, residual stream fp32"}
 PEAK_HBM_GBS = 8000.0
 TRAFFIC_SOURCE = ("committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x 2 "
-                  "correction; scripts/final_measure_r4.sh -> profiles/) — not measured in this run")
+                  "correction; scripts/final_measure_r4.sh, final_measure_r4b.sh -> profiles/) — not measured in this run")
 # what holds the results of this path to the reference's (tests/ -m gpu, all through the C ABI; fixtures made by
 # oracle/gen_golden.py from the reference's own code)
 PARITY_NOTE = {
