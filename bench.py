@@ -105,6 +105,63 @@ PMC_SYMBOLS = {"conv0_ln_gelu": "conv0_kernel", "conv01_fused": "conv01_fused_ke
                "resblock32_ws_f32h": "resblock_ws_kernel<32>"}
 
 
+class PowerSampler:
+    """Board power and shader clock DURING the timed steps (rank 0, best effort): `rocm-smi --showpower --showclocks
+    --showmaxpower --csv` polled from a thread.  The dominant contraction runs with the package at its power cap
+    (profiles/r4_power_cap.txt, DESIGN.md 4.5) — this puts that evidence into the line the driver records.  Never raises;
+    `result()` is None when rocm-smi is missing or answers nothing."""
+
+    def __init__(self, period_s: float = 0.35, max_samples: int = 12):
+        import threading
+        self.period, self.max = period_s, max_samples
+        self.samples, self.cap = [], None
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _poll(self):
+        import subprocess
+        try:
+            out = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks", "--showmaxpower", "--csv"],
+                                 capture_output=True, text=True, timeout=15).stdout
+            rows = [ln.split(",") for ln in out.splitlines() if ln.strip()]
+            hdr = next(r for r in rows if r[0] == "device")
+            row = next(r for r in rows if r[0].startswith("card"))     # card0: the one device this process runs on
+            col = {h.strip(): v for h, v in zip(hdr, row)}
+            watts = float(next(v for h, v in col.items() if h.startswith("Current Socket Graphics Package Power")))
+            sclk = next((v for h, v in col.items() if h.startswith("sclk clock speed")), "")
+            mhz = int("".join(ch for ch in sclk if ch.isdigit()) or 0)
+            cap = next((v for h, v in col.items() if h.startswith("Max Graphics Package Power")), None)
+            if cap is not None:
+                self.cap = float(cap)
+            self.samples.append((watts, mhz))
+        except Exception:      # noqa: BLE001 — evidence, not a dependency
+            pass
+
+    def _run(self):
+        while not self._stop.is_set() and len(self.samples) < self.max:
+            self._poll()
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._th.start()
+
+    def stop(self):
+        self._stop.set()
+        self._th.join(timeout=20)
+
+    def result(self):
+        if not self.samples:
+            return None
+        w = [s[0] for s in self.samples]
+        f = [s[1] for s in self.samples if s[1] > 0]
+        return {"package_w": {"mean": round(sum(w) / len(w), 1), "max": round(max(w), 1)}, "cap_w": self.cap,
+                "sclk_mhz": {"mean": round(sum(f) / len(f)) if f else None, "min": min(f) if f else None},
+                "samples": len(w),
+                "source": "rocm-smi polled from a thread while the timed steps ran (whole pipeline: every kernel, not only the "
+                          "contraction; back to back the contraction alone holds 1400 W of 1400 W at 1.84-1.92 GHz, "
+                          "profiles/r4_power_cap.txt)"}
+
+
 def pmc_table(args):
     """HBM bytes per launch / MfmaUtil per kernel from the committed rocprofv3 --pmc passes of this same command
     (separate passes per counter, gfx950 FETCH_SIZE correction: scripts/pmc_traffic.py, scripts/pmc_mfma.py).
@@ -490,6 +547,7 @@ def main():
                          "slice + one window of halo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi (package power, sclk) during the timed steps")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra steps in the other fp32 modes")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (device + host AHC) leg")
     ap.add_argument("--e2e-steps", type=int, default=3, help="timed passes of the end-to-end leg (upload + device + host AHC)")
@@ -624,11 +682,16 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    power = PowerSampler() if rank == 0 and not args.no_power else None
+    if power:
+        power.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0           # this rank's own K steps (before it waits for the others)
+    if power:
+        power.stop()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -754,6 +817,7 @@ def main():
             "windows_per_s": round((1 if strong else world) * n_windows * args.steps / dt, 1),
             "unprofiled_ms_per_step": round(unprofiled_ms, 2),
             "roofline": roofline,
+            "power": power.result() if power else None,
             "roofline_extra": extra,
             "parity": PARITY_NOTE,
             "kernels": kernels,
