@@ -531,7 +531,7 @@ def main():
     ap.add_argument("--window", type=float, default=8.0)
     ap.add_argument("--batch", type=int, default=576,
                     help="maximum windows per launch (the runner balances: 2241 windows -> 4 launches of 561; r4 sweep on one box: "
-                         "384 / 576 / 768 / 1152 -> 1062 / 1043 / 1042 / 1036 ms per step; 576 keeps two handles of 68 GB each "
+                         "384 / 576 / 768 / 1152 -> 1062 / 1043 / 1042 / 1036 ms per step; 576 keeps two handles of 68 GB each (91 GB with the per-layer buffers of the deferred layer-weighted sum) "
                          "and an even number of launches for the two-stream pipeline)")
     ap.add_argument("--streams", type=int, default=1,
                     help="engine handles / HIP streams that consecutive batches of a step alternate over (WindowRunner "

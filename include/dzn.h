@@ -134,7 +134,13 @@ typedef struct dzn_config {
 
 typedef struct dzn_handle dzn_handle;
 
-/* Create an engine on the current HIP device. */
+/* Create an engine on the current HIP device.
+ * Workspace (allocated when the weights are finalised, sized for max_batch windows of max_samples): besides the activation
+ * buffers, pre-norm (layer_norm_first) encoders in the fp32 modes take n_layers further [max_batch * frames, D] fp32 buffers —
+ * every layer's output rows stay in the layer's own buffer and the layer-weighted sum (model_wavlm_conformer.py:236,253-254)
+ * is one pass over them after the last layer instead of a read-modify-write per layer (same additions, same order, same bits;
+ * 22.6 GB at 576 windows of 8 s for wavlm-large).  They are taken only while they fit in half of the free device memory;
+ * DZN_NO_WS_DEFER in the environment at that time keeps the per-layer read-modify-write. */
 int dzn_create(const dzn_config* cfg, dzn_handle** out);
 
 /*
