@@ -77,3 +77,31 @@ def test_no_gpu_is_a_loud_failure():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "HIP device" in r.stderr
+
+
+def test_power_sampler_reads_the_rocm_smi_csv(monkeypatch):
+    """bench.py's `power` object: package power / cap / sclk parsed from `rocm-smi --showpower --showclocks --showmaxpower --csv`
+    (the layout recorded on the MI355X box in profiles/r4_power_cap.txt); a missing or silent rocm-smi yields None, never an error."""
+    import subprocess
+    import bench
+    line = next(ln for ln in (ROOT / "profiles" / "r4_power_cap.txt").read_text().splitlines() if ln.startswith("[f32h K1024 random] device"))
+    csv_text = line.split("] ", 1)[1].replace(" | ", "\n")
+
+    class Done:
+        stdout = csv_text
+
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: Done)
+    ps = bench.PowerSampler()
+    ps._poll()
+    ps._poll()
+    res = ps.result()
+    assert res["cap_w"] == 1400.0 and res["package_w"] == {"mean": 1400.0, "max": 1400.0}
+    assert res["sclk_mhz"]["min"] == 1920 and res["samples"] == 2
+
+    def boom(*a, **k):
+        raise FileNotFoundError("rocm-smi")
+
+    monkeypatch.setattr(subprocess, "run", boom)
+    silent = bench.PowerSampler()
+    silent._poll()
+    assert silent.result() is None
