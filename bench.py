@@ -111,7 +111,7 @@ class PowerSampler:
     (profiles/r4_power_cap.txt, DESIGN.md 4.5) — this puts that evidence into the line the driver records.  Never raises;
     `result()` is None when rocm-smi is missing or answers nothing."""
 
-    def __init__(self, period_s: float = 0.35, max_samples: int = 12):
+    def __init__(self, period_s: float = 1.0, max_samples: int = 6):   # A/B on one box: 10 polls in a 4-step region cost 0.35 %
         import threading
         self.period, self.max = period_s, max_samples
         self.samples, self.cap = [], None
