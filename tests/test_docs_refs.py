@@ -45,3 +45,26 @@ def test_cited_files_exist(doc):
                 continue
             missing.append(p)
     assert not missing, f"{doc} cites files that are not in the tree: {missing}"
+
+
+@pytest.mark.parametrize("doc", DOCS)
+def test_cited_test_names_are_defined(doc):
+    """`test_...` names quoted in the documents are functions in tests/ (a trailing `*` or `_` quotes a family by prefix);
+    file names (`test_x.py`, `test_x.c`) and the reference's own tests (`pyannote-audio/tests/...`) are not names of ours."""
+    defs, files = set(), set()
+    for f in (ROOT / "tests").glob("*.py"):
+        files.add(f.stem)
+        defs.update(re.findall(r"^def (test_\w+)", f.read_text(), re.M))
+    text = (ROOT / doc).read_text()
+    unknown = set()
+    for m in re.finditer(r"(?<![\w/])(test_[a-z0-9_]+)(\*?)", text):
+        name, star = m.group(1), m.group(2)
+        if text[m.end():m.end() + 3] in (".py", ".c ", ".c)", ".c`") or text[m.end():m.end() + 2] == ".c" or name in files:
+            continue
+        if "pyannote-audio/tests" in text[max(0, m.start() - 48):m.start()]:
+            continue
+        family = bool(star) or name.endswith("_")
+        if name in defs or (family and any(d.startswith(name) for d in defs)):
+            continue
+        unknown.add(name)
+    assert not unknown, f"{doc} quotes tests that do not exist: {sorted(unknown)}"
