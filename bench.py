@@ -100,7 +100,9 @@ PMC_SYMBOLS = {"conv0_ln_gelu": "conv0_kernel", "conv01_fused": "conv01_fused_ke
                "attention_relpos_f32s": "attn_split_kernel<true, 3>", "attention_relpos_f32h": "attn_split_kernel<true, 2>",
                "attention_f32s": "attn_split_kernel<false, 3>", "attention_f32h": "attn_split_kernel<false, 2>",
                "conv3x3_c32_f32s": "conv3x3_c32_split_kernel<3>", "conv3x3_c32_f32h": "conv3x3_c32_split_kernel<2>",
-               "layernorm": "layernorm_kernel<4", "row_stats": "row_stats_kernel<16>", "gate_ln_stats": "gate_stats_kernel",
+               "layernorm": "layernorm_v4_kernel<16", "row_stats": "row_stats_kernel<16>", "gate_ln_stats": "gate_stats_kernel",
+               "ws_sum": "ws_sum_kernel", "stem_conv": "stem_conv_kernel", "glu_dwconv": "glu_dwconv_kernel",
+               "stats_pool": "stats_pool_kernel", "pad_rows_split2": "pad_rows_split2_kernel",
                "resblock32_fused_f32h": "resblock32_fused_kernel<2>", "resblock64_ws_f32h": "resblock_ws_kernel<64>",
                "resblock32_ws_f32h": "resblock_ws_kernel<32>"}
 
