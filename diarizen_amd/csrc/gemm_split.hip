@@ -34,6 +34,7 @@
 // (dzn_gemm_desc.a_amax / c_amax); the epilogue multiplies the accumulator by the exact inverse powers of two.
 // Elements more than 2^17 below the tensor's maximum keep a lo term in fp16's subnormal range: their ABSOLUTE
 // error stays <= 2^-25 * max / 2^14, i.e. below fp32 resolution of any dot product that contains the maximum.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -68,7 +69,7 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 //   1 = no operand split (raw bits as fragments), 2 = no MFMAs, 3 = no steady-state LDS-DMA refills, 4 = no barrier,
 //   5 = no fragment reads after the first tile
 template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0>
-__global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const dzn_gemm_desc d) {
+__global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const dzn_gemm_desc d, const int ngroups) {
   constexpr int NW = WGM * WGN;           // wavefronts per workgroup
   constexpr int BK = 32;
   constexpr int TM = BM / WGM, TN = BN / WGN;
@@ -97,7 +98,31 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = t / tilesN, tn = t % tilesN;
+  // (r4) COLUMN GROUPS.  t walks the tiles XCD by XCD (contiguous ranges).  With ngroups == 1 that order is row-block-major:
+  // an XCD works on a few row blocks with ALL their column tiles, so it streams the whole weight-plane set (N x K x 2 NP bytes)
+  // once per row block — and from ~4 MB on that set no longer survives in the XCD's 4 MB L2 between two row blocks
+  // (profiles/r4_gemm_refetch_probe.txt: fabric reads 1.02 x the algorithmic bytes at N = 128, 2.1 x at N = K = 1024, 4.7 x at
+  // N = 2048; the excess is 0.27 / 0.69 of the plane set PER ROW BLOCK).  With ngroups = G the column tiles are cut into G
+  // contiguous groups and the order is group-major, so an XCD meets only 1 / G of the planes (they stay in its L2) while a row
+  // block of A is fetched by G XCDs instead of one; the launcher picks G from that trade (choose_column_groups).  A
+  // permutation of the tile index: every tile is computed exactly once, by the same code — results do not change.
+  int tm, tn;
+  if (ngroups <= 1) {
+    tm = t / tilesN;
+    tn = t % tilesN;
+  } else {
+    const int tilesM_ = (int)gridDim.x / tilesN;
+    const int base = tilesN / ngroups, rem = tilesN % ngroups;
+    int g = 0, cg = base + (rem > 0), cs = 0, r = t;
+    while (r >= tilesM_ * cg) {     // ngroups <= 8 iterations, scalar
+      r -= tilesM_ * cg;
+      cs += cg;
+      ++g;
+      cg = base + (g < rem);
+    }
+    tm = r / cg;
+    tn = cs + r - tm * cg;
+  }
   const int z = blockIdx.y;
   int z0 = z / d.zdiv;
   const int z1 = z - z0 * d.zdiv;
@@ -611,6 +636,46 @@ int launch_split32_cfg(const dzn_gemm_desc& d, hipStream_t s) {
 
 #endif  // DZN_TUNING (32x32x16 probe)
 
+// Column groups of a launch (gemm_split_kernel, "COLUMN GROUPS").  Fabric reads of a launch as a function of G, from the
+// measured miss fractions of the weight-plane set per row block (profiles/r4_gemm_refetch_probe.txt; M = 149226, K = 1024,
+// one XCD = 4 MB of L2 shared with the streaming A / C / residual traffic):
+//     plane set seen by an XCD   0.5 MB   1 MB    2 MB    4 MB    8 MB
+//     fraction re-fetched        0.02     0.055   0.12    0.27    0.69        (log-linear between, 1.0 from 12 MB on)
+//     reads(G) = G x A  +  row_blocks x W x miss(W / G)
+// G in {1, 2, 4, 8}, G <= column tiles, the smallest reads(G) wins and G = 1 unless the saving is worth 5 % of the launch's reads.
+// STATE (end of r4): built, correct (kernel tests + the turn-taking goldens pass under forced G = 3 / 4), and NEUTRAL in time — the
+// step is 1040.8 ms with the model's choice against 1039.2 ms with G = 1 (profiles/r4_gemm_refetch_probe.txt); whether the
+// fabric reads drop as modelled was not measured (no GPU budget left for the PMC pass).  So the default stays G = 1, the r1-r3
+// order; DZN_GEMM_NGROUPS (read once) = "auto" takes the model's choice, a number forces it.
+int choose_column_groups(const dzn_gemm_desc& d, int tilesM, int tilesN, int BM, int NP) {
+  static const char* env = getenv("DZN_GEMM_NGROUPS");
+  static const bool automatic = env && !strcmp(env, "auto");
+  static const int forced = env && !automatic ? atoi(env) : 0;
+  if (tilesN < 2 || d.w_z0 || d.w_z1 || (!automatic && forced <= 1)) return 1;
+  if (forced > 0) return forced < tilesN ? (forced > 8 ? 8 : forced) : tilesN > 8 ? 8 : tilesN;
+  if ((d.nz > 1) || (int64_t)tilesM * tilesN < 1024) return 1;   // z-batched / small launches: the planes are small or the chip is not full
+  const double W = (double)d.N * d.K * 2.0 * NP;
+  const double a_cols = d.a_rowoff ? (double)d.kc : (d.lda > 0 && d.lda < d.K ? (double)d.lda : (double)d.K);
+  const double A = (double)d.M * a_cols * 4.0;
+  auto miss = [](double bytes) {
+    static const double mb[] = {0.5, 1.0, 2.0, 4.0, 8.0, 12.0}, f[] = {0.02, 0.055, 0.12, 0.27, 0.69, 1.0};
+    const double x = bytes / (1024.0 * 1024.0);
+    if (x <= mb[0]) return f[0] * x / mb[0];
+    for (int i = 1; i < 6; ++i)
+      if (x <= mb[i]) return f[i - 1] + (f[i] - f[i - 1]) * (log2(x) - log2(mb[i - 1])) / (log2(mb[i]) - log2(mb[i - 1]));
+    return 1.0;
+  };
+  int best = 1;
+  const double r1 = A + tilesM * W * miss(W);
+  double rbest = r1;
+  for (int G = 2; G <= 8 && G <= tilesN; G *= 2) {
+    const double r = G * A + tilesM * W * miss(W / G);
+    if (r < rbest) { rbest = r; best = G; }
+  }
+  (void)BM;
+  return rbest < 0.95 * r1 ? best : 1;
+}
+
 template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0>
 int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
@@ -634,7 +699,7 @@ int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
     pid = prof_begin(s, cls, fl, gemm_alg_bytes(d, NP * 2));
   }
-  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, d);
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, d, choose_column_groups(d, tilesM, tilesN, BM, NP));
   prof_end(pid, s);
   if (hipGetLastError() != hipSuccess) return DZN_E_HIP;
   if (d.stat_partial && d.stat_final)

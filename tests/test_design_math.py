@@ -397,3 +397,34 @@ def test_resblock_ws_ring_schedule(H):
             outputs.append(r - 1)
         _run_intervals([iv], X, M, sl, sl)
     assert outputs == list(range(H))
+
+
+def test_column_group_tile_order_is_a_permutation():
+    """csrc/gemm_split.hip "COLUMN GROUPS": with G groups the linear tile index walks group-major (all row blocks of the first
+    cg column tiles, then the next group ...).  Restated here: every (row block, column tile) is produced exactly once for any
+    grid and any G <= 8, groups are contiguous column ranges of near-equal width, and G = 1 is the row-block-major order."""
+    def tile(t, tiles_m, tiles_n, groups):
+        if groups <= 1:
+            return t // tiles_n, t % tiles_n
+        base, rem = tiles_n // groups, tiles_n % groups
+        g, cg, cs, r = 0, base + (rem > 0), 0, t
+        while r >= tiles_m * cg:
+            r -= tiles_m * cg
+            cs += cg
+            g += 1
+            cg = base + (g < rem)
+        tm = r // cg
+        return tm, cs + r - tm * cg
+
+    for tiles_m, tiles_n in ((1, 2), (3, 5), (7, 8), (1166, 8), (1749, 15), (13, 16), (5, 9)):
+        for groups in (1, 2, 3, 4, 8):
+            if groups > tiles_n:
+                continue
+            seen = [tile(t, tiles_m, tiles_n, groups) for t in range(tiles_m * tiles_n)]
+            assert sorted(seen) == [(m, n) for m in range(tiles_m) for n in range(tiles_n)], (tiles_m, tiles_n, groups)
+            if groups > 1:     # group-major: the column index never decreases by more than a group's width along the walk
+                first_cols = [n for m, n in seen if m == 0]
+                assert first_cols == sorted(first_cols)
+                width = -(-tiles_n // groups)
+                quarter = seen[: tiles_m * (tiles_n // groups)]
+                assert max(n for _, n in quarter) < width
