@@ -644,9 +644,10 @@ int launch_split32_cfg(const dzn_gemm_desc& d, hipStream_t s) {
 //     reads(G) = G x A  +  row_blocks x W x miss(W / G)
 // G in {1, 2, 4, 8}, G <= column tiles, the smallest reads(G) wins and G = 1 unless the saving is worth 5 % of the launch's reads.
 // STATE (end of r4): built, correct (kernel tests + the turn-taking goldens pass under forced G = 3 / 4), and NEUTRAL in time — the
-// step is 1040.8 ms with the model's choice against 1039.2 ms with G = 1 (profiles/r4_gemm_refetch_probe.txt); whether the
-// fabric reads drop as modelled was not measured (no GPU budget left for the PMC pass).  So the default stays G = 1, the r1-r3
-// order; DZN_GEMM_NGROUPS (read once) = "auto" takes the model's choice, a number forces it.
+// step is 1040.8 ms with the model's choice against 1039.2 ms with G = 1 — although the fabric reads DO drop as modelled (N = 2048:
+// 8.59 -> 4.82 GB per launch, model 4.9; profiles/r4_gemm_refetch_probe.txt): the re-fetched planes come from the 256 MB
+// Infinity Cache, which costs neither time nor measurable power.  So the default stays G = 1, the r1-r3 order;
+// DZN_GEMM_NGROUPS (read once) = "auto" takes the model's choice, a number forces it.
 int choose_column_groups(const dzn_gemm_desc& d, int tilesM, int tilesN, int BM, int NP) {
   static const char* env = getenv("DZN_GEMM_NGROUPS");
   static const bool automatic = env && !strcmp(env, "auto");
