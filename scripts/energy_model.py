@@ -9,7 +9,9 @@ to the Infinity Cache / HBM, FETCH_SIZE x 2 + WRITE_SIZE) and three measured anc
                                                      traffic the Infinity Cache answers; the copy streams from HBM)
   package cap                           1400 W
 The model charges every kernel class idle + 146 W x its fabric TB/s and calls the rest of what the step draws (bench `power`,
-~1315 W mean) "compute" (matrix pipe, VALU, LDS, L2).  It is an attribution, not a measurement per kernel."""
+~1315 W mean) "compute" (matrix pipe, VALU, LDS, L2).  It is an attribution, not a measurement per kernel — and an UPPER bound on
+the fabric side: the per-TB/s anchor is an HBM-streaming copy, while much of the L2-miss traffic of the contractions is answered by the
+256 MB Infinity Cache, where halving it changed neither time nor the step (profiles/r4_gemm_refetch_probe.txt)."""
 from __future__ import annotations
 
 import json
