@@ -2,6 +2,7 @@
 SURVEY 8d's reduced bar (max |dlogp| <= 5e-2, argmax >= 99.5 %) on the non-degenerate turn-taking weights?   
 
     python scripts/emulate_reduced_modes.py [model=wavlm_large_s80_md] [windows=2]
+    python scripts/emulate_reduced_modes.py embedding [windows=2]
 
 Every linear layer / 1x1 conv / positional conv of oracle/seg_model.py is replaced by an emulated contraction (products of
 rounded operands are exact in fp32, accumulation in fp32 — what the MFMA forms do); the conv stack, the gate, attention products
@@ -120,6 +121,50 @@ def run(model: str, n_windows: int):
         F.linear, F.conv1d = real_linear, real_conv1d
 
 
+def run_embedding(n_windows: int):
+    """the WeSpeaker ResNet34 trunk the same way (SURVEY 8d reduced bar: cosine >= 0.999): every 3x3 / 1x1 convolution but the
+    one-channel stem and the seg_1 linear emulated; two half-window masks per window"""
+    from oracle import emb_model
+    from oracle.gen_golden import tt_windows
+    sd = emb_model.emb_state_dict(0)
+    N = 128000
+    wave = tt_windows([0, 192000, 96000, 288000][:n_windows], N)
+    L = 399
+    masks = torch.zeros(n_windows, 2, L)
+    masks[:, 0, : L // 2] = 1.0
+    masks[:, 1, L // 3:] = 1.0
+    real_conv2d, real_linear = F.conv2d, F.linear
+    scheme = Scheme("fp32")
+
+    def conv2d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+        if scheme.name == "fp32" or w.shape[1] == 1:       # the stem (one input plane) is VALU fp32 on the device
+            return real_conv2d(x, w, b, stride, padding, dilation, groups)
+        return scheme.contract(lambda a, ww: real_conv2d(a, ww, None, stride, padding, dilation, groups), x, w, None, (1, 2, 3), (1, 2, 3))
+
+    def linear(x, w, b=None):
+        if scheme.name == "fp32":
+            return real_linear(x, w, b)
+        return scheme.contract(lambda a, ww: real_linear(a, ww), x, w, b, tuple(range(1, x.dim())), (1,))
+
+    F.conv2d, F.linear = conv2d, linear
+    try:
+        with torch.inference_mode():
+            ref = emb_model.emb_forward(sd, wave, masks)
+            print(f"ResNet34 embeddings: {n_windows} windows of {N} samples x 2 masks", flush=True)
+            for name in ("f32h", "f16", "w16", "a16", "fp8x", "fp8xa"):
+                scheme.name = name
+                out = emb_model.emb_forward(sd, wave, masks)
+                cos = F.cosine_similarity(out.reshape(-1, out.shape[-1]), ref.reshape(-1, ref.shape[-1]), dim=-1)
+                rel = ((out - ref).norm(dim=-1) / ref.norm(dim=-1)).max().item()
+                print(f"  {name:6s} min cosine {cos.min().item():.7f}  max relative error {rel:.2e}  -> reduced bar (cos >= 0.999) "
+                      f"{'MET' if cos.min().item() >= 0.999 else 'not met'}", flush=True)
+    finally:
+        F.conv2d, F.linear = real_conv2d, real_linear
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    run(sys.argv[1] if len(sys.argv) > 1 else "wavlm_large_s80_md", int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+    if len(sys.argv) > 1 and sys.argv[1] == "embedding":
+        run_embedding(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+    else:
+        run(sys.argv[1] if len(sys.argv) > 1 else "wavlm_large_s80_md", int(sys.argv[2]) if len(sys.argv) > 2 else 2)
