@@ -3,6 +3,7 @@ SURVEY 8d's reduced bar (max |dlogp| <= 5e-2, argmax >= 99.5 %) on the non-degen
 
     python scripts/emulate_reduced_modes.py [model=wavlm_large_s80_md] [windows=2]
     python scripts/emulate_reduced_modes.py embedding [windows=2]
+    python scripts/emulate_reduced_modes.py wavlm_large_s80_md 2 sweep     # + one contraction class at a time at the other scheme
 
 Every linear layer / 1x1 conv / positional conv of oracle/seg_model.py is replaced by an emulated contraction (products of
 rounded operands are exact in fp32, accumulation in fp32 — what the MFMA forms do); the conv stack, the gate, attention products
@@ -16,6 +17,7 @@ and the classifier stay fp32, as in the device's f16 mode.  Schemes:
 Scaling: exact powers of two per window (activations) / per output row (weights), as the device does."""
 from __future__ import annotations
 
+import re
 import sys
 from pathlib import Path
 
@@ -74,7 +76,7 @@ class Scheme:
         return y if b is None else y + b
 
 
-def run(model: str, n_windows: int):
+def run(model: str, n_windows: int, sweep: bool = False):
     from diarizen_amd.configs import get_seg_config
     from oracle import seg_model
     from oracle.gen_golden import TT_CASES, tt_windows
@@ -88,19 +90,36 @@ def run(model: str, n_windows: int):
     wave = tt_windows(starts[:n_windows], N)
     real_linear, real_conv1d = F.linear, F.conv1d
     scheme = Scheme("fp32")
+    overrides = {}                                          # contraction class -> scheme name (class sweep below)
+    cls_of = {}
+    for key, t in sd.items():                               # call sites are recognised by the weight tensor they pass
+        c = ("qkv" if re.search(r"attention\.[qkv]_proj\.weight$", key) else
+             "out_proj" if key.endswith("attention.out_proj.weight") else
+             "ffn1" if key.endswith("intermediate_dense.weight") else
+             "ffn2" if key.endswith("output_dense.weight") else
+             "feature projection" if "feature_projection.projection.weight" in key else
+             "proj" if key == "proj.weight" else
+             "conformer" if key.startswith("conformer.") and key.endswith("weight") else None)
+        if c:
+            cls_of[id(t)] = c
+
+    def pick(w):
+        c = cls_of.get(id(w), "pos conv" if w.dim() == 3 and w.shape[-1] > 31 else "other")
+        s_ = Scheme(overrides[c]) if c in overrides else scheme
+        return s_
 
     def linear(x, w, b=None):
         if w.shape[0] <= 16 or scheme.name == "fp32":      # gate projection (8), classifier (11): fp32 on the device too
             return real_linear(x, w, b)
         xdims = tuple(range(1, x.dim()))                    # one scale per window (dim 0)
-        return scheme.contract(lambda a, ww: real_linear(a, ww), x, w, b, xdims, (1,))
+        return pick(w).contract(lambda a, ww: real_linear(a, ww), x, w, b, xdims, (1,))
 
     def conv1d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
         k = w.shape[-1]
         emulate = scheme.name != "fp32" and (k == 1 or (groups > 1 and k > 31))   # conformer pointwise convs, positional conv
         if not emulate:
             return real_conv1d(x, w, b, stride, padding, dilation, groups)
-        y = scheme.contract(lambda a, ww: real_conv1d(a, ww, None, stride, padding, dilation, groups), x, w, None, (1, 2), (1, 2))
+        y = pick(w).contract(lambda a, ww: real_conv1d(a, ww, None, stride, padding, dilation, groups), x, w, None, (1, 2), (1, 2))
         return y if b is None else y + b.view(1, -1, 1)
 
     F.linear, F.conv1d = linear, conv1d
@@ -117,6 +136,19 @@ def run(model: str, n_windows: int):
                 agree = (out.argmax(-1) == ref.argmax(-1)).float().mean().item()
                 print(f"  {name:6s} max |dlogp| {d.max().item():.3e}  mean {d.mean().item():.2e}  argmax agreement {100 * agree:.3f} %"
                       f"  -> reduced bar (5e-2, 99.5 %) {'MET' if d.max().item() <= 5e-2 and agree >= 0.995 else 'not met'}", flush=True)
+            if sweep:
+                # which classes can stay at ONE fp16 term when everything else keeps fp8 cross terms (and the converse)
+                classes = ["qkv", "out_proj", "ffn1", "ffn2", "feature projection", "pos conv", "proj", "conformer"]
+                for base, alt in (("fp8x", "f16"), ("f16", "fp8x")):
+                    scheme.name = base
+                    for c in classes:
+                        overrides.clear()
+                        overrides[c] = alt
+                        out = seg_model.seg_forward(sd, cfg, wave)
+                        d = (out - ref).abs()
+                        agree = (out.argmax(-1) == ref.argmax(-1)).float().mean().item()
+                        print(f"  all {base:5s} but {c:18s} = {alt:5s}: max |dlogp| {d.max().item():.3e}  argmax {100 * agree:.3f} %", flush=True)
+                overrides.clear()
     finally:
         F.linear, F.conv1d = real_linear, real_conv1d
 
@@ -167,4 +199,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "embedding":
         run_embedding(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
     else:
-        run(sys.argv[1] if len(sys.argv) > 1 else "wavlm_large_s80_md", int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+        run(sys.argv[1] if len(sys.argv) > 1 else "wavlm_large_s80_md", int(sys.argv[2]) if len(sys.argv) > 2 else 2,
+            sweep=len(sys.argv) > 3 and sys.argv[3] == "sweep")
