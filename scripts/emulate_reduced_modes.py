@@ -14,6 +14,8 @@ and the classifier stay fp32, as in the device's f16 mode.  Schemes:
   fp8x   hi*hi in fp16  +  the two cross terms hi*lo, lo*hi with BOTH operands rounded to fp8 e4m3 (twice the MFMA rate)
   fp8xa  as fp8x, but only the small factor (lo) of each cross term in fp8, the hi factor stays fp16 (mixed-type MFMA is not
          available: an upper bound on what a better fp8 encoding of the cross terms could reach)
+  mx8 / mx6a / mx6b / mx4   the cross terms in the OCP MX formats of v_mfma_scale_f32_16x16x128_f8f6f4 — e4m3 / e2m3 / e3m2 / e2m1 (fp4) —
+         with a power-of-two block scale per 32 k (linear layers; the 1x1 and positional convs keep per-tensor scales)
 Scaling: exact powers of two per window (activations) / per output row (weights), as the device does."""
 from __future__ import annotations
 
@@ -47,9 +49,38 @@ def q8(x, dims):
     return quant(x, dims, torch.float8_e4m3fn, 8)
 
 
+# minifloat formats of v_mfma_scale_f32_16x16x128_f8f6f4 (OCP MX): (exponent bits, mantissa bits, bias, largest finite value)
+MINI = {"e4m3": (4, 3, 7, 448.0), "e3m2": (3, 2, 3, 28.0), "e2m3": (2, 3, 1, 7.5), "e2m1": (2, 1, 1, 6.0)}
+
+
+def round_mini(y: torch.Tensor, fmt: str) -> torch.Tensor:
+    """round-to-nearest-even onto the format's grid (normals and subnormals), saturating"""
+    eb, mb, bias, vmax = MINI[fmt]
+    emin = 1 - bias
+    a = y.abs().clamp_min(1e-38)
+    e = torch.floor(torch.log2(a)).clamp_min(emin)
+    step = torch.exp2(e - mb)
+    q = torch.round(y / step) * step          # torch.round: half to even
+    return q.clamp(-vmax, vmax)
+
+
+def quant_mini(x: torch.Tensor, dims, fmt: str, block: int = 0) -> torch.Tensor:
+    """power-of-two scale per `dims` group — or, block > 0, per block of `block` consecutive elements of the LAST dim (the MX
+    block scale along k) — so that the group's |max| lands in the format's top binade"""
+    eb, mb, bias, vmax = MINI[fmt]
+    top = int(torch.floor(torch.log2(torch.tensor(vmax))).item()) + 1        # amax * s in [2^(top-1), 2^top)
+    if block and x.shape[-1] % block == 0:
+        xb = x.reshape(*x.shape[:-1], x.shape[-1] // block, block)
+        s = pow2_scale(xb.abs().amax(dim=-1, keepdim=True), top)
+        return (round_mini(xb * s, fmt) / s).reshape(x.shape)
+    s = pow2_scale(x.abs().amax(dim=dims, keepdim=True), top)
+    return round_mini(x * s, fmt) / s
+
+
 class Scheme:
     def __init__(self, name):
         self.name = name
+        self.k_last = False        # set per call: the contraction runs over the LAST dim of both operands (linear layers)
 
     def contract(self, op, x, w, b, xdims, wdims):
         """op(x, w) = the contraction in fp32 without bias; xdims / wdims = the dims one scale is shared over"""
@@ -71,6 +102,11 @@ class Scheme:
                 y = op(xh, wh) + op(xh, q8(wl, wdims)) + op(q8(xl, xdims), wh)
             elif n == "f32h":
                 y = op(xh, wh) + op(xh, wl) + op(xl, wh)
+            elif n in ("mx8", "mx6a", "mx6b", "mx4"):      # cross terms in an MX format, block scale per 32 k
+                fmt = {"mx8": "e4m3", "mx6a": "e2m3", "mx6b": "e3m2", "mx4": "e2m1"}[n]
+                blk = 32 if self.k_last else 0
+                q = lambda t, dims: quant_mini(t, dims, fmt, blk)      # noqa: E731
+                y = op(xh, wh) + op(q(xh, xdims), q(wl, wdims)) + op(q(xl, xdims), q(wh, wdims))
             else:
                 raise ValueError(n)
         return y if b is None else y + b
@@ -112,14 +148,18 @@ def run(model: str, n_windows: int, sweep: bool = False):
         if w.shape[0] <= 16 or scheme.name == "fp32":      # gate projection (8), classifier (11): fp32 on the device too
             return real_linear(x, w, b)
         xdims = tuple(range(1, x.dim()))                    # one scale per window (dim 0)
-        return pick(w).contract(lambda a, ww: real_linear(a, ww), x, w, b, xdims, (1,))
+        sch = pick(w)
+        sch.k_last = True
+        return sch.contract(lambda a, ww: real_linear(a, ww), x, w, b, xdims, (1,))
 
     def conv1d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
         k = w.shape[-1]
         emulate = scheme.name != "fp32" and (k == 1 or (groups > 1 and k > 31))   # conformer pointwise convs, positional conv
         if not emulate:
             return real_conv1d(x, w, b, stride, padding, dilation, groups)
-        y = pick(w).contract(lambda a, ww: real_conv1d(a, ww, None, stride, padding, dilation, groups), x, w, None, (1, 2), (1, 2))
+        sch = pick(w)
+        sch.k_last = False
+        y = sch.contract(lambda a, ww: real_conv1d(a, ww, None, stride, padding, dilation, groups), x, w, None, (1, 2), (1, 2))
         return y if b is None else y + b.view(1, -1, 1)
 
     F.linear, F.conv1d = linear, conv1d
@@ -129,7 +169,7 @@ def run(model: str, n_windows: int, sweep: bool = False):
             top2 = ref.topk(2, dim=-1).values
             print(f"{model}: {n_windows} windows of {N} samples, {ref.shape[1]} frames each; smallest top-2 margin of the fp32 oracle "
                   f"{(top2[..., 0] - top2[..., 1]).min().item():.2e}", flush=True)
-            for name in ("f32h", "f16", "w16", "a16", "fp8x", "fp8xa"):
+            for name in ("f32h", "f16", "w16", "a16", "fp8x", "fp8xa", "mx8", "mx6a", "mx6b", "mx4"):
                 scheme.name = name
                 out = seg_model.seg_forward(sd, cfg, wave)
                 d = (out - ref).abs()
