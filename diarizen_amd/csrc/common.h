@@ -127,6 +127,8 @@ int launch_pad_rows_split2(const float* x, void* planes, int64_t plane_stride, i
                            const float* amax, float* snapshot, hipStream_t st, int cg = 0, int cgp = 0);
 int launch_split_weights(const float* W, int64_t rows, int K, int64_t ldw, void* W3, hipStream_t s);
 int launch_split_weights_h2(const float* W, int64_t rows, int K, int64_t ldw, void* W2, float* col_scale, hipStream_t s);
+int launch_gemm_mx(const dzn_gemm_desc& d, hipStream_t s);   // gemm_mx.hip: fp16 hi*hi + fp8 cross terms (DZN_PREC_F16)
+int launch_split_weights_mx(const float* W, int64_t rows, int K, int64_t ldw, void* Wmx, float* col_scale, hipStream_t s);
 int launch_amax(const float* x, int64_t n, float* amax, hipStream_t s);
 int launch_fill_u32(void* p, unsigned value, int64_t n, hipStream_t st);   // norm.hip: p[0 .. n) = value, as a kernel (graph-safe ordering)
 int launch_stats_finalize(const float* partial, int64_t rows, int P, int C, float eps, float* stats, hipStream_t s);

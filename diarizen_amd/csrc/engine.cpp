@@ -58,6 +58,8 @@ struct Lin {       // y = x W^T + b with W [N, K] (rows zero-padded to Np, cols 
   u16* W2h = nullptr;  // two-term fp16 planes of W * 2^e_row (DZN_PREC_F32_H2) ...
   float* wsc = nullptr;   // ... and 2^-e_row per output row (dzn_gemm_desc.col_scale)
   float* csum = nullptr;  // LayerNorm folded into W (make_lin_ln): column sums of W diag(gamma), dzn_gemm_desc.ln_colsum
+  unsigned char* Wmx = nullptr;   // DZN_PREC_F16: planes of the reduced-precision contraction (gemm_mx.hip: fp16 hi | fp8 hi, fp8 lo) ...
+  float* wsc_mx = nullptr;        // ... and their inverse row scales (dzn_gemm_desc.col_scale_mx)
   int N = 0, K = 0;    // padded sizes
   int Nt = 0, Kt = 0;  // reference (un-padded) sizes, for algorithmic flop accounting
 };
@@ -163,6 +165,7 @@ struct dzn_handle {
   // a read-modify-write of `ws` in every FFN-output epilogue: 25 reads + 1 write of [rows, D] where there were 25 reads and
   // 25 writes.  nullptr: the fused read-modify-write (post-norm encoders, DZN_NO_WS_DEFER, not enough free memory).
   float* xl = nullptr;
+  int64_t xl_elems = 0;     // size xl would have (0: not applicable to this model / switched off)
   float* spart = nullptr;   // [max_batch * maxL][32][2] per-row partial sums left by a producing epilogue (stat_partial)
   float* rstat = nullptr;   // [max_batch * maxL][2] (mean, rstd) of the LayerNorm folded into the next contraction
   // |max| trackers of activation tensors (DZN_PREC_F32_H2), ONE PER WINDOW of the batch (slot * max_batch + b): written
@@ -197,6 +200,7 @@ struct dzn_handle {
   // list of active windows + its length, running totals (windows seen, windows skipped) for dzn_embed_skip_stats
   int *win_flag = nullptr, *win_idx = nullptr, *win_cnt = nullptr;
   long long* emb_totals = nullptr;
+  long long emb_dense_windows = 0;   // windows that went through the trunk on the dense path (no subset: nothing to skip)
   bool emb_skip = true;       // DZN_EMB_NO_SKIP (read once, at dzn_create) switches the subset off
   // DZN_PREC_F16 (reduced precision): which contraction classes keep two fp16 terms (F16_CLASSES bit mask; bit 14 = the
   // ResNet stages 2-4), and whether LayerNorm-folded single-term contractions subtract the row mean BEFORE rounding
@@ -205,10 +209,19 @@ struct dzn_handle {
   // (= f32h) does; the conv stack alone carries ~70 % of the error variance for 4 % of the flops, so it keeps two terms
   // (0.247 -> 0.133, flips 0.52 % -> 0.33 %); centring the LayerNorm-folded split changes nothing (0.228 vs 0.247: the
   // error is plain operand rounding, not the mean * colsum cancellation) and stays off.
+  // NOTE: the stride-1 BasicBlocks of ResNet stages 1-2 run the fused kernels (resblock_fused.hip / resblock_ws.hip),
+  // which exist in the two-term form only — in DZN_PREC_F16 they are two-term whatever bit 14 says; bit 14 governs the
+  // stride-2 / shortcut / stage 3-4 contractions, which go through gemm_split.hip.
   bool fuse_resblock = true;  // DZN_NO_RESBLOCK_FUSION (read once, at dzn_create)
   int resblock_ws = 2;        // DZN_RESBLOCK_WS bit mask: 1 = 32-plane blocks, 2 = 64-plane blocks on the producer / consumer form
   unsigned f16_keep2 = 0x1;
   bool f16_center = false;
+  // (r5) DZN_PREC_F16: the classes whose bit is set run fp16 hi*hi + the two cross terms in fp8 (gemm_mx.hip) — every linear
+  // contraction of the segmentation model: the class sweep of profiles/r4_reduced_mode_emulation.txt shows that any one of them
+  // at a single fp16 term costs 0.04-0.21 of max |dlogp| against SURVEY 8d's 5e-2, only the positional conv (bit 2) can stay at
+  // one term.  Bit 0 (the conv stack) keeps two fp16 terms (f16_keep2).  DZN_F16_MX overrides (0 = r4's single-term mode).
+  unsigned f16_mx = 0x3ffa;
+  bool mx_pack = false;   // make_lin also packs the MX planes (set while the segmentation weights are finalized)
 };
 
 namespace {
@@ -278,6 +291,12 @@ Lin make_lin(H* h, const std::vector<float>& W, const float* bias, int N, int K,
       l.wsc = dalloc<float>(h, Np, false);
       if (launch_split_weights_h2(l.W, Np, Kp, Kp, l.W2h, l.wsc, nullptr) != DZN_OK)
         throw EngineError(DZN_E_HIP, "split_weights_h2 launch failed");
+    }
+    if (h->cfg.precision == DZN_PREC_F16 && h->mx_pack && h->f16_mx) {
+      l.Wmx = dalloc<unsigned char>(h, (int64_t)4 * Np * Kp, false);
+      l.wsc_mx = dalloc<float>(h, Np, false);
+      if (launch_split_weights_mx(l.W, Np, Kp, Kp, l.Wmx, l.wsc_mx, nullptr) != DZN_OK)
+        throw EngineError(DZN_E_HIP, "split_weights_mx launch failed");
     }
     HIPCHK(hipDeviceSynchronize());
   }
@@ -727,13 +746,9 @@ void finalize_seg(H* h) {
   }
   h->y = dalloc<float>(h, ML * D);
   h->ws = dalloc<float>(h, ML * D);
-  if (c.layer_norm_first && h->fold_ln && c.n_layers > 0 && c.n_layers < WS_SUM_MAX && !getenv("DZN_NO_WS_DEFER")) {
-    size_t free_b = 0, total_b = 0;
-    const int64_t need = (int64_t)c.n_layers * ML * D * (int64_t)sizeof(float);
-    // taken only when it leaves more than half of what is free now to everything allocated after it
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < (int64_t)(free_b / 2))
-      h->xl = dalloc<float>(h, (int64_t)c.n_layers * ML * D, false);
-  }
+  // the per-layer buffers of the deferred layer-weighted sum are OPTIONAL: they are taken last, by alloc_optional_workspace()
+  h->xl_elems = (c.layer_norm_first && h->fold_ln && c.n_layers > 0 && c.n_layers < WS_SUM_MAX && D % 4 == 0 &&
+                 !getenv("DZN_NO_WS_DEFER")) ? (int64_t)c.n_layers * ML * D : 0;
   h->qkv = dalloc<float>(h, ML * 3 * maxQ);
   h->ao = dalloc<float>(h, ML * maxQ);
   h->gate = dalloc<float>(h, ML * h->H);
@@ -745,6 +760,27 @@ void finalize_seg(H* h) {
   h->rstat = dalloc<float>(h, ML * 2);
   h->spart = dalloc<float>(h, ML * 32 * 2);
   h->amax = dalloc<float>(h, (int64_t)dzn_handle::AM_COUNT * c.max_batch);
+}
+
+// Optional workspace, taken AFTER everything a forward needs (segmentation + embedding) and only against a reserve, so that
+// several handles on one device (DiariZenPipeline num_streams, bench config1) cannot starve what is allocated later — torch's
+// waveform / chunk copies, VBx, RCCL (the r4 gate was `need < free / 2` per handle at a point where the embedding
+// workspace did not exist yet).  A failed hipMalloc leaves the read-modify-write path in place instead of failing the handle.
+void alloc_optional_workspace(H* h) {
+  if (h->xl_elems <= 0) return;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+  const int64_t need = h->xl_elems * (int64_t)sizeof(float);
+  const int64_t reserve = std::max<int64_t>((int64_t)32 << 30, (int64_t)(total_b / 4));   // stays free after the allocation
+  if (need + reserve > (int64_t)free_b) return;
+  void* p = nullptr;
+  if (hipMalloc(&p, (size_t)need) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  h->allocs.push_back(p);
+  h->bytes += need;
+  h->xl = reinterpret_cast<float*>(p);
 }
 
 // ------------------------------------------------------------------ embedding: finalize
@@ -973,6 +1009,8 @@ dzn_gemm_desc gd(H* h, const float* A, const Lin& l, float* C, int64_t M, int64_
   d.W3 = l.W3;
   d.W2h = l.W2h;
   d.col_scale = l.wsc;
+  d.Wmx = l.Wmx;
+  d.col_scale_mx = l.wsc_mx;
   d.C = C;
   d.bias = l.b;
   d.M = (int)M;
@@ -1054,8 +1092,10 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
     d.c_bf16 = c16;
     if (c.precision == DZN_PREC_F16) {
       const int cls = f16_class(what);
+      const bool mx = cls >= 0 && ((h->f16_mx >> cls) & 1) && d.Wmx;
+      if (!mx) d.Wmx = nullptr;     // single-term fp16 (or two terms, next line)
       if (cls >= 0 && ((h->f16_keep2 >> cls) & 1)) d.precision = DZN_PREC_F32_H2;
-      else if (d.ln_stats && h->f16_center) d.ln_centered = 1;
+      else if (!mx && d.ln_stats && h->f16_center) d.ln_centered = 1;
     }
     // |max| trackers are per window: rows of a [B*L, .] tensor belong to window m / L; z-batched launches
     // (conv stack: z = window) use the z index
@@ -1466,6 +1506,8 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
     zc = h->win_cnt;
     zl = h->win_idx;
     zflag = h->win_flag;
+  } else {
+    h->emb_dense_windows += B;   // dzn_embed_skip_stats counts every window, whichever path it took
   }
   const int64_t MT = (int64_t)B * T;
   // ---- kaldi fbank ----
@@ -1667,6 +1709,7 @@ int dzn_create(const dzn_config* cfg, dzn_handle** out) {
   if (const char* e = getenv("DZN_RESBLOCK_WS")) h->resblock_ws = atoi(e);
   if (const char* e = getenv("DZN_F16_KEEP2")) h->f16_keep2 = (unsigned)strtoul(e, nullptr, 0);
   if (const char* e = getenv("DZN_F16_CENTER")) h->f16_center = e[0] != '0';
+  if (const char* e = getenv("DZN_F16_MX")) h->f16_mx = (unsigned)strtoul(e, nullptr, 0);
   const char* dbg = getenv("DZN_DEBUG_TAPS");
   h->debug = dbg && dbg[0] == '1';
   *out = h;
@@ -1712,9 +1755,12 @@ int dzn_finalize_weights(dzn_handle* h) {
   }
   DeviceGuard dg(h->device);
   int rc = guarded(h, [&] {
+    h->mx_pack = true;
     finalize_seg(h);
+    h->mx_pack = false;
     h->has_emb = h->cfg.has_embedding != 0;
     if (h->has_emb) finalize_emb(h);
+    alloc_optional_workspace(h);
     HIPCHK(hipDeviceSynchronize());
   });
   if (rc == DZN_OK) {
@@ -1812,6 +1858,7 @@ int dzn_embed_skip_stats(const dzn_handle* h, int64_t* windows, int64_t* skipped
         hipMemcpy(t, h->emb_totals, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess)
       return DZN_E_HIP;
   }
+  t[0] += h->emb_dense_windows;
   if (windows) *windows = (int64_t)t[0];
   if (skipped) *skipped = (int64_t)t[1];
   return DZN_OK;

@@ -455,6 +455,8 @@ int launch_gemm(const dzn_gemm_desc& din, hipStream_t s) {
     return launch_prec<true>(d, s);
   }
   if (!d.W) return DZN_E_INVALID;
+  if (d.ln_centered && !(d.precision == DZN_PREC_F16 && d.W3 && !(d.K & 31) && !(d.kc & 31) && d.ldw == d.K && !d.a_split3))
+    return DZN_E_INVALID;    // only gemm_split.hip's single-term kernel subtracts the row mean (see launch_gemm_split)
   if (d.a_split3) return prec_is_split(d.precision) ? launch_gemm_split_pre(d, s) : DZN_E_INVALID;
   if (prec_is_split(d.precision) && d.W3 && !(d.K & 31) && !(d.kc & 31) && d.ldw == d.K)
     return launch_gemm_split(d, s);

@@ -871,9 +871,16 @@ int launch_gemm_split(const dzn_gemm_desc& d, hipStream_t s) {
   // fp16 two-term path: needs the fp16 planes + their row scales, the producer-tracked |max| of A, and weights
   // that do not move with z (col_scale is indexed by the output column alone)
   static const bool no_h2 = getenv("DZN_NO_H2") != nullptr;
-  if (prec_is_h2(d.precision) && d.W2h && d.col_scale && d.a_amax && !d.w_z0 && !d.w_z1 && !no_h2)
-    return d.precision == DZN_PREC_F16 ? launch_gemm_split_np<1>(d, s) : launch_gemm_split_np<2>(d, s);
-  if (!d.W3) return DZN_E_INVALID;
+  // DZN_PREC_F16 with the MX planes: fp16 hi*hi + fp8 cross terms (gemm_mx.hip); without them the single-term fp16 kernel
+  // (ln_centered — the row mean subtracted before the fp16 rounding — is implemented by the single-term kernel alone: any
+  // other dispatch with it set would silently drop the mean term of the folded LayerNorm, so it is refused)
+  if (d.precision == DZN_PREC_F16 && d.Wmx && d.col_scale_mx && d.a_amax && !d.w_z0 && !d.w_z1 && !no_h2)
+    return d.ln_centered ? DZN_E_INVALID : launch_gemm_mx(d, s);
+  if (prec_is_h2(d.precision) && d.W2h && d.col_scale && d.a_amax && !d.w_z0 && !d.w_z1 && !no_h2) {
+    if (d.precision == DZN_PREC_F16) return launch_gemm_split_np<1>(d, s);
+    return d.ln_centered ? DZN_E_INVALID : launch_gemm_split_np<2>(d, s);
+  }
+  if (!d.W3 || d.ln_centered) return DZN_E_INVALID;
   return launch_gemm_split_np<3>(d, s);
 }
 

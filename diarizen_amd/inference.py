@@ -49,14 +49,22 @@ class SlideResult:
 class WindowRunner:
     def __init__(self, engine: Engine, duration: float, step_ratio: float = 0.1, batch_size: int = 32,
                  median_size: int = 11, exclude_overlap: bool = True, sample_rate: int = 16000,
-                 extra_engines: Tuple[Engine, ...] = ()):
+                 extra_engines: Tuple[Engine, ...] = (), engine_factory=None, max_engines: int = 1):
         """extra_engines (r4): further handles with the SAME weights (one workspace each).  Consecutive batches then
         alternate over [engine, *extra_engines], each on its own HIP stream, so that independent batches overlap on the
         device — a batch's HBM-bound kernels run beside another batch's matrix-bound ones, launch tails fill, and at small
         batches (BASELINE configs[1]: 32 windows) the under-filled chip takes two launches at once.  Results are the same
-        bits: a window's result does not depend on the batch or the handle it runs in."""
+        bits: a window's result does not depend on the batch or the handle it runs in.
+        engine_factory / max_engines (r5): instead of handing in ready handles, let the runner CREATE further handles the first
+        time a run has more than one batch — and only while the device keeps a reserve free afterwards (each handle is a full
+        copy of the weights plus a workspace for `batch_size` windows: two of them created up front could take most of the
+        then-free HBM before the embedding side, torch or RCCL had allocated anything).  A handle that cannot be
+        created is simply not used."""
         self.engine = engine
         self.engines = (engine,) + tuple(extra_engines)
+        self._factory = engine_factory
+        self._max_engines = max(int(max_engines), len(self.engines))
+        self._owned = []                 # handles this runner created (closed by close())
         self._streams = None
         self.sample_rate = sample_rate
         self.duration = duration
@@ -72,6 +80,33 @@ class WindowRunner:
         # embedding model needs one 400-sample fbank frame (speaker_verification.py:677-691)
         self.min_num_samples = 400
         self.min_num_frames = math.ceil(self.num_frames * self.min_num_samples / self.window)
+
+    RESERVE_BYTES = 32 << 30             # HBM that must stay free after a further handle is created (or a quarter of the device)
+
+    def _grow(self, device) -> None:
+        """create further engine handles up to max_engines, each only if free HBM - its size stays above the reserve"""
+        while self._factory is not None and len(self.engines) < self._max_engines:
+            free, total = torch.cuda.mem_get_info(device)
+            need = int(self.engine.workspace_bytes)
+            if free - need < max(self.RESERVE_BYTES, total // 4):
+                self._max_engines = len(self.engines)
+                break
+            try:
+                e = self._factory()
+            except Exception:            # MemoryError / DznError: run on the handles that exist
+                self._max_engines = len(self.engines)
+                break
+            self._owned.append(e)
+            self.engines = self.engines + (e,)
+            self._streams = None
+
+    def close(self) -> None:
+        """release the handles this runner created (their weights and workspaces) — not the caller's engine"""
+        for e in self._owned:
+            e.close()
+        self.engines = tuple(e for e in self.engines if e not in self._owned)
+        self._owned = []
+        self._streams = None
 
     def num_windows(self, num_samples: int) -> int:
         n, last = window_plan(num_samples, self.window, self.step)
@@ -114,6 +149,8 @@ class WindowRunner:
         bs = max(1, -(-C // nb))
         if hook is not None:
             hook(completed=0, total=C)
+        if nb > 1 and hook is None and len(self.engines) < self._max_engines:
+            self._grow(wave.device)
         multi = len(self.engines) > 1 and hook is None and nb > 1
         cur = torch.cuda.current_stream(wave.device)
         if multi:

@@ -25,7 +25,8 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
          ws_init=False, a_rowoff=None, c_rowoff=None, lda=None, kc=0, ldk=0, ldw=None, ldc=None,
          ldws=0, act=0, alpha=1.0, post_relu=False, nz=1, zdiv=1, zs=None, precision=0,
          W16=None, W3=None, a_planes=None, ln_stats=None, ln_colsum=None, W2h=None, col_scale=None,
-         a_amax=None, c_amax=None, amax_unit=None, want_row_stats=False, stat_eps=1e-5):
+         a_amax=None, c_amax=None, amax_unit=None, want_row_stats=False, stat_eps=1e-5, mx=False, Wmx=None,
+         col_scale_mx=None):
     """C = epilogue(A @ W^T); see dzn_gemm_desc.  A: [M, K] (or raw buffer with lda / rowoff),
     W: [N, K] fp32 (and optionally W16 bf16)."""
     lib = _lib.load()
@@ -74,7 +75,11 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
         W2h, col_scale = split_weights_h2(W.reshape(-1, K))
         if a_amax is None:      # one |max| for the whole tensor, replicated for every z scale unit
             a_amax = amax(A).repeat(max(1, nz // max(zdiv, 1)))
+    if mx and Wmx is None:          # DZN_PREC_F16 with fp8 cross terms (csrc/gemm_mx.hip)
+        assert precision == _lib.DZN_PREC_F16 and K % 32 == 0 and ldw == K and W.is_contiguous()
+        Wmx, col_scale_mx = split_weights_mx(W.reshape(-1, K))
     d.W2h, d.col_scale, d.a_amax, d.c_amax = _p(W2h), _p(col_scale), _p(a_amax), _p(c_amax)
+    d.Wmx, d.col_scale_mx = _p(Wmx), _p(col_scale_mx)
     # one scale unit for the whole tensor unless told otherwise (engines use one unit per window)
     d.amax_unit = int(amax_unit) if amax_unit is not None else (max(M, 1) if nz == 1 else 0)
     stats = None
@@ -107,6 +112,18 @@ def split_weights_h2(W):
     sc = torch.empty((rows,), device=W.device, dtype=torch.float32)
     check(lib.dzn_op_split_weights_h2(_p(W), rows, K, W.stride(0), _p(out), _p(sc), _stream()),
           what="dzn_op_split_weights_h2")
+    return out, sc
+
+
+def split_weights_mx(W):
+    """planes of the reduced-precision contraction (DZN_PREC_F16, csrc/gemm_mx.hip): (uint8 [rows, K // 32, 128], col_scale f32 [rows])"""
+    lib = _lib.load()
+    assert W.is_cuda and W.dtype == torch.float32 and W.dim() == 2 and W.shape[1] % 32 == 0
+    rows, K = W.shape
+    out = torch.empty((rows, K // 32, 128), device=W.device, dtype=torch.uint8)
+    sc = torch.empty((rows,), device=W.device, dtype=torch.float32)
+    check(lib.dzn_op_split_weights_mx(_p(W), rows, K, W.stride(0), _p(out), _p(sc), _stream()),
+          what="dzn_op_split_weights_mx")
     return out, sc
 
 

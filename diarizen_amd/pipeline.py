@@ -120,9 +120,11 @@ class DiariZenPipeline:
         the WeSpeaker checkpoint.  `seg_state` / `emb_state` / `config` let callers (tests, bench)
         inject in-memory weights instead of files.
         num_streams (r4): engine handles that consecutive batches of windows alternate over, each on its own HIP stream
-        (inference.WindowRunner extra_engines): independent batches overlap on the device — +2.6 % on the 30-min workload,
+        (inference.WindowRunner): independent batches overlap on the device — +2.6 % on the 30-min workload,
         +44 % at 32-window batches (profiles/r4_*), same bits.  Each extra handle costs one more copy of the weights and a
-        workspace for `batch_size` windows; 1 = the single-stream engine of r1-r3."""
+        workspace for `batch_size` windows, so (r5) it is an UPPER bound: the further handles are created lazily, the first time
+        a recording has more than one batch, and only while a reserve of HBM stays free (a short recording never pays for
+        them); `close()` releases them.  1 = the single-stream engine of r1-r3."""
         hub = Path(diarizen_hub) if diarizen_hub is not None else None
         if config is None:
             with open(hub / "config.toml", "rb") as f:
@@ -154,14 +156,18 @@ class DiariZenPipeline:
         self.engine = Engine(self.segmentation_model.cfg, seg_state, RESNET34, emb_state,
                              max_batch=self.batch_size, max_samples=window, precision=precision,
                              device=self.device)
-        self.extra_engines = tuple(Engine(self.segmentation_model.cfg, seg_state, RESNET34, emb_state, max_batch=self.batch_size,
-                                          max_samples=window, precision=precision, device=self.device)
-                                   for _ in range(max(0, int(num_streams) - 1)))
+        # further handles are created by the runner the first time a recording needs more than one batch, and only against a
+        # memory reserve (inference.WindowRunner._grow); the factory keeps the host state dicts alive for that
+        seg_cfg = self.segmentation_model.cfg
+
+        def _more():
+            return Engine(seg_cfg, seg_state, RESNET34, emb_state, max_batch=self.batch_size, max_samples=window,
+                          precision=precision, device=self.device)
         self.segmentation_model.load_state_dict(seg_state).bind(self.engine)
         self._embedding = SpeakerEmbedding(engine=self.engine)
         self._runner = WindowRunner(self.engine, self.seg_duration, self.segmentation_step,
                                     self.batch_size, median_size=11 if self.apply_median_filtering else 0,
-                                    exclude_overlap=True, extra_engines=self.extra_engines)
+                                    exclude_overlap=True, engine_factory=_more, max_engines=max(1, int(num_streams)))
         assert self.segmentation_model.specifications.powerset is True
 
         # ---- clustering (same [clustering.args] keys as the reference) ----
@@ -183,6 +189,16 @@ class DiariZenPipeline:
         self.rttm_out_dir = rttm_out_dir
         self.device_postprocess = True      # speaker counting / reconstruction aggregations on the device (row f2)
         self.timings: Dict[str, float] = {}
+
+    @property
+    def extra_engines(self):
+        """the further engine handles that exist right now (created lazily by the runner)"""
+        return tuple(self._runner.engines[1:])
+
+    def close(self) -> None:
+        """release every device allocation of this pipeline (engine handles, their weights and workspaces)"""
+        self._runner.close()
+        self.engine.close()
 
     # ------------------------------------------------------------------ construction
     @classmethod

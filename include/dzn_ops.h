@@ -112,6 +112,12 @@ typedef struct dzn_gemm_desc {
    * only multiplies by rstd — C = rstd * ((x - mean) W'^T) + bias, LayerNorm as defined, instead of the folded form
    * rstd * (x W'^T - mean colsum), whose two terms cancel to the size of the rounding error when |mean| >> std(x). */
   int32_t ln_centered;
+  /* DZN_PREC_F16 (r5): the reduced-precision contraction of csrc/gemm_mx.hip — fp16 hi*hi plus the two cross terms in fp8 on the
+   * block-scaled matrix instruction.  Wmx = planes from dzn_op_split_weights_mx ([rows][K/32][128 B]: fp16 hi | fp8 hi, fp8 lo of
+   * w * 2^e_row), col_scale_mx[n] = 2^-e_row; needs a_amax like the fp16 two-term form.  Either NULL -> the single-term fp16
+   * kernel on the leading plane of W2h (r2-r4's DZN_PREC_F16 arithmetic, kept for the positional conv and the ResNet trunk). */
+  const void* Wmx;
+  const float* col_scale_mx;
 } dzn_gemm_desc;
 
 /* (r4) One BasicBlock of the 32-channel ResNet stage in one kernel (csrc/resblock_fused.hip):
@@ -138,6 +144,14 @@ int dzn_op_split_weights(const float* W, int64_t rows, int32_t K, int64_t ldw, v
  * W * 2^e_row with max|row| in [2^14, 2^15), col_scale f32 [rows] = 2^-e_row. */
 int dzn_op_split_weights_h2(const float* W, int64_t rows, int32_t K, int64_t ldw, void* W2h, float* col_scale,
                             void* stream);
+
+/* planes of the reduced-precision contraction (DZN_PREC_F16, csrc/gemm_mx.hip): Wmx = 128 bytes per (row, 32 k) = 4 * rows * K
+ * bytes — fp16 of w * 2^e_row (64 B, fragment order) then four 16-B slots [fp8 e4m3 of w * 2^e_row x 8 | fp8 of the fp16
+ * remainder * 2^11 x 8]; max|row| * 2^e_row in [2^7, 2^8); col_scale f32 [rows] = 2^-e_row. */
+int dzn_op_split_weights_mx(const float* W, int64_t rows, int32_t K, int64_t ldw, void* Wmx, float* col_scale,
+                            void* stream);
+/* tests / tuning: force one tile shape of csrc/gemm_mx.hip ("128x128", "128x64"; "auto" / NULL = the shape rule) */
+int dzn_op_set_gemm_mx_cfg(const char* cfg);
 
 /* tuning knob (scripts/bench_gemm_h2.py): force one tile configuration of csrc/gemm_split.hip for the calls that
  * follow ("128x128", "256x128s3", ...; "auto" / NULL = the shape heuristic).  Same effect as the DZN_GEMM_CFG

@@ -17,7 +17,11 @@ from testkit.synth import synth_recording
 from testkit.weights import emb_state_dict, turn_taking_state_dict
 
 backend = os.environ.get("DZN_TEST_BACKEND", "nccl")
-dev = torch.device("cuda", 0)
+# one device per rank wherever the box has them (then `nccl` IS a real multi-rank RCCL job); ranks share device 0 only
+# on a box with fewer devices than ranks (RCCL refuses duplicate devices there: the test stages that run through gloo)
+_world = int(os.environ.get("WORLD_SIZE", "1"))
+_local = int(os.environ.get("LOCAL_RANK", "0"))
+dev = torch.device("cuda", _local if torch.cuda.device_count() >= _world else 0)
 torch.cuda.set_device(dev)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 if backend == "nccl":
@@ -52,7 +56,7 @@ if rank == 0:
     assert seg.shape[0] == C, (seg.shape, C)
     assert torch.equal(seg.cpu(), full.segmentations.cpu()), "sharded decisions differ"
     assert torch.equal(emb.cpu(), full.embeddings.cpu()), "sharded embeddings differ"
-    print(f"DIST_OK backend={backend} world={world} windows={C}")
+    print(f"DIST_OK backend={backend} world={world} windows={C} devices={min(world, torch.cuda.device_count())}")
 dist.barrier()
 eng.close()
 

@@ -1,7 +1,7 @@
 """(e) multi-GPU path on real hardware before an 8-GPU node sees it: the window sharding + padded all-gather of
-diarizen_amd/dist.py through the `nccl` backend (RCCL on ROCm).  World size 1 always; world size 2 with both ranks on
-the single visible GPU when RCCL accepts that (it may refuse duplicate devices — then the 2-rank run uses gloo over the
-same GPU results, and the RCCL path stays covered at world size 1)."""
+diarizen_amd/dist.py through the `nccl` backend (RCCL on ROCm).  World size 1 always; world size 2 on two devices
+through RCCL wherever the box has them (a failure there fails the test); on a 1-GPU box both ranks share the device, RCCL
+refuses duplicate devices, and the 2-rank run stages through gloo (the RCCL path then stays covered at world size 1)."""
 import os
 import subprocess
 import sys
@@ -30,8 +30,17 @@ def test_window_shard_gather_rccl_world1(built_lib, gpu):
     assert "DIST_RTTM_OK backend=nccl world=1" in r.stdout
 
 
-def test_window_shard_gather_two_ranks_one_device(built_lib, gpu):
+def test_window_shard_gather_two_ranks(built_lib, gpu):
+    """two ranks.  On a box with >= 2 devices each rank takes its own (tests/_dist_worker.py: LOCAL_RANK) and the all-gather
+    MUST run on RCCL — a failure there is a failure of the N > 1 path, never papered over by gloo.  On a
+    1-GPU box RCCL refuses the duplicate device; only then both ranks share device 0 and stage through gloo."""
+    import torch
     r = _run(2, "nccl", 29612)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and "DIST_OK backend=nccl world=2" in r.stdout and "devices=2" in r.stdout, \
+            (r.stdout[-2000:], r.stderr[-3000:])
+        assert "DIST_RTTM_OK backend=nccl world=2" in r.stdout
+        return
     if r.returncode == 0 and "DIST_OK backend=nccl world=2" in r.stdout:
         assert "DIST_RTTM_OK backend=nccl world=2" in r.stdout
         return

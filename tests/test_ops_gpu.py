@@ -190,6 +190,75 @@ def test_gemm_f16_single_term(built_lib, gpu, M, N, K):
     assert ((out3 - ref).abs() / scale).max().item() < 2e-6           # the two-term mode on the same data, for scale
 
 
+@pytest.mark.parametrize("M,N,K,cfg", [(300, 200, 512, "auto"), (257, 64, 96, "auto"), (515, 384, 1056, "128x128"), (515, 384, 1056, "128x64"),
+                                       (1000, 1024, 1024, "128x128"), (129, 96, 32, "128x128"), (640, 640, 448, "auto")])
+def test_gemm_mx_cross_terms(built_lib, gpu, M, N, K, cfg):
+    """(r5) DZN_PREC_F16 as csrc/gemm_mx.hip computes it: fp16 hi*hi + the two cross terms in fp8 e4m3 on
+    v_mfma_scale_f32_32x32x64_f8f6f4 (block scales 2^0 / 2^-11).  (a) Against testkit/mx_emulation.py — the same operands
+    rounded the same way, exact accumulation: agreement at fp32-accumulation level pins the device's operand layout, the scale
+    bytes, the fp8 conversion and the plane packing all at once (K % 64 == 32 exercises the half-filled last group, N % 64 != 0
+    and M % 128 != 0 the tile edges, both tile shapes are forced).  (b) Against the plain float64 product: the error must sit
+    near 2^-15 of sum |a||w| — an order of magnitude under the single-term mode on the same data, which is what brings the
+    segmentation model inside SURVEY 8d's reduced bar."""
+    import ctypes
+    from diarizen_amd import _lib, ops
+    from testkit.mx_emulation import mx_gemm, single_term_gemm
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * 3.0 * torch.exp(0.5 * torch.randn(M, 1, generator=g))
+    W = torch.randn(N, K, generator=g) * 0.05 * torch.exp(torch.randn(N, 1, generator=g))
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    lib = _lib.load()
+    lib.dzn_op_set_gemm_mx_cfg(cfg.encode())
+    try:
+        out = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), R=R.to(gpu), precision=4, mx=True).cpu().double()
+        out1 = ops.gemm(A.to(gpu), W.to(gpu), bias=bias.to(gpu), R=R.to(gpu), precision=4).cpu().double()
+    finally:
+        lib.dzn_op_set_gemm_mx_cfg(b"auto")
+    tail = bias.double() + R.double()
+    emu = mx_gemm(A, W) + tail
+    ref = A.double() @ W.double().T + tail
+    scale = A.double().abs() @ W.double().abs().T + 1.0
+    e_emu = ((out - emu).abs() / scale).max().item()
+    e = (out - ref).abs() / scale
+    e1 = (out1 - ref).abs() / scale
+    print(f"[mx {M}x{N}x{K} {cfg}] vs emulation {e_emu:.2e}; vs float64 max {e.max().item():.2e} rms {e.pow(2).mean().sqrt().item():.2e}; "
+          f"single term max {e1.max().item():.2e} rms {e1.pow(2).mean().sqrt().item():.2e}")
+    assert e_emu < 2e-6                                   # the same rounded operands, fp32 accumulation
+    assert e.max().item() < 2.0 ** -13 and e.pow(2).mean().sqrt().item() < 2.0 ** -15
+    assert e.pow(2).mean().sqrt().item() * 8 < e1.pow(2).mean().sqrt().item()
+    assert ((single_term_gemm(A, W) + tail - out1).abs() / scale).max().item() < 2e-6   # the single-term path is still there
+
+
+def test_gemm_mx_layernorm_folded_and_row_stats(built_lib, gpu):
+    """the MX contraction behind the descriptor's other features: a folded LayerNorm (raw rows in, statistics applied in the
+    epilogue), GELU, per-row statistics of the output for the next folded norm, the |max| tracker of the output"""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 700, 320, 1024
+    x = torch.randn(M, K, generator=g) * 2.0 + 0.7
+    gamma = 1.0 + 0.1 * torch.randn(K, generator=g)
+    beta = 0.1 * torch.randn(K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.03
+    b = torch.randn(N, generator=g)
+    Wf = W * gamma
+    bf = b + W @ beta
+    csum = Wf.sum(1)
+    stats = ops.row_stats(x.to(gpu), K, 1e-5)
+    camax = torch.zeros(1, device=gpu)
+    out, st = ops.gemm(x.to(gpu), Wf.to(gpu), bias=bf.to(gpu), ln_stats=stats, ln_colsum=csum.to(gpu), act=1, precision=4, mx=True,
+                       want_row_stats=True, c_amax=camax)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5) @ W.double().T + b.double())
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"[mx folded LN] max err {err:.2e}")
+    assert err < 4e-3          # operands rounded at ~2^-15 of sum |x||w| (~60 here), amplified by rstd
+    mu, var = out.cpu().double().mean(1), out.cpu().double().var(1, unbiased=False)
+    assert (st.cpu()[:, 0].double() - mu).abs().max().item() < 1e-4
+    assert (st.cpu()[:, 1].double() - (var + 1e-5).rsqrt()).abs().max().item() / (var + 1e-5).rsqrt().max().item() < 1e-4
+    assert abs(camax.item() - out.abs().max().item()) < 1e-6
+
+
 def test_gemm_bf16(built_lib, gpu):
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(9)
