@@ -159,3 +159,15 @@ def test_reference_get_embeddings_drives_the_embedding_facade(monkeypatch):
     assert [c[0][0] for c in calls[n0:]] == [6, 6, 6, 2]                  # ceil(5 * 4 / 6) batches of (chunk, speaker) pairs
     assert all(c[1][1] == 1 for c in calls[n0:])                          # one mask per row, as the reference calls it
     assert np.abs(emb - g["emb"][:C]).max() <= 1e-5 * np.abs(g["emb"][:C]).max()
+
+
+def test_product_host_stage_equals_reference_run_at_30min_scale():
+    """(r5) ONE run of the product's run_host_stage (scipy / numpy backends: no device here) against ONE run
+    of the reference's own `AgglomerativeClustering` + reconstruct + Binarize on the same arrays — the device outputs of the
+    bench's 30-min recording, 2241 windows = 8964 (window, speaker) rows, 2415 training embeddings: past the sizes at which the
+    product switches to its vectorised assignment shortcut, and (with a device: tests/test_pipeline_gpu.py) to its device
+    linkage and device cdist.  tests/_host30.py: hard clusters, counts and every frame whose selection is defined by the data are
+    exact; frames cut through equal activations may differ only as another valid selection (np.argsort tie order)."""
+    from tests._host30 import run_and_check
+    res = run_and_check(device=None, linkage_backend="scipy", cdist_backend="scipy")
+    print(res)

@@ -247,3 +247,16 @@ def test_eval_scp_harness_on_the_fixture(built_lib, gpu, tmp_path):
     assert (out / "sessB.rttm").read_text() == gold.replace("EN2002a", "sessB")
     assert res["der_files"]["sessB"]["total"] < res["der_files"]["sessA"]["total"]       # the UEM cut sessB's scored speech
     assert (out / "result_collar0").exists()
+
+
+@pytest.mark.parametrize("backends", ["auto", "hip"])
+def test_host_stage_30min_device_backends_equal_reference_golden(built_lib, gpu, backends):
+    """(r5, VERDICT r4 item 4) the same golden as tests/test_host_ref.py::test_product_host_stage_equals_reference_run_at_30min_scale,
+    with the product's DEVICE backends on: centroid linkage on the device (2415 training embeddings >= HIP_LINKAGE_MIN), float64
+    cosine scores on the device (8964 rows >= HIP_CDIST_MIN), counting / cluster activations on the device.  `hip` forces them."""
+    import json
+    from tests._host30 import run_and_check
+    res = run_and_check(device=gpu, linkage_backend=backends, cdist_backend=backends)
+    print(json.dumps(res))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(res, open(f"gpurun_out/host30_{backends}.json", "w"))
