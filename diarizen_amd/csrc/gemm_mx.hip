@@ -442,11 +442,12 @@ extern "C" int dzn_op_set_gemm_mx_cfg(const char* cfg) {
 // the reduced-precision contraction: caller (launch_gemm_split) has checked K % 32 == 0, kc % 32 == 0, ldw == K
 int launch_gemm_mx(const dzn_gemm_desc& d, hipStream_t s) {
   if (!d.Wmx || !d.col_scale_mx || !d.a_amax || d.w_z0 || d.w_z1) return DZN_E_INVALID;
-  const int cols128 = (d.N + 127) / 128 * 128, cols64 = (d.N + 63) / 64 * 64;
-  // the tile rules of gemm_split.hip: narrow tiles for short K (epilogue-bound launches), small launches and widths that
-  // 64-wide tiles pad much less
-  const bool narrow = d.N <= 64 || d.K <= 512 || cols64 * 9 < cols128 * 8 ||
-                      (int64_t)((d.M + 127) / 128) * (cols128 / 128) * (d.nz > 0 ? d.nz : 1) < 448;
+  const int cols128 = (d.N + 127) / 128 * 128;
+  // 128 x 128 tiles unless the launch is narrow or too small to fill the chip with them.  gemm_split.hip's other rules — narrow
+  // tiles for K <= 512 and for widths that 64-wide tiles pad less — do NOT carry over: measured at M = 223 839 (first GPU run of
+  // the round, profiles/r5_gemm_mx_first_bench.txt) the wide tile wins on all of them (N 1024 K 256: 186 vs 166 TFLOP/s, K 480:
+  // 243 vs 214, N 320 K 1024: 256 vs 244): a 32 x 64 wavefront tile has half the MFMAs per converted A value.
+  const bool narrow = d.N <= 64 || (int64_t)((d.M + 127) / 128) * (cols128 / 128) * (d.nz > 0 ? d.nz : 1) < 448;
   const char* force = g_mx_force();
   if (force && !strcmp(force, "128x64")) return launch_mx_cfg<128, 64, 4, 1, 2, 3>(d, s);
   if (force && !strcmp(force, "128x128")) return launch_mx_cfg<128, 128, 4, 1, 2, 2>(d, s);

@@ -354,3 +354,12 @@ def test_fp8_cross_terms_keep_the_reduced_mode_inside_its_bar_on_the_tiny_model(
     assert got["f32h"] <= 1e-3                       # the emulation of the shipped arithmetic is fp32-grade
     assert got["fp8x"] <= 5e-2 / 5 and got["fp8x"] * 5 < got["f16"]
     assert min(got["w16"], got["a16"]) > got["fp8x"] * 3
+
+
+def test_clustering_port_equals_reference_run_at_30min_scale():
+    """oracle/clustering_port.py (what bench.py's cpu_baseline runs where /root/reference is absent) against the hard clusters
+    the REFERENCE's own AgglomerativeClustering produced on the same 8964 rows (tests/golden/host30.npz)."""
+    from oracle.clustering_port import agglomerative
+    g = np.load(os.path.join(GOLD, "host30.npz"))
+    hard = agglomerative(g["emb"], g["seg"], 0.1, 13, 1, 20)
+    assert np.array_equal(hard.astype(np.int64), g["hard_clusters"].astype(np.int64))

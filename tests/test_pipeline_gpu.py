@@ -150,10 +150,11 @@ max_iters = 20
 
 
 def test_der_between_arithmetic_modes(built_lib, gpu):
-    """BASELINE configs[4] groundwork: the in-tree DER scorer (diarizen_amd/der.py: collar 0, overlap scored, optimal
-    mapping) on the RTTMs of the same recording in the three fp32 modes (must be IDENTICAL, DER 0) and in the reduced
-    bf16 mode (reported; with the seeded stress weights only a loose bound is asserted — the acceptance bar of
-    SURVEY §8d, |dDER| <= 0.1 abs, is for trained weights scored against the AMI reference RTTM)."""
+    """BASELINE configs[4]: the in-tree DER scorer (diarizen_amd/der.py: collar 0, overlap scored, optimal mapping) on the RTTMs
+    of the same recording in the three fp32 modes (must be IDENTICAL, DER 0) and in the reduced `f16` mode, which (r5: fp16
+    hi*hi + fp8 cross terms, csrc/gemm_mx.hip) is held to SURVEY 8d's reduced bar: |dDER| <= 0.1 abs (percentage points)
+    against the fp32 RTTM — on the seeded stress weights, whose margins are far smaller than trained weights'.  The quarantined
+    bf16 mode (DZN_TUNING builds) is only reported."""
     import copy
     from diarizen_amd.audio import first_channel_16k
     from diarizen_amd.configs import get_seg_config
@@ -180,7 +181,8 @@ def test_der_between_arithmetic_modes(built_lib, gpu):
         assert d["der"] <= 0.6
     d16 = der_rttm(gold, rttm["f16"], "EN2002a")
     print("f16 vs fp32 RTTM on EN2002a_30s (seeded stress weights):", {k: round(v, 4) for k, v in d16.items() if k != "mapping"})
-    assert d16["der"] <= 0.6
+    assert d16["der"] * 100.0 <= 0.1, d16          # SURVEY 8d reduced bar: DER delta <= 0.1 abs
+    os.makedirs("gpurun_out", exist_ok=True)
     if os.path.isdir("gpurun_out"):
         import json
         with open("gpurun_out/der_reduced_modes.json", "w") as f:

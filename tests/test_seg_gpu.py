@@ -143,15 +143,13 @@ def test_seg_f16_within_tolerance(built_lib, gpu, name):
 
 
 @pytest.mark.parametrize("name", ["tiny_ln", "wavlm_large_s80_md", "wavlm_base_s80_md"])
-def test_seg_f16_on_the_turn_taking_fixtures_is_reported_against_the_reduced_bar(built_lib, gpu, name):
-    """the reduced mode on the NON-degenerate reference goldens (seg_tt_*: many classes, ~15 transitions
-    per window, top-2 margins down to 1e-4).  SURVEY 8d's reduced bar is max |dlogp| <= 5e-2 and argmax >= 99.5 %.  On these
-    seeded stress weights (calibrated classifier rows of norm ~20 on a 9 % time-varying feature component) the single-term
-    mode does NOT reach the log-prob part of the bar — profiles/r4_f16_sensitivity.json: the error is spread over every
-    contraction class and only two terms everywhere (= f32h) gets under 5e-2 — so this test (a) holds the mode to what it
-    does deliver: argmax agreement >= 99.4 % and max |dlogp| <= 0.3, (b) writes the measured figures and `meets_survey_8d_bar`
-    to gpurun_out/f16_turn_taking_bar.json, which bench.py's reduced_precision_mode.parity quotes.  It never passes by
-    pretending the bar is met."""
+def test_seg_f16_meets_the_reduced_bar_on_the_turn_taking_fixtures(built_lib, gpu, name):
+    """The reduced mode on the NON-degenerate reference goldens (seg_tt_*: many classes, ~15 transitions per window, top-2 margins
+    down to 1e-4; base-s80 at BASELINE configs[1]'s full size, 32 windows).  SURVEY 8d's reduced bar: max |dlogp| <= 5e-2, argmax
+    >= 99.5 %.  r2-r4's single-term fp16 mode measured 0.15 / 0.18 here and a test REPORTED that; since r5 every linear
+    contraction of the segmentation model keeps its two cross terms in fp8 (csrc/gemm_mx.hip) and this test ASSERTS the bar.
+    The measured figures go to gpurun_out/f16_turn_taking_bar.json (committed as part of profiles/r5_reduced_mode_parity.json,
+    which bench.py quotes)."""
     import json
     from diarizen_amd.configs import get_seg_config
     from diarizen_amd.engine import Engine
@@ -177,7 +175,29 @@ def test_seg_f16_on_the_turn_taking_fixtures_is_reported_against_the_reduced_bar
     allrec[name] = rec
     json.dump(allrec, open(path, "w"), indent=1)
     print(json.dumps(rec))
-    assert agree >= 0.994 and err <= 0.3, rec
+    assert err <= 5e-2 and agree >= 0.995, rec
+
+
+def test_seg_f16_single_term_switch_reproduces_the_r4_arithmetic(built_lib, gpu, monkeypatch):
+    """DZN_F16_MX=0 (read at dzn_create) switches the cross terms off: the engine then runs r2-r4's single-term contractions,
+    which is what keeps the r4 measurements (0.15 on this fixture) reproducible — and shows the cross terms are what meets the bar."""
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from testkit.weights import turn_taking_state_dict
+    from oracle.gen_golden import tt_windows
+    name = "wavlm_large_s80_md"
+    cfg = get_seg_config(name)
+    g = np.load(os.path.join(GOLD, f"seg_tt_{name}.npz"))
+    ref = torch.from_numpy(g["logp"])
+    wave = tt_windows(g["starts"].tolist(), int(g["N"]))
+    monkeypatch.setenv("DZN_F16_MX", "0")
+    eng = Engine(cfg, turn_taking_state_dict(cfg, int(g["weight_seed"])), max_batch=wave.shape[0], max_samples=int(g["N"]),
+                 precision="f16", device=gpu)
+    logp, _ = eng.segment(wave.to(gpu))
+    torch.cuda.synchronize()
+    err = (logp.cpu() - ref).abs().max().item()
+    print(f"[single-term f16, {name}] max |dlogp| = {err:.3f}")
+    assert 5e-2 < err <= 0.3
 
 
 def test_seg_batch_and_ragged_lengths(built_lib, gpu):
