@@ -96,6 +96,7 @@ class DznGemmDesc(C.Structure):
         ("stat_partial", C.c_void_p), ("stat_final", C.c_void_p), ("stat_C", C.c_int32), ("stat_eps", C.c_float),
         ("z_count", C.c_void_p), ("z_list", C.c_void_p), ("ln_centered", C.c_int32),
         ("Wmx", C.c_void_p), ("col_scale_mx", C.c_void_p),
+        ("amax_count", C.c_int32),
     ]
 
 
@@ -168,6 +169,7 @@ def load() -> C.CDLL:
     sig("dzn_op_split_weights_h2", i32, [vp, i64, i32, i64, vp, vp, vp])
     sig("dzn_op_split_weights_mx", i32, [vp, i64, i32, i64, vp, vp, vp])
     sig("dzn_op_set_gemm_mx_cfg", i32, [C.c_char_p])
+    sig("dzn_checked_status", i32, [vp, i32])
     sig("dzn_op_set_gemm_cfg", i32, [C.c_char_p])
     sig("dzn_op_amax", i32, [vp, i64, vp, vp])
     sig("dzn_op_split_rows", i32, [vp, vp, i64, i64, i32, vp])
@@ -190,7 +192,7 @@ EXPORTED = [
     "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_speaker_count", "dzn_cluster_activations", "dzn_debug_fetch", "dzn_embed_skip_stats", "dzn_num_ignored",
     "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid", "dzn_cdist_cosine",
     "dzn_vbx_create", "dzn_vbx_stats", "dzn_vbx_estep", "dzn_vbx_gamma", "dzn_vbx_destroy",
-    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_split_weights_mx", "dzn_op_set_gemm_mx_cfg", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_resblock32_fused", "dzn_op_resblock_ws", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",
+    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_split_weights_mx", "dzn_op_set_gemm_mx_cfg", "dzn_checked_status", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_resblock32_fused", "dzn_op_resblock_ws", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",
     "dzn_profile_enable", "dzn_profile_collect", "dzn_profile_reserve", "dzn_op_relpos_bucket",
 ]
 

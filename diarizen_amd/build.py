@@ -49,7 +49,22 @@ def _compile(src: Path, force: bool, hdr_mtime: float) -> Path:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
+def build_checked(force: bool = False, verbose: bool = False) -> Path:
+    """python -m diarizen_amd.build --checked: the same sources with -DDZN_CHECKED (csrc/checked.h: device-side bounds
+    assertions in the hand-scheduled kernels) into lib/libdzn_hip_checked.so, objects under build_checked/.  Select it with
+    DZN_HIP_LIB=<path> (scripts/run_checked.sh runs the GPU kernel / segmentation tests under it)."""
+    global OBJ, LIB
+    saved = (OBJ, LIB, list(FLAGS))
+    OBJ, LIB = ROOT / "build_checked", LIBDIR / "libdzn_hip_checked.so"
+    FLAGS.append("-DDZN_CHECKED")
+    try:
+        return build(force, verbose, harness=False)
+    finally:
+        OBJ, LIB = saved[0], saved[1]
+        FLAGS[:] = saved[2]
+
+
+def build(force: bool = False, verbose: bool = False, harness: bool = True) -> Path:
     OBJ.mkdir(exist_ok=True)
     LIBDIR.mkdir(exist_ok=True)
     srcs = sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp")))
@@ -67,7 +82,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
         if verbose:
             print(f"linked {LIB}")
-    build_c_harness(force, verbose)
+    if harness:
+        build_c_harness(force, verbose)
     return LIB
 
 
@@ -102,5 +118,8 @@ def build_c_harness(force: bool = False, verbose: bool = False):
 
 
 if __name__ == "__main__":
-    p = build(force="--force" in sys.argv, verbose=True)
+    if "--checked" in sys.argv:
+        p = build_checked(force="--force" in sys.argv, verbose=True)
+    else:
+        p = build(force="--force" in sys.argv, verbose=True)
     print(p)

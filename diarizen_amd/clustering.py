@@ -150,7 +150,7 @@ HIP_CDIST_MIN = 8192     # rows; below this scipy's single-core loop is faster t
 
 
 def _soft_clusters(embeddings: np.ndarray, centroids: np.ndarray, metric: str, backend: str = "auto",
-                   device: int = -1) -> np.ndarray:
+                   device: int = -1, active: Optional[np.ndarray] = None) -> np.ndarray:
     """2 - cdist(embeddings, centroids) (PA/pipelines/clustering.py:207-216).  From HIP_CDIST_MIN rows up, float32
     embeddings and the cosine metric go through csrc/linkage.hip's dzn_cdist_cosine (float64, same formula, in-order
     sums: agrees with scipy to 2e-15 and keeps identical rows identical, tests/test_ops_gpu.py); anything else is
@@ -162,11 +162,48 @@ def _soft_clusters(embeddings: np.ndarray, centroids: np.ndarray, metric: str, b
         from . import ops
         from ._lib import DznError
         try:
-            return 2 - ops.cdist_cosine(flat, centroids, device=device).reshape(C, S, -1)
+            soft = 2 - ops.cdist_cosine(flat, centroids, device=device).reshape(C, S, -1)
         except (DznError, MemoryError):
             if backend == "hip":
                 raise
+        else:
+            _exact_scores_for_tied_rows(embeddings, centroids, metric, soft, active)
+            return soft
     return 2 - cdist(flat, centroids, metric=metric).reshape(C, S, -1)
+
+
+def _exact_scores_for_tied_rows(embeddings: np.ndarray, centroids: np.ndarray, metric: str, soft: np.ndarray,
+                                active: Optional[np.ndarray] = None) -> None:
+    """(r5) Local speakers of ONE window with bit-identical embeddings — every inactive speaker and every speaker whose mask
+    samples to all-zero pooling weights gets seg_1's bias, and two speakers that are only ever active together
+    share a mask — make the window's constrained assignment an exact tie, which `linear_sum_assignment` breaks by the LAST BIT
+    of the scores (tests/golden/host30.npz: a 1e-15 perturbation of scipy's own scores moves ~330 active assignments, and an
+    active few-frame speaker that ties with an inactive one then lands in another cluster, which the RTTM shows).  The
+    reference's bits are scipy.cdist's, and scipy.cdist is row-independent (bit-identical for a row whatever else is in the
+    call), so the rows that have an identical twin in their window get scipy's own scores, computed once per distinct vector:
+    a few hundred rows at 30 min.  Windows in which a tied row belongs to an ACTIVE speaker (`active` [C, S]: the tie decides
+    where real activity goes) take scipy's scores for ALL their rows, so that the assignment solver sees exactly the
+    reference's matrix there (16 % of the rows of the 30-min fixture).  Every other row keeps the device's float64 scores
+    (2e-15 from scipy's, against margins of 1e-6).  In place."""
+    C, S, D = embeddings.shape
+    twin = np.zeros((C, S), dtype=bool)
+    for i in range(S):
+        for j in range(i + 1, S):
+            eq = (embeddings[:, i] == embeddings[:, j]).all(axis=-1)
+            twin[:, i] |= eq
+            twin[:, j] |= eq
+    ci, si = np.nonzero(twin)
+    if not len(ci):
+        return
+    rows = np.ascontiguousarray(embeddings[ci, si])
+    keys = rows.view(np.dtype((np.void, rows.dtype.itemsize * D))).ravel()
+    _, first, inv = np.unique(keys, return_index=True, return_inverse=True)
+    exact = 2 - cdist(rows[first], centroids, metric=metric)
+    soft[ci, si] = exact[inv]
+    if active is not None:
+        win = np.nonzero((twin & np.asarray(active, dtype=bool)).any(axis=1))[0]
+        if len(win):
+            soft[win] = 2 - cdist(embeddings[win].reshape(len(win) * S, D), centroids, metric=metric).reshape(len(win), S, -1)
 
 
 def _set_num_clusters(n, num_clusters, min_clusters, max_clusters):
@@ -274,7 +311,7 @@ class AgglomerativeClustering(_DeviceBackends):
         train = embeddings[ci, si]
         centroids = np.vstack([np.mean(train[train_clusters == k], axis=0) for k in range(K)])
         soft = _soft_clusters(embeddings, centroids, self.metric, self.cdist_backend,
-                              self.device)
+                              self.device, active=active_speakers(segmentations))
         hard = constrained_argmax(soft) if self.constrained_assignment else np.argmax(soft, axis=2)
         return hard, soft, centroids
 
@@ -409,7 +446,7 @@ class VBxClustering(_DeviceBackends):
                        device=self.device)
         centroids = q[:, sp > 1e-7].T @ train.reshape(-1, D)            # unnormalised: cosine follows
         soft = _soft_clusters(embeddings, centroids, self.metric, self.cdist_backend,
-                              self.device)
+                              self.device, active=active_speakers(segmentations))
         hard = constrained_argmax(soft) if self.constrained_assignment else np.argmax(soft, axis=2)
         _, hard = np.unique(hard, return_inverse=True)
         return hard.reshape(C, S), soft, centroids

@@ -13,8 +13,11 @@
 //     one 16-byte run of the [d][key] plane — the P fragment needs no data movement at all.
 //   * planes are [64][128 B] images with the 16-B slot XOR ((row >> 1) & 7): every fragment is one
 //     conflict-free ds_read_b128.
+#include "checked.h"
 #include "common.h"
 #include "split.h"
+
+DZN_CHECKED_TU(attention_split)
 
 namespace {
 
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
   const float s_inv = op_inv * op_inv;          // scores leave the MFMA scaled by op_scale^2
   constexpr float PSHIFT = NP == 2 ? 14.0f : 0.0f;   // p' = 2^PSHIFT p
   // ---- Q fragments (B operand of S^T = K Q^T): lane (query lr, group lq) holds d = 32 half + 8 lq .. +7 ----
+  DZN_CHECK(qt * 64 < L && j < h && (!BIAS || (H >= 0 && H < Htot)), 0x603, qt);              // query tile / head inside the launch
   const int q_row = qt * 64 + wave * 16 + lr;
   const bool q_ok = q_row < L;
   u32x4 qf[2][NP];
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
       {
         const int key = item >> 3, slot = item & 7;
         const int off = key * 128 + ((slot ^ ((key >> 1) & 7)) << 4);
+        DZN_CHECK(key < 64 && off + 16 <= ATT_PLANE, 0x601, off);                                  // staged K chunk inside its plane
         split_np(rk[i][0], rk[i][1], op_scale, pf);
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(sK + p * ATT_PLANE + off) = pf[p];
@@ -151,6 +156,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
       {
         const int d = item & 63, grp = item >> 6;
         const int off = d * 128 + ((grp ^ ((d >> 1) & 7)) << 4);
+        DZN_CHECK(grp < 8 && off + 16 <= ATT_PLANE, 0x602, off);                                   // staged V group inside its plane
         split_np(rv[i][0], rv[i][1], op_scale, pf);
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(sV + p * ATT_PLANE + off) = pf[p];

@@ -23,8 +23,11 @@
 //     multiplies while the other computes activations.
 #include <cstdlib>
 
+#include "checked.h"
 #include "common.h"
 #include "split.h"
+
+DZN_CHECKED_TU(frontend_fused)
 
 namespace {
 
@@ -58,16 +61,22 @@ struct FusedArgs {
 // its MFMA phase (conv1 from LDS), on every SIMD, by construction.  Measured with the phases switched off one at a time
 // (DZN_CONV01_ABL, scripts/probe_kernel_class.py, 374 windows): VALU alone 7.8 ms, MFMA alone 8.9 ms, both 13.9 ms with
 // two independent 256-thread workgroups per CU (PP = false: their phases overlap only by chance).
-template <bool PP>
+// UF (r5): conv0 frames a wavefront carries through the VALU phase at once (independent 10-FMA -> LayerNorm -> erf chains that
+// interleave); 4 = r2-r4.
+template <bool PP, int UF = 4>
 __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-  constexpr int GROUP_LDS = (2 * FF_PLANE + (int)sizeof(float) * (5 * (FF_FR - 1) + 10 + 6) + (int)sizeof(float2) * FF_FR + 15) / 16 * 16;
+  constexpr int GROUP_LDS = (2 * FF_PLANE + (int)sizeof(float) * (5 * (FF_FR - 1) + 10 + 6 + 112) + (int)sizeof(float2) * FF_FR + 15) / 16 * 16;
   const int grp = PP ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
   unsigned char* smem = smem_all + grp * GROUP_LDS;
   unsigned char* pl0 = smem;                                   // hi plane  [FF_FR][64 ch] fp16, slots swizzled
   unsigned char* pl1 = smem + FF_PLANE;                        // lo plane
   float* sx = reinterpret_cast<float*>(smem + 2 * FF_PLANE);   // normalised samples of the strip
   float2* sst = reinterpret_cast<float2*>(sx + (5 * (FF_FR - 1) + 10 + 6));   // (mean, rstd) per conv0 frame
+  // (r5) the 110 LayerNorm-statistics coefficients live in LDS (behind sst): as kernel-argument scalars they needed more SGPRs
+  // than a wavefront has (r2-r4: 153 spilled SGPRs, ~200 v_readlane reloads in the statistics loop; now 0 —
+  // profiles/r5_conv01_resources.txt)
+  float* slnq = reinterpret_cast<float*>(sst + FF_FR);
 
   const int tid = threadIdx.x & 255, lane = tid & 63;  // thread / wavefront index inside the group
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,6 +94,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const F
   const float wrstd = a.wstats ? a.wstats[2 * b + 1] : 1.f;
   const float* wp = a.wave + (int64_t)b * a.N + (int64_t)f0 * 5;
   for (int i = tid; i < nsamp; i += 256) sx[i] = (wp[i] - wmean) * wrstd;
+  if (tid < 110) slnq[tid] = a.lnq[tid];
   __syncthreads();
   for (int f = tid; f < nfr; f += 256) {     // LayerNorm statistics from the 10 samples of the frame (see header)
     float xv[10];
@@ -93,10 +103,10 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const F
     float mu = 0.f, var = 0.f;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-      mu = fmaf(a.lnq[i], xv[i], mu);
+      mu = fmaf(slnq[i], xv[i], mu);
       float q = 0.f;
 #pragma unroll
-      for (int j = 0; j < 10; ++j) q = fmaf(a.lnq[10 + i * 10 + j], xv[j], q);
+      for (int j = 0; j < 10; ++j) q = fmaf(slnq[10 + i * 10 + j], xv[j], q);
       var = fmaf(q, q, var);     // lnq rows are the factor F of Q = F^T F: a sum of squares
     }
     sst[f] = make_float2(mu, 1.0f / sqrtf(fmaxf(var, 0.f) + a.eps));
@@ -126,7 +136,6 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const F
       for (int t = 0; t < 10; ++t) w0[t] = a.w0[ch * 10 + t];
       const float g0 = a.gamma0[ch], b0 = a.beta0[ch];
       const int cslot = lane >> 3, cbyte = (lane & 7) * 2;
-      constexpr int UF = 4;
       for (int fb = wave; fb < (a.abl == 1 ? 0 : FF_FR); fb += 4 * UF) {
         float o[UF];
 #pragma unroll
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const F
             const _Float16 hi = (_Float16)xs;
             const _Float16 lo = (_Float16)(xs - (float)hi);
             const int off = f * FF_ROW + ((cslot ^ ((f >> 1) & 7)) << 4) + cbyte;
+            DZN_CHECK(off + 2 <= FF_PLANE, 0x701, off);                                          // activation written inside its plane
             *reinterpret_cast<_Float16*>(pl0 + off) = hi;
             *reinterpret_cast<_Float16*>(pl1 + off) = lo;
           }
@@ -165,6 +175,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const F
       for (int jn = 0; jn < NI; ++jn) {
         const int n = wn * 80 + jn * 16 + lr;
         const u16* wpn = a.W2h + ((int64_t)n * KB + kblk) * 64 + lq * 8;
+        DZN_CHECK(n < a.N1p && kblk < KB, 0x703, kblk);                                              // weight fragment inside the planes
         wf[jn][0] = *reinterpret_cast<const u32x4*>(wpn);
         wf[jn][1] = *reinterpret_cast<const u32x4*>(wpn + 32);
       }
@@ -175,6 +186,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const F
       for (int i = 0; i < MI; ++i) {
         const int f = 2 * (wm * 64 + i * 16 + lr) + j;
         const int off = f * FF_ROW + (((kb * 4 + lq) ^ ((f >> 1) & 7)) << 4);
+        DZN_CHECK(f < FF_FR + 3 && off + 16 <= FF_PLANE, 0x702, f);                                  // conv1 fragment (frame 2 t + tap) inside the plane
         u32x4 af[2];
         af[0] = *reinterpret_cast<const u32x4*>(pl0 + off);
         af[1] = *reinterpret_cast<const u32x4*>(pl1 + off);
@@ -339,25 +351,30 @@ int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, co
     a.a_scale = ldexpf(1.0f, 15 - e);
     a.a_inv = ldexpf(1.0f, e - 15);
   }
-  const size_t group_lds = (2 * FF_PLANE + sizeof(float) * (5 * (FF_FR - 1) + 10 + 6) + sizeof(float2) * FF_FR + 15) / 16 * 16;
+  const size_t group_lds = (2 * FF_PLANE + sizeof(float) * (5 * (FF_FR - 1) + 10 + 6 + 112) + sizeof(float2) * FF_FR + 15) / 16 * 16;
   // two tiles per 512-thread workgroup with the phases in anti-phase: measured SLOWER (15.7 vs 13.7 ms per 374 windows,
   // profiles/r3_conv01_phase_probe.txt) — a phase that runs on ONE wavefront per SIMD is bound by its dependent chains
   // (VALU alone: 13.4 ms in this form, 7.8 ms when two workgroups share the SIMDs), so forcing the overlap costs more
   // than it hides.  Kept behind DZN_CONV01_PP=1 for the record; the default is two independent workgroups per CU.
   static const bool pp = getenv("DZN_CONV01_PP") != nullptr;
+  // frames per wavefront iteration of the VALU phase: 8 since r5 (22.03 -> 21.65 ms per 561-window launch; 4 = r2-r4's kernel;
+  // profiles/r5_conv01_probe.txt, which also re-measures the anti-phase form: 23.8 / 22.7 ms at 4 / 8 — still slower)
+  static const int uf = getenv("DZN_CONV01_UF") ? atoi(getenv("DZN_CONV01_UF")) : 8;
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_fused_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int ntile = (T1 + FF_BM - 1) / FF_BM;
   // algorithmic work: conv0 + conv1 flops; algorithmic HBM bytes: waveform in, conv1's raw output out
   const int pid = prof_begin(st, "conv01_fused", 2.0 * B * ((double)T0 * C0 * 10 + (double)T1 * 153.0 * 3 * C0),
                              B * (4.0 * N + 4.0 * (double)T1 * N1p));
-  if (pp) hipLaunchKernelGGL(conv01_fused_kernel<true>, dim3((ntile + 1) / 2, B), dim3(512), 2 * group_lds, st, a);
-  else hipLaunchKernelGGL(conv01_fused_kernel<false>, dim3(ntile, B), dim3(256), group_lds, st, a);
+  if (pp && uf == 8) hipLaunchKernelGGL((conv01_fused_kernel<true, 8>), dim3((ntile + 1) / 2, B), dim3(512), 2 * group_lds, st, a);
+  else if (pp) hipLaunchKernelGGL((conv01_fused_kernel<true, 4>), dim3((ntile + 1) / 2, B), dim3(512), 2 * group_lds, st, a);
+  else if (uf == 8) hipLaunchKernelGGL((conv01_fused_kernel<false, 8>), dim3(ntile, B), dim3(256), group_lds, st, a);
+  else hipLaunchKernelGGL((conv01_fused_kernel<false, 4>), dim3(ntile, B), dim3(256), group_lds, st, a);
   prof_end(pid, st);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }

@@ -183,16 +183,19 @@ __device__ __forceinline__ float apply_act_c(float v) {
 //   * out-of-range rows / columns load from clamped (valid) addresses and only their STORES are predicated: no control
 //     flow between the loads; the activation is a template argument (one switch per wavefront).
 // Needs 4-element alignment of N and every stride (else the general form).
+// (r5) `rpre` != nullptr: the residual float4s of the whole wavefront tile were fetched at the START of the kernel
+// (gemm_prefetch_residual below) and the epilogue only consumes them — no load sits between the last MFMA and the first store.
 template <int BM, int BN, int TM, int TN, int MI, int NI, bool LDSCOLS = false, int RS = 16, int CS = 16>
 __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&acc)[MI][NI], int tm, int tn,
                                               int wm, int wn, int lr, int lq, int64_t cz, int64_t bz, int z0 = 0,
                                               const float* row_inv = nullptr, const float* col_scale = nullptr,
-                                              float* lds_cols = nullptr) {
+                                              float* lds_cols = nullptr, const f32x4 (*rpre)[NI] = nullptr) {
   const bool vec = (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0 && d.N >= 4;
   if (!vec) {
     gemm_epilogue_general<BM, BN, TM, TN, MI, NI, RS, CS>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, col_scale);
     return;
   }
+  const bool ring = d.R && !rpre;                       // residual through the two-deep ring (fetched here)
   // column blocks per batch: 4 keeps acc + two residual batches + the hoisted column-vector reads inside 256 registers
   constexpr int JCMAX = MI * NI > 16 ? 4 : 8;          // wide tiles: 128 accumulator registers leave room for 2 x 4 float4s
   constexpr int JC = epi_chunk(NI, JCMAX);
@@ -224,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
 #pragma unroll
     for (int jj = 0; jj < JC; ++jj) r4[slot][jj] = *reinterpret_cast<const float4*>(d.R + crow[i] + nc_(jc * JC + jj));
   };
-  if (d.R) issue_r(0, 0);
+  if (ring) issue_r(0, 0);
   float ln_mu[MI], ln_rs[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -297,7 +300,7 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int i = b / NJC, jc = b % NJC;
-      if (d.R && b + 1 < NB) issue_r(b + 1, (b + 1) & 1);
+      if (ring && b + 1 < NB) issue_r(b + 1, (b + 1) & 1);
       const float acc_scale = (col_scale && row_inv) ? row_inv[i] : 1.f;
 #pragma unroll
       for (int jj = 0; jj < JC; ++jj) {
@@ -315,7 +318,10 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
         if (bias) { v[0] += bb4.x; v[1] += bb4.y; v[2] += bb4.z; v[3] += bb4.w; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act_c<ACT>(v[e]) * d.alpha;
-        if (d.R) {
+        if (rpre) {
+          const f32x4 r = rpre[i][j];
+          v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+        } else if (d.R) {
           const float4 r = r4[b & 1][jj];
           v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
         }
@@ -421,6 +427,31 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
     if (wrow0 + TM > boundary && boundary < d.M) track_amax(d.c_amax + unit0 + 1, amax_hi);   // wave-uniform
   } else if (d.c_amax && d.amax_unit <= 0) {
     track_amax(d.c_amax + z0, amax);
+  }
+}
+
+// (r5) residual prefetch for short-K launches (out_proj / FFN-output: K <= 512, N = 1024), whose time is their epilogue: the
+// float4s the epilogue will add are requested BEFORE the first operand tile, so they travel beside the prologue's LDS-DMA and
+// the epilogue is stores only.  Same addresses, same clamping as gemm_epilogue (valid: N % 4 == 0 and aligned strides — the
+// caller checks `gemm_epilogue_vec`); costs MI x NI x 4 registers for the life of the K loop.
+__device__ __forceinline__ bool gemm_epilogue_vec(const dzn_gemm_desc& d, int64_t cz, int64_t bz) {
+  return (((int64_t)d.N | d.ldc | d.ldws | cz | bz) & 3) == 0 && d.N >= 4;
+}
+template <int BM, int BN, int TM, int TN, int MI, int NI, int RS = 16, int CS = 16>
+__device__ __forceinline__ void gemm_prefetch_residual(const dzn_gemm_desc& d, f32x4 (&rpre)[MI][NI], int tm, int tn, int wm, int wn,
+                                                       int lr, int lq, int64_t cz) {
+  const int ncol0 = tn * BN + wn * TN + lq * 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    int m = tm * BM + wm * TM + i * RS + lr;
+    m = m < d.M ? m : d.M - 1;
+    const int64_t crow = cz + (d.c_rowoff ? (int64_t)d.c_rowoff[m] : (int64_t)m * d.ldc);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int n0 = ncol0 + j * CS;
+      n0 = n0 < d.N ? n0 : d.N - 4;
+      rpre[i][j] = *reinterpret_cast<const f32x4*>(d.R + crow + n0);
+    }
   }
 }
 

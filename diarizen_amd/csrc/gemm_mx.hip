@@ -35,9 +35,12 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "checked.h"
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "split.h"
+
+DZN_CHECKED_TU(gemm_mx)
 
 namespace {
 
@@ -89,7 +92,8 @@ __device__ __forceinline__ void split8_mx(const f32x4& u, const f32x4& v, float 
 // BM x BN tile per workgroup of WGM x WGN wavefronts, S LDS stages of one 32-k tile each; wavefront tiles of 32 x 32 blocks.
 // sc_one / sc_lo arrive as kernel arguments so that the scale operands of the MX instruction are registers (a literal there is
 // taken as an f32 constant by the compiler).
-template <int BM, int BN, int WGM, int WGN, int S, int OCC = 1>
+// RPF: residual prefetch at kernel start (gemm_epilogue.h), for the short-K launches whose time is their epilogue.
+template <int BM, int BN, int WGM, int WGN, int S, int OCC = 1, bool RPF = false>
 __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_mx_kernel(const dzn_gemm_desc d, const int sc_one, const int sc_lo) {
   constexpr int NW = WGM * WGN;
   constexpr int BK = 32;
@@ -132,11 +136,19 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_mx_kernel(const dzn_
   for (int i = 0; i < MI; ++i) {
     int m = tm * BM + wm * TM + i * 32 + l31;
     m = m < d.M ? m : d.M - 1;
-    mx_scale(d.a_amax[d.amax_unit > 0 ? m / d.amax_unit : z0], a_scale[i], row_inv[i]);
+    const int unit = d.amax_unit > 0 ? m / d.amax_unit : z0;
+    DZN_CHECK(d.amax_count <= 0 || (unit >= 0 && unit < d.amax_count), 0x201, unit);
+    mx_scale(d.a_amax[unit], a_scale[i], row_inv[i]);
   }
   const int64_t cz = z0 * d.c_z0 + z1 * d.c_z1;
   const int64_t bz = z0 * d.b_z0 + z1 * d.b_z1;
 
+  f32x4 rpre[RPF ? MI : 1][RPF ? 4 * NJ : 1];
+  bool use_rpre = false;
+  if constexpr (RPF) {
+    use_rpre = d.R != nullptr && gemm_epilogue_vec(d, cz, bz);
+    if (use_rpre) gemm_prefetch_residual<BM, BN, TM, TN, MI, 4 * NJ, 32, 8>(d, rpre, tm, tn, wm, wn, l31, lh, cz);
+  }
   // ---- LDS-DMA sources: identical to gemm_split_kernel ----
   const int r0 = tid >> 3;
   const int csw = (tid & 7) ^ ((r0 >> 1) & 7);
@@ -162,6 +174,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_mx_kernel(const dzn_
   auto issue = [&](int stage) {
     unsigned char* sA = smem + stage * BUF + wave * 1024;
     unsigned char* sW = smem + stage * BUF + ABYTES + wave * 1024;
+    DZN_CHECK(stage >= 0 && stage < S && ik < d.K, 0x205, stage);
 #pragma unroll
     for (int i = 0; i < ACH; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[i] + ikoff),
@@ -218,6 +231,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_mx_kernel(const dzn_
 #pragma unroll
     for (int e = 0; e < 8; ++e) ah8[i][e] = al8[i][e] = 0;
 
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) DZN_CHECK(woff[j][kh] >= ABYTES && woff[j][kh] + WPLANE + 16 <= BUF, 0x202, woff[j][kh]);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) DZN_CHECK(aoff0[i][kh] + 16 <= ABYTES && aoff1[i][kh] + 16 <= ABYTES, 0x203, aoff1[i][kh]);
+  DZN_CHECK(tm * BM < d.M && tn * BN < d.N, 0x204, t);
   auto read_w16 = [&](int stage, u32x4 (&wf)[NJ][2]) {
     const unsigned char* base = smem + stage * BUF;
 #pragma unroll
@@ -361,15 +383,22 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_mx_kernel(const dzn_
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) accv[i][4 * j + g][e] = acc[i][j][4 * g + e];
+  if constexpr (RPF) {
+    if (use_rpre) {
+      gemm_epilogue<BM, BN, TM, TN, MI, 4 * NJ, true, 32, 8>(d, accv, tm, tn, wm, wn, l31, lh, cz, bz, z0, row_inv, d.col_scale_mx,
+                                                           reinterpret_cast<float*>(smem) + wave * 3 * TN, rpre);
+      return;
+    }
+  }
   gemm_epilogue<BM, BN, TM, TN, MI, 4 * NJ, true, 32, 8>(d, accv, tm, tn, wm, wn, l31, lh, cz, bz, z0, row_inv, d.col_scale_mx,
                                                        reinterpret_cast<float*>(smem) + wave * 3 * TN);
 }
 
-template <int BM, int BN, int WGM, int WGN, int S, int OCC>
+template <int BM, int BN, int WGM, int WGN, int S, int OCC, bool RPF = false>
 int launch_mx_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
   const size_t lds = (size_t)S * (BM * 128 + 2 * BN * 64);
-  auto kern = gemm_mx_kernel<BM, BN, WGM, WGN, S, OCC>;
+  auto kern = gemm_mx_kernel<BM, BN, WGM, WGN, S, OCC, RPF>;
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -379,7 +408,7 @@ int launch_mx_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     char cls[64];
     static const bool by_shape = getenv("DZN_PROFILE_SHAPES") != nullptr;
     if (by_shape) snprintf(cls, sizeof(cls), "gemm_mx_%dx%d M%d N%d K%d z%d", BM, BN, d.M, d.N, d.K, d.nz);
-    else snprintf(cls, sizeof(cls), "gemm_mx_%dx%d", BM, BN);
+    else snprintf(cls, sizeof(cls), "gemm_mx_%dx%d%s", BM, BN, RPF ? "_rpf" : "");
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
     pid = prof_begin(s, cls, fl, gemm_alg_bytes(d, 4));
   }
@@ -451,6 +480,7 @@ int launch_gemm_mx(const dzn_gemm_desc& d, hipStream_t s) {
   const char* force = g_mx_force();
   if (force && !strcmp(force, "128x64")) return launch_mx_cfg<128, 64, 4, 1, 2, 3>(d, s);
   if (force && !strcmp(force, "128x128")) return launch_mx_cfg<128, 128, 4, 1, 2, 2>(d, s);
+  if (force && !strcmp(force, "128x64rpf")) return launch_mx_cfg<128, 64, 4, 1, 2, 2, true>(d, s);
   if (narrow) return launch_mx_cfg<128, 64, 4, 1, 2, 3>(d, s);
   return launch_mx_cfg<128, 128, 4, 1, 2, 2>(d, s);
 }

@@ -39,9 +39,12 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "checked.h"
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "split.h"
+
+DZN_CHECKED_TU(gemm_split)
 
 namespace {
 
@@ -68,7 +71,9 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 // ABL != 0: ABLATION probes for scripts/bench_gemm_cfgs.py (wrong results on purpose; never launched by the engines):
 //   1 = no operand split (raw bits as fragments), 2 = no MFMAs, 3 = no steady-state LDS-DMA refills, 4 = no barrier,
 //   5 = no fragment reads after the first tile
-template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0>
+// RPF (r5): the residual of the whole wavefront tile is requested before the first operand tile (gemm_prefetch_residual): the
+// short-K launches' epilogue is then stores only.
+template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0, bool RPF = false>
 __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const dzn_gemm_desc d, const int ngroups) {
   constexpr int NW = WGM * WGN;           // wavefronts per workgroup
   constexpr int BK = 32;
@@ -144,7 +149,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
     for (int i = 0; i < MI; ++i) {
       int m = tm * BM + wm * TM + i * 16 + (lane & 15);
       m = m < d.M ? m : d.M - 1;
-      h2_scale(d.a_amax[d.amax_unit > 0 ? m / d.amax_unit : z0], a_scale[i], row_inv[i]);
+      const int unit = d.amax_unit > 0 ? m / d.amax_unit : z0;
+      DZN_CHECK(d.amax_count <= 0 || (unit >= 0 && unit < d.amax_count), 0x101, unit);   // tracker index inside its array
+      h2_scale(d.a_amax[unit], a_scale[i], row_inv[i]);
     }
   }
   // NP = 1 with a folded LayerNorm (d.ln_centered): the row mean is subtracted before the fp16 rounding; |x - mean| <=
@@ -197,6 +204,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
   auto issue = [&](int stage) {
     unsigned char* sA = smem + stage * BUF + wave * 1024;
     unsigned char* sW = smem + stage * BUF + ABYTES + wave * 1024;
+    DZN_CHECK(stage >= 0 && stage < S && ik < d.K, 0x102, stage);                              // a stage of the ring, a k tile of the operand
+    DZN_CHECK(wave * 1024 + (ACH - 1) * RB + 1024 <= ABYTES, 0x103, wave);                      // A fill stays inside the A image
+    DZN_CHECK(!wfull || wave * 1024 + (WR - 1) * RB + 1024 <= WPLANE, 0x104, wave);                  // W fill stays inside its plane image
 #pragma unroll
     for (int i = 0; i < ACH; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[i] + ikoff),
@@ -221,6 +231,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int lr = lane & 15, lq = lane >> 4;
+  f32x4 rpre[RPF ? MI : 1][RPF ? NI : 1];
+  bool use_rpre = false;
+  if constexpr (RPF) {
+    use_rpre = d.R != nullptr && gemm_epilogue_vec(d, cz, bz);
+    if (use_rpre) gemm_prefetch_residual<BM, BN, TM, TN, MI, NI>(d, rpre, tm, tn, wm, wn, lr, lq, cz);
+  }
 
   // per-lane LDS byte offsets of the fragments inside a stage
   int woff[NI], aoff0[MI], aoff1[MI];
@@ -236,6 +252,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
     aoff0[i] = row * 128 + ((lq ^ sw) << 4);
     aoff1[i] = row * 128 + (((4 + lq) ^ sw) << 4);
   }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) DZN_CHECK(woff[j] >= ABYTES && woff[j] + (NP - 1) * WPLANE + 16 <= BUF, 0x105, woff[j]);   // fragment reads inside the stage
+#pragma unroll
+  for (int i = 0; i < MI; ++i) DZN_CHECK(aoff0[i] + 16 <= ABYTES && aoff1[i] + 16 <= ABYTES, 0x106, aoff1[i]);
+  DZN_CHECK(tm * BM < d.M && tn * BN < d.N, 0x107, t);                                            // the tile exists
   auto read_w = [&](int stage, u32x4 (&wf)[NI][NP]) {
     const unsigned char* base = smem + stage * BUF;
 #pragma unroll
@@ -350,6 +371,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const d
     // the epilogue's column vectors live in LDS (48 registers less than holding them): the stages are dead once every
     // wavefront left the loop
     __syncthreads();
+    if constexpr (RPF) {
+      if (use_rpre) {
+        gemm_epilogue<BM, BN, TM, TN, MI, NI, true>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr,
+                                                    reinterpret_cast<float*>(smem) + wave * 3 * TN, rpre);
+        return;
+      }
+    }
     gemm_epilogue<BM, BN, TM, TN, MI, NI, true>(d, acc, tm, tn, wm, wn, lr, lq, cz, bz, z0, row_inv, NP <= 2 ? d.col_scale : nullptr,
                                                 reinterpret_cast<float*>(smem) + wave * 3 * TN);
   } else {
@@ -677,11 +705,11 @@ int choose_column_groups(const dzn_gemm_desc& d, int tilesM, int tilesN, int BM,
   return rbest < 0.95 * r1 ? best : 1;
 }
 
-template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0>
+template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0, bool RPF = false>
 int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
   const size_t lds = (size_t)S * (BM * 128 + NP * BN * 64);
-  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, NP, OCC, ABL>;
+  auto kern = gemm_split_kernel<BM, BN, WGM, WGN, S, NP, OCC, ABL, RPF>;
   static unsigned long long attr_mask = 0;  // one bit per HIP device: function attributes are per device
   if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -696,7 +724,7 @@ int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
       snprintf(cls, sizeof(cls), "gemm_%s_%dx%d M%d N%d K%d z%d", NP == 3 ? "f32s" : NP == 2 ? "f32h" : "f16", BM, BN, d.M,
                d.N, d.K, d.nz);
     else
-      snprintf(cls, sizeof(cls), "gemm_%s_%dx%d", NP == 3 ? "f32s" : NP == 2 ? "f32h" : "f16", BM, BN);
+      snprintf(cls, sizeof(cls), "gemm_%s_%dx%d%s", NP == 3 ? "f32s" : NP == 2 ? "f32h" : "f16", BM, BN, RPF ? "_rpf" : "");
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
     pid = prof_begin(s, cls, fl, gemm_alg_bytes(d, NP * 2));
   }
@@ -815,6 +843,16 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     if ((m32 & 2) && d.N > 32 && (d.N <= 64 || d.K <= 512)) return launch_split32_cfg<128, 64, 4, 1, 2, NP, 3>(d, s);
   }
 #endif
+  if constexpr (NP == 2) {
+    // (r5) short-K launches with a residual (out_proj / FFN-output) with the residual requested at kernel START: a MEASURED
+    // NEGATIVE, kept as a switch (DZN_GEMM_RPF=1, read once).  The 32 residual registers cost the third workgroup per CU: class
+    // 168 -> 134 TFLOP/s, device step 1743 -> 1705 audio-s/s on one box (profiles/r5_rpf_probe.txt); at three workgroups per CU
+    // the form spills (probed as DZN_GEMM_RPF=2, instantiation removed).  The epilogue's load latency is not what these launches wait for.
+    static const int rpf = getenv("DZN_GEMM_RPF") ? atoi(getenv("DZN_GEMM_RPF")) : 0;
+    if (rpf && d.R && d.N > 64 && d.K <= 512) {
+      return launch_split_cfg<128, 64, 4, 1, 2, NP, 2, 0, true>(d, s);   // (at 3 workgroups per CU the form spills 24 registers: probed, removed)
+    }
+  }
   if (d.N <= 64 || d.K <= 512) return launch_split_cfg<128, 64, 4, 1, 2, NP, OCC64>(d, s);
   // 128-wide column tiles unless 64-wide ones save more than ~1/8 of the (padded) columns; widths that
   // are multiples of 80 but not of 64 (conv1 of the extractor: 153 -> 160) get exact 80-wide tiles

@@ -13,9 +13,12 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "checked.h"
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "split.h"
+
+DZN_CHECKED_TU(gemm_split_pre)
 
 namespace {
 
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_split_pre_kernel(const dz
   auto issue = [&](int stage) {
     unsigned char* sA = smem + stage * BUF + wave * 1024;
     unsigned char* sW = sA + NP * APLANE;
+    DZN_CHECK(stage >= 0 && stage < S && ik < d.K, 0x301, stage);                              // a stage of the ring, a k tile of the operand
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll

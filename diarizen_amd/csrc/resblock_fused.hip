@@ -35,8 +35,11 @@
 // than 2^17 below the BOUND (instead of below the true maximum) get a subnormal lo term — so the result differs from the
 // unfused pipeline in the last bits only (tests/test_ops_gpu.py::test_resblock32_fused_equals_two_convs: <= 2e-6 of the
 // block's |max|; the model-level embedding tests run through it).
+#include "checked.h"
 #include "common.h"
 #include "split.h"
+
+DZN_CHECKED_TU(resblock_fused)
 
 namespace {
 
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256, 2) void resblock32_fused_kernel(const ResBlock
     const float* ib = a.in + (int64_t)b * img;
     float* ob = a.out + (int64_t)b * img;
     float xs, xinv, ms, minv;
+    DZN_CHECK(b >= 0 && b < a.B, 0x403, b);                                               // image index (device-chosen subset) inside the batch
     h2_scale(a.amax_in[b], xs, xinv);
     h2_scale(fmaf(a.amax_in[b], a.l1max1, a.bmax1), ms, minv);
     float out_amax = 0.f;
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void resblock32_fused_kernel(const ResBlock
       u32x4 pf[NP];
       split_np<NP>((f32x4){xu.x, xu.y, xu.z, xu.w}, (f32x4){xv.x, xv.y, xv.z, xv.w}, xs, pf);
       unsigned char* dst = sX + ((q + 1) & 3) * RB_ROW + soff;
+      DZN_CHECK(soff + 16 <= RB_ROW && q >= -1 && q <= a.Hs, 0x401, q);                  // staged pixel inside its ring row, row inside the padded image
 #pragma unroll
       for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dst + p * XPL) = pf[p];
     };
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void resblock32_fused_kernel(const ResBlock
           for (int m = 0; m < 2; ++m) {
             const int px = (2 * mh + m) * 16 + lr + dw;
             const int off = rowoff[dh] + px * 64 + ((lq ^ ((px >> 1) & 3)) << 4);
+            DZN_CHECK(off >= 0 && off + 16 <= plane_bytes, 0x402, off);                      // fragment read inside its ring plane
 #pragma unroll
             for (int p = 0; p < NP; ++p) xf[m][p] = *reinterpret_cast<const u32x4*>(ring + p * plane_bytes + off);
           }

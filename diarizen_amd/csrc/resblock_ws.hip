@@ -16,8 +16,11 @@
 //   C = 32: 4 wavefronts, 68 KB of LDS (2 workgroups per CU);  C = 64: 8 wavefronts, 152 KB (1 per CU).
 // Geometry, masking, scales and arithmetic are those of resblock_fused.hip (intermediate scale from the a-priori bound
 // amax(x) * max_oc sum|W1| + max|b1|); pixel rows are [pixel][k-block of 32 channels][64 B] per plane (WsLayout below).
+#include "checked.h"
 #include "common.h"
 #include "split.h"
+
+DZN_CHECKED_TU(resblock_ws)
 
 namespace {
 
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(2 * (C / 16) * 64, C == 32 ? 2 : 1) void resblock_w
     const float* ib = a.in + (int64_t)b * img;
     float* ob = a.out + (int64_t)b * img;
     float xs, xinv, ms, minv;
+    DZN_CHECK(b >= 0 && b < a.B, 0x502, b);                                                   // image index inside the batch
     h2_scale(a.amax_in[b], xs, xinv);
     h2_scale(fmaf(a.amax_in[b], a.l1max1, a.bmax1), ms, minv);
     float out_amax = 0.f;
@@ -155,6 +159,7 @@ __global__ __launch_bounds__(2 * (C / 16) * 64, C == 32 ? 2 : 1) void resblock_w
               for (int m = 0; m < 2; ++m) {
                 const int px = (2 * g + m) * 16 + lr + dw;
                 const int off = rowoff[dh] + ws_pix_off<C>(px, kb, lq);
+                DZN_CHECK(off >= 0 && off + 16 <= PL, 0x501, off);                               // fragment read inside its ring plane
                 xf[m][0] = *reinterpret_cast<const u32x4*>(ring + off);
                 xf[m][1] = *reinterpret_cast<const u32x4*>(ring + PL + off);
               }

@@ -118,6 +118,9 @@ typedef struct dzn_gemm_desc {
    * kernel on the leading plane of W2h (r2-r4's DZN_PREC_F16 arithmetic, kept for the positional conv and the ResNet trunk). */
   const void* Wmx;
   const float* col_scale_mx;
+  /* number of entries of the a_amax / c_amax arrays (0 = not stated): only read by CHECKED builds (csrc/checked.h), which
+   * assert that every scale-unit index stays inside them */
+  int32_t amax_count;
 } dzn_gemm_desc;
 
 /* (r4) One BasicBlock of the 32-channel ResNet stage in one kernel (csrc/resblock_fused.hip):
@@ -150,6 +153,12 @@ int dzn_op_split_weights_h2(const float* W, int64_t rows, int32_t K, int64_t ldw
  * remainder * 2^11 x 8]; max|row| * 2^e_row in [2^7, 2^8); col_scale f32 [rows] = 2^-e_row. */
 int dzn_op_split_weights_mx(const float* W, int64_t rows, int32_t K, int64_t ldw, void* Wmx, float* col_scale,
                             void* stream);
+/* CHECKED builds only (python -m diarizen_amd.build --checked, csrc/checked.h): device-side bounds assertions in the hand-
+ * scheduled kernels (LDS stage / fragment offsets, tracker indices, tile ranges).  out4 (may be NULL) = {failed checks since the
+ * last reset, id of the first, its workgroup, its detail value}; reset != 0 clears the counters.  Returns the number of failed
+ * checks (0 = clean), DZN_E_STATE in a release build. */
+int dzn_checked_status(uint32_t* out4, int32_t reset);
+
 /* tests / tuning: force one tile shape of csrc/gemm_mx.hip ("128x128", "128x64"; "auto" / NULL = the shape rule) */
 int dzn_op_set_gemm_mx_cfg(const char* cfg);
 

@@ -2,6 +2,7 @@
 times, on the same operands (planes packed beforehand, residual epilogue as in the encoder), the fp16 two-term kernel (f32h,
 3 products), the single-term fp16 kernel (r2-r4's f16) and the MX kernel (fp16 hi*hi + fp8 cross terms, csrc/gemm_mx.hip) in its
 shape-rule tile and in both forced tiles."""
+import os
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -24,7 +25,8 @@ for spec in sys.argv[1:]:
     runs = [("f32h", 3, base, None), ("f16x1", 4, base, None),
             ("mx auto", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "auto"),
             ("mx 128x128", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "128x128"),
-            ("mx 128x64", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "128x64")]
+            ("mx 128x64", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "128x64"),
+            ("mx 128x64rpf", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "128x64rpf")]
     for name, prec, kw, force in runs:
         if force is not None:
             lib.dzn_op_set_gemm_mx_cfg(force.encode())
@@ -38,5 +40,5 @@ for spec in sys.argv[1:]:
             ops.gemm(A, W, C_out=out, R=R, precision=prec, **kw)
         en.record(); torch.cuda.synchronize()
         dt = st.elapsed_time(en) / it * 1e-3
-        print(f"{name:11s} M={M} N={N} K={K}: {dt*1e6:8.1f} us {2*M*N*K/dt/1e12:6.1f} TFLOP/s algorithmic", flush=True)
+        print(f"[DZN_GEMM_RPF={os.environ.get('DZN_GEMM_RPF', 'default')}] {name:12s} M={M} N={N} K={K}: {dt*1e6:8.1f} us {2*M*N*K/dt/1e12:6.1f} TFLOP/s algorithmic", flush=True)
     lib.dzn_op_set_gemm_mx_cfg(b"auto")

@@ -29,10 +29,34 @@ def run_and_check(device=None, linkage_backend="auto", cdist_backend="auto"):
         seen[step] = artifact
     ann = run_host_stage(seg, emb, chunks=SlidingWindow(start=0.0, duration=8.0, step=0.8), clustering=clustering, min_speakers=1,
                          max_speakers=20, sess_name="host30", device=device, hook=hook)
-    # 1. the clustering step: every (window, speaker) in the reference's cluster
+    # 1. the clustering step: every ACTIVE (window, speaker) in the reference's cluster.  Inactive local speakers are overwritten
+    #    with -2 right after the clustering (diarizen/pipelines/inference.py:166-170); their embeddings are all the same vector
+    #    (seg_1's bias: zero mask), so inside a window the constrained assignment is tied between them and which of two equal
+    #    rows gets which left-over cluster follows the last bit of the float64 scores (device cdist vs scipy: 2e-15) — first GPU
+    #    run of this test: 372 such entries, all inactive (profiles/r5_diag_host30.txt)
+    #    Active speakers can be tied the same way: two local speakers of a window that are active in exactly the same frames
+    #    (a window that only ever shows the overlap class {1, 3}) fall back to the same full mask and get the SAME embedding, so
+    #    "1 -> a, 3 -> b" and "1 -> b, 3 -> a" score identically; which one linear_sum_assignment returns follows the last bit
+    #    of the scores (a 1e-15 perturbation of scipy's own scores moves ~330 active entries of this fixture), and the
+    #    reconstruction cannot tell them apart (identical activity).  So rows of a window with identical embeddings are compared
+    #    as a SET of clusters; every other entry exactly.
     ref_hard = g["hard_clusters"].astype(np.int64)
-    assert np.array_equal(seen["hard"].astype(np.int64), ref_hard), \
-        f"{int((seen['hard'] != ref_hard).sum())} of {ref_hard.size} hard-cluster entries differ from the reference's"
+    active = seg.sum(axis=1) > 0
+    got = seen["hard"].astype(np.int64)
+
+    def canon(h):
+        h = np.array(h, copy=True)
+        for c in range(h.shape[0]):
+            keys = {}
+            for s_ in range(h.shape[1]):
+                keys.setdefault(emb[c, s_].tobytes(), []).append(s_)
+            for idx in keys.values():
+                if len(idx) > 1:
+                    h[c, idx] = np.sort(h[c, idx])
+        return h
+    cg, cr = canon(got), canon(ref_hard)
+    assert np.array_equal(cg, cr), \
+        f"{int((cg != cr).sum())} of {ref_hard.size} hard-cluster entries differ from the reference's beyond ties between identical rows"
     # 2. speaker counting
     assert np.array_equal(np.minimum(seen["speaker_counting"].data, 20).astype(np.int8).reshape(-1), g["count"].reshape(-1))
     # 3. discrete diarization: exact wherever the reference's own result is defined by the data; at frames whose top-`count`
@@ -55,4 +79,5 @@ def run_and_check(device=None, linkage_backend="auto", cdist_backend="auto"):
     if not len(diff):
         assert ann.to_rttm() == rttm_ref
     return {"tie_frames_resolved_differently": int(len(diff)), "rttm_equal": ann.to_rttm() == rttm_ref,
+            "tied_entries_assigned_differently": int((got != ref_hard).sum()), "of_them_active": int((got != ref_hard)[active].sum()),
             "n_train": int(g["n_train"]), "rows": int(ref_hard.size)}

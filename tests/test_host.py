@@ -370,7 +370,7 @@ def test_contraction_kernels_do_not_spill():
     from diarizen_amd import build as b
     if not shutil.which(b.HIPCC) and not os.path.exists(b.HIPCC):
         pytest.skip("hipcc not available")
-    srcs = ["gemm.hip", "gemm_split.hip", "gemm_split_pre.hip", "conv_split.hip"]
+    srcs = ["gemm.hip", "gemm_split.hip", "gemm_split_pre.hip", "conv_split.hip", "gemm_mx.hip"]
     procs = {src: subprocess.Popen([b.HIPCC, *b.FLAGS, "-c", str(b.CSRC / src), "-o", os.devnull,
                                     "-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.PIPE,
                                    stderr=subprocess.PIPE, text=True) for src in srcs}
@@ -384,7 +384,7 @@ def test_contraction_kernels_do_not_spill():
         names = re.findall(r"Function Name: (\S+)", err)
         occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", err)]
         for n, o in zip(names, occ):
-            if "gemm_split_kernelILi128ELi" in n or "gemm_split_pre_kernelILi128ELi64" in n:   # the pipeline's tiles
+            if "gemm_split_kernelILi128ELi" in n or "gemm_split_pre_kernelILi128ELi64" in n or "gemm_mx_kernelILi128ELi" in n:   # the pipeline's tiles
                 assert o >= 2, f"{n}: {o} wavefront(s) per SIMD"
 
 

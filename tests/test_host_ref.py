@@ -171,3 +171,29 @@ def test_product_host_stage_equals_reference_run_at_30min_scale():
     from tests._host30 import run_and_check
     res = run_and_check(device=None, linkage_backend="scipy", cdist_backend="scipy")
     print(res)
+
+
+def test_device_score_deviation_cannot_move_the_reference_result_at_30min_scale(monkeypatch):
+    """The device cosine scores (csrc/linkage.hip:dzn_cdist_cosine) agree with scipy.cdist to 2e-15 — and the 30-min fixture
+    has hundreds of windows whose constrained assignment is an EXACT tie (local speakers with bit-identical embeddings: seg_1's
+    bias for every inactive or zero-weight speaker), which linear_sum_assignment breaks by the last bit of the scores: the first
+    GPU run of the device backends moved 242 active assignments and one RTTM frame.  clustering._exact_scores_for_tied_rows gives
+    tied rows (and whole windows whose tie involves an active speaker) scipy's own bits.  Here, without a GPU: a stand-in for the
+    device kernel = scipy's scores plus a 2e-15-level deviation that (like the kernel) is a function of the row alone; every
+    active assignment, every frame and the RTTM must equal the reference's run."""
+    from scipy.spatial.distance import cdist
+    from diarizen_amd import clustering as cl, ops
+    from tests._host30 import run_and_check
+
+    def fake_cdist(flat, cent, device=-1):
+        d = cdist(flat, cent, metric="cosine")
+        h = (np.abs(flat[:, :8].astype(np.float64)).sum(1) * 1e6 % 1.0) - 0.5
+        return d + 2e-15 * h[:, None] * np.arange(1, d.shape[1] + 1)
+    monkeypatch.setattr(ops, "cdist_cosine", fake_cdist)
+    monkeypatch.setattr(cl, "_hip_ready", lambda: True)
+    res = run_and_check(device=None, linkage_backend="scipy", cdist_backend="hip")
+    assert res["of_them_active"] == 0 and res["rttm_equal"] and res["tie_frames_resolved_differently"] == 0, res
+    # and without the repair the same deviation does move the result (the test would be vacuous otherwise)
+    monkeypatch.setattr(cl, "_exact_scores_for_tied_rows", lambda *a, **k: None)
+    with pytest.raises(AssertionError):
+        run_and_check(device=None, linkage_backend="scipy", cdist_backend="hip")

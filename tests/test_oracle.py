@@ -363,3 +363,13 @@ def test_clustering_port_equals_reference_run_at_30min_scale():
     g = np.load(os.path.join(GOLD, "host30.npz"))
     hard = agglomerative(g["emb"], g["seg"], 0.1, 13, 1, 20)
     assert np.array_equal(hard.astype(np.int64), g["hard_clusters"].astype(np.int64))
+
+
+def test_release_library_says_it_is_not_a_checked_build(built_lib):
+    """dzn_checked_status exists in every build; only `python -m diarizen_amd.build --checked` (csrc/checked.h) carries the
+    device-side assertions — the release library answers DZN_E_STATE instead of a misleading 0."""
+    import ctypes as C
+    if b"checked build" in built_lib.dzn_version():
+        pytest.skip("this IS the checked library")
+    w = (C.c_uint32 * 4)()
+    assert built_lib.dzn_checked_status(w, 0) == -4
