@@ -170,12 +170,15 @@ def load() -> C.CDLL:
     sig("dzn_op_split_weights_mx", i32, [vp, i64, i32, i64, vp, vp, vp])
     sig("dzn_op_set_gemm_mx_cfg", i32, [C.c_char_p])
     sig("dzn_checked_status", i32, [vp, i32])
+    sig("dzn_flac_info", i32, [vp, C.c_size_t, vp, vp, vp, vp, vp])
+    sig("dzn_flac_decode", i32, [vp, C.c_size_t, vp, i64, vp])
     sig("dzn_op_set_gemm_cfg", i32, [C.c_char_p])
     sig("dzn_op_amax", i32, [vp, i64, vp, vp])
     sig("dzn_op_split_rows", i32, [vp, vp, i64, i64, i32, vp])
     sig("dzn_op_conv3x3_c32", i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp])
     sig("dzn_op_resblock_ws", i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, i32, vp])
     sig("dzn_op_resblock32_fused", i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp])
+    sig("dzn_op_set_resblock_np", i32, [i32])
     sig("dzn_op_conv3x3_c32_h2", i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp])
     sig("dzn_op_layernorm", i32, [vp, i64, vp, i64, vp, vp, i64, i32, i32, f32, i32, vp])
     sig("dzn_op_gate", i32, [vp, i64, vp, vp, vp, vp, i64, i32, vp])
@@ -191,8 +194,8 @@ EXPORTED = [
     "dzn_create", "dzn_load_tensor", "dzn_finalize_weights", "dzn_num_frames",
     "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_speaker_count", "dzn_cluster_activations", "dzn_debug_fetch", "dzn_embed_skip_stats", "dzn_num_ignored",
     "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid", "dzn_cdist_cosine",
-    "dzn_vbx_create", "dzn_vbx_stats", "dzn_vbx_estep", "dzn_vbx_gamma", "dzn_vbx_destroy",
-    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_split_weights_mx", "dzn_op_set_gemm_mx_cfg", "dzn_checked_status", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_resblock32_fused", "dzn_op_resblock_ws", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",
+    "dzn_flac_info", "dzn_flac_decode", "dzn_vbx_create", "dzn_vbx_stats", "dzn_vbx_estep", "dzn_vbx_gamma", "dzn_vbx_destroy",
+    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_split_weights_mx", "dzn_op_set_gemm_mx_cfg", "dzn_checked_status", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_resblock32_fused", "dzn_op_resblock_ws", "dzn_op_set_resblock_np", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",
     "dzn_profile_enable", "dzn_profile_collect", "dzn_profile_reserve", "dzn_op_relpos_bucket",
 ]
 

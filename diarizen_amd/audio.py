@@ -1,5 +1,5 @@
 """Audio ingest for the pipeline (replaces `torchaudio.load` at diarizen/pipelines/inference.py:127
-and the `Audio` helper of PA/core/io.py for what the hot path needs: WAV in, first channel kept —
+and the `Audio` helper of PA/core/io.py for what the hot path needs: WAV or (r5) FLAC in, first channel kept —
 "force to use the SDM data", inference.py:128 — resampled to 16 kHz when the file is at another
 rate, as `Audio.downmix_and_resample` does with `torchaudio.functional.resample`, PA/core/io.py:214-218).
 torchaudio is not available in this image: RIFF/WAVE (PCM 8/16/24/32, float 32/64, WAVE_FORMAT_EXTENSIBLE) is parsed
@@ -195,9 +195,78 @@ def resample(x: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width:
     return y[..., :target].reshape(shape[:-1] + (target,)).numpy()
 
 
+def _read_all(src) -> bytes:
+    if isinstance(src, (bytes, bytearray, memoryview)):
+        return src
+    if hasattr(src, "read"):
+        if hasattr(src, "seek"):
+            src.seek(0)
+        return src.read()
+    with open(src, "rb") as f:
+        return f.read()
+
+
+def load_flac(src: Union[str, bytes, BinaryIO, io.BytesIO], verify_md5: bool = True) -> Tuple[np.ndarray, int]:
+    """-> (float32 [channels, samples] in [-1, 1), sample_rate) of a FLAC stream (torchaudio.load semantics: integer samples
+    divided by 2^(bits - 1)).  Decoded by the native decoder of libdzn_hip.so (csrc/flac.cpp: host code, written from the
+    format specification — libFLAC / libsndfile / torchaudio are not in this image); frame CRCs are verified inside, and the
+    STREAMINFO MD5 of the decoded PCM here (a stream whose MD5 field is set cannot decode to wrong samples silently)."""
+    import ctypes as C
+    import hashlib
+    from . import _lib
+    data = bytes(_read_all(src))
+    lib = _lib.load()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    sr, ch, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    md5 = (C.c_uint8 * 16)()
+    rc = lib.dzn_flac_info(buf, len(data), C.byref(sr), C.byref(ch), C.byref(bits), C.byref(total), md5)
+    if rc != 0:
+        raise ValueError("not a FLAC stream (or a malformed STREAMINFO block)")
+    cap = total.value if total.value > 0 else max(1, len(data) * 8)      # unknown length: no frame codes < 1 bit per sample pair
+    out = np.empty((cap, ch.value), dtype=np.int32)
+    done = C.c_int64()
+    rc = lib.dzn_flac_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), cap, C.byref(done))
+    if rc != 0:
+        raise ValueError(f"FLAC decode failed (code {rc}): corrupt frame (CRC / syntax) or an unsupported stream")
+    out = out[:done.value]
+    if verify_md5 and any(md5):
+        width = (bits.value + 7) // 8
+        if width == 4:
+            raw = out.astype("<i4").tobytes()
+        else:
+            raw = out.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :width].tobytes()      # little-endian, sign already extended
+        if hashlib.md5(raw).digest() != bytes(md5):
+            raise ValueError("FLAC decode: MD5 of the decoded samples differs from the STREAMINFO signature")
+    x = out.T.astype(np.float32) * np.float32(1.0 / float(1 << (bits.value - 1)))
+    return np.ascontiguousarray(x), sr.value
+
+
+_FORMATS = ((b"fLaC", "FLAC"), (b"OggS", "Ogg (Vorbis / Opus / FLAC-in-Ogg)"), (b"ID3", "MP3 (ID3 tag)"), (b"\xff\xfb", "MP3"),
+            (b"\xff\xf3", "MP3"), (b"\xff\xf2", "MP3"), (b"FORM", "AIFF"), (b".snd", "Sun AU"), (b"\x1aE\xdf\xa3", "Matroska / WebM"),
+            (b"NIST_1A", "NIST SPHERE"))
+
+
+def load_audio(src) -> Tuple[np.ndarray, int]:
+    """`torchaudio.load` for what this image can decode natively: RIFF/WAVE (load_wav) and FLAC (load_flac).  Anything else is
+    refused BY NAME (the reference accepts whatever torchaudio's backend reads, diarizen/pipelines/inference.py:127; here an
+    unsupported container must not surface as "not a RIFF/WAVE file")."""
+    data = _read_all(src)
+    head = bytes(data[:12])
+    if head[:4] in (b"RIFF", b"RF64"):
+        return load_wav(data)
+    if head[:4] == b"fLaC":
+        return load_flac(data)
+    if len(head) >= 8 and head[4:8] == b"ftyp":
+        raise ValueError("unsupported audio container: MP4 / M4A (AAC) — decodable formats: WAV, FLAC")
+    for magic, name in _FORMATS:
+        if head.startswith(magic):
+            raise ValueError(f"unsupported audio format: {name} — decodable formats: WAV (PCM / float), FLAC")
+    raise ValueError("unrecognised audio file (decodable formats: WAV (PCM / float), FLAC)")
+
+
 def first_channel_16k(src, expected_sr: int = 16000) -> np.ndarray:
     """-> float32 [N] at `expected_sr`: channel 0 of the file (inference.py:128), resampled if needed."""
-    x, sr = load_wav(src)
+    x, sr = load_audio(src)
     x0 = np.ascontiguousarray(x[0])
     if sr != expected_sr:
         x0 = resample(x0, sr, expected_sr)

@@ -220,7 +220,10 @@ int launch_resblock32_fused(const float* in, float* out, const void* W1, const f
 // resblock_ws.hip (r4): the same block with producer / consumer wavefronts, C = 32 or 64 planes
 int launch_resblock_ws(const float* in, float* out, const void* W1, const float* cs1, const float* b1, const void* W2,
                        const float* cs2, const float* b2, const float* amax_in, float* amax_out, float l1max1, float bmax1,
-                       int B, int Hs, int Ws, int C, hipStream_t s, const int* z_count = nullptr, const int* z_list = nullptr);
+                       int B, int Hs, int Ws, int C, hipStream_t s, const int* z_count = nullptr, const int* z_list = nullptr,
+                       int np = 2);   // np = 1 (r5): leading fp16 term only (DZN_PREC_F16)
+
+int op_resblock_np();   // resblock_fused.hip: terms per operand of the dzn_op_resblock* test entry points (dzn_op_set_resblock_np)
 
 // post.hip
 int launch_prepare_masks(const uint8_t* ml, int B, int L, int S, int median, int exclude_overlap,

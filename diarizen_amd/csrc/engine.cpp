@@ -209,9 +209,9 @@ struct dzn_handle {
   // (= f32h) does; the conv stack alone carries ~70 % of the error variance for 4 % of the flops, so it keeps two terms
   // (0.247 -> 0.133, flips 0.52 % -> 0.33 %); centring the LayerNorm-folded split changes nothing (0.228 vs 0.247: the
   // error is plain operand rounding, not the mean * colsum cancellation) and stays off.
-  // NOTE: the stride-1 BasicBlocks of ResNet stages 1-2 run the fused kernels (resblock_fused.hip / resblock_ws.hip),
-  // which exist in the two-term form only — in DZN_PREC_F16 they are two-term whatever bit 14 says; bit 14 governs the
-  // stride-2 / shortcut / stage 3-4 contractions, which go through gemm_split.hip.
+  // (r5) bit 14 governs the whole trunk: the stride-2 / shortcut / stage 3-4 contractions (gemm_split.hip NP = 1)
+  // AND the fused stride-1 BasicBlocks of stages 1-2 (resblock_fused.hip / resblock_ws.hip, which have a single-term form
+  // since r5; in r4 they were two-term whatever the bit said).
   bool fuse_resblock = true;  // DZN_NO_RESBLOCK_FUSION (read once, at dzn_create)
   int resblock_ws = 2;        // DZN_RESBLOCK_WS bit mask: 1 = 32-plane blocks, 2 = 64-plane blocks on the producer / consumer form
   // (r5) with the cross terms in fp8 everywhere else, the Conformer head (bits 8-13, 8 % of the segmentation flops) keeps two
@@ -1629,14 +1629,17 @@ void emb_forward(H* h, const float* wave, const float* masks, int B, int S, int 
         // stays in LDS (resblock_fused.hip); DZN_NO_RESBLOCK_FUSION=1 (read at dzn_create) keeps the per-conv kernels
         const bool fusable = h->fuse_resblock && prec_is_h2(c.precision) && rb.c1.cin == rb.c1.cout && rb.c1.l.W2h &&
                              rb.c2.l.W2h && img_am(inb) != nullptr;
+        // (r5) DZN_PREC_F16: the fused blocks keep ONE fp16 term unless bit 14 of DZN_F16_KEEP2 asks for two (the embedding
+        // trunk is three orders of magnitude inside its cosine bar with one term: profiles/r4_reduced_mode_emulation.txt)
+        const int rb_np = (c.precision == DZN_PREC_F16 && !((h->f16_keep2 >> 14) & 1)) ? 1 : 2;
         if (fusable && rb.c1.cin == 32 && !(h->resblock_ws & 1)) {
           chk(launch_resblock32_fused(inb, outb, rb.c1.l.W2h, rb.c1.l.wsc, rb.c1.l.b, rb.c2.l.W2h, rb.c2.l.wsc, rb.c2.l.b,
-                                      img_am(inb), img_am(outb), rb.c1.l1max, rb.c1.bmax, B, Hs, Ws, 2, st, zc, zl),
+                                      img_am(inb), img_am(outb), rb.c1.l1max, rb.c1.bmax, B, Hs, Ws, rb_np, st, zc, zl),
               "resblock32 fused");
         } else if (fusable && ((rb.c1.cin == 32 && (h->resblock_ws & 1)) || (rb.c1.cin == 64 && (h->resblock_ws & 2)))) {
           // producer / consumer wavefronts (resblock_ws.hip): the only fused form for the 64-plane stage
           chk(launch_resblock_ws(inb, outb, rb.c1.l.W2h, rb.c1.l.wsc, rb.c1.l.b, rb.c2.l.W2h, rb.c2.l.wsc, rb.c2.l.b, img_am(inb),
-                                 img_am(outb), rb.c1.l1max, rb.c1.bmax, B, Hs, Ws, rb.c1.cin, st, zc, zl),
+                                 img_am(outb), rb.c1.l1max, rb.c1.bmax, B, Hs, Ws, rb.c1.cin, st, zc, zl, rb_np),
               "resblock ws");
         } else {
           conv3(inb, rb.c1, midb, nullptr, DZN_ACT_RELU, 0);

@@ -85,13 +85,14 @@ __global__ __launch_bounds__(256, 2) void resblock32_fused_kernel(const ResBlock
   // weight fragments of this wavefront's 16 output channels, both convolutions
   u32x4 wf1[9][NP], wf2[9][NP];
   {
-    const int64_t wo = (int64_t)(nb * 16 + lr) * (9 * NP * 32) + lq * 8;
+    constexpr int SP = NP == 3 ? 3 : 2;          // planes STORED per weight row (NP = 1 reads the leading one of two)
+    const int64_t wo = (int64_t)(nb * 16 + lr) * (9 * SP * 32) + lq * 8;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        wf1[t][p] = *reinterpret_cast<const u32x4*>(a.W1 + wo + t * NP * 32 + p * 32);
-        wf2[t][p] = *reinterpret_cast<const u32x4*>(a.W2 + wo + t * NP * 32 + p * 32);
+        wf1[t][p] = *reinterpret_cast<const u32x4*>(a.W1 + wo + t * SP * 32 + p * 32);
+        wf2[t][p] = *reinterpret_cast<const u32x4*>(a.W2 + wo + t * SP * 32 + p * 32);
       }
   }
   const float4 b1v = *reinterpret_cast<const float4*>(a.b1 + nb * 16 + lq * 4);
@@ -268,29 +269,43 @@ int launch_resblock32_fused(const float* in, float* out, const void* W1, const f
                             float bmax1, int B, int Hs, int Ws, int np, hipStream_t s, const int* z_count,
                             const int* z_list) {
   if (B <= 0 || Hs <= 0 || Ws <= 0) return DZN_OK;
-  if (!in || !out || !W1 || !W2 || !cs1 || !cs2 || !b1 || !b2 || !amax_in || np != 2) return DZN_E_INVALID;
+  if (!in || !out || !W1 || !W2 || !cs1 || !cs2 || !b1 || !b2 || !amax_in || (np != 2 && np != 1)) return DZN_E_INVALID;
   static unsigned long long attr_mask = 0;
-  const size_t lds = (size_t)2 * (RB_XROWS + RB_MROWS) * RB_ROW;
-  if (first_use_on_device(attr_mask))
+  const size_t lds = (size_t)np * (RB_XROWS + RB_MROWS) * RB_ROW;
+  if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock32_fused_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock32_fused_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
   ResBlockArgs a{in, out, static_cast<const u16*>(W1), static_cast<const u16*>(W2), b1, b2, cs1, cs2, amax_in, amax_out,
                  l1max1, bmax1, B, Hs, Ws, z_list ? z_count : nullptr, z_count ? z_list : nullptr};
   const int nstrip = (Ws + RB_OUT - 1) / RB_OUT;
   const int64_t nitem = (int64_t)B * nstrip;
   const int grid = (int)(nitem < 512 ? nitem : 512);      // persistent: 2 workgroups per CU
   // algorithmic work of the two convolutions; bytes: x in + out, once each (the residual is x)
-  const int pid = prof_begin(s, "resblock32_fused_f32h", 2.0 * 2.0 * B * Hs * (double)Ws * 32.0 * 288.0,
+  const int pid = prof_begin(s, np == 2 ? "resblock32_fused_f32h" : "resblock32_fused_f16", 2.0 * 2.0 * B * Hs * (double)Ws * 32.0 * 288.0,
                              (double)B * Hs * Ws * 32.0 * 4.0 * 2.0);
-  hipLaunchKernelGGL(resblock32_fused_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+  if (np == 2) hipLaunchKernelGGL(resblock32_fused_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(resblock32_fused_kernel<1>, dim3(grid), dim3(256), lds, s, a);
   prof_end(pid, s);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
+
+// terms per operand the kernel-level entry points below (and dzn_op_resblock_ws) run with: 2 (default) or 1 (the DZN_PREC_F16
+// form) — a test knob, set by dzn_op_set_resblock_np
+static int g_op_resblock_np = 2;
+int op_resblock_np() { return g_op_resblock_np; }
+extern "C" int dzn_op_set_resblock_np(int32_t np) {
+  if (np != 1 && np != 2) return DZN_E_INVALID;
+  g_op_resblock_np = np;
+  return DZN_OK;
 }
 
 // kernel-level entry point (tests): amax_in f32 [B] per-image |max| of `in`; l1max1 / bmax1 as computed by the caller
 extern "C" int dzn_op_resblock32_fused(const float* in, float* out, const void* W1, const float* cs1, const float* b1,
                                        const void* W2, const float* cs2, const float* b2, const float* amax_in,
                                        float l1max1, float bmax1, int32_t B, int32_t Hs, int32_t Ws, void* stream) {
-  return launch_resblock32_fused(in, out, W1, cs1, b1, W2, cs2, b2, amax_in, nullptr, l1max1, bmax1, B, Hs, Ws, 2,
+  return launch_resblock32_fused(in, out, W1, cs1, b1, W2, cs2, b2, amax_in, nullptr, l1max1, bmax1, B, Hs, Ws, g_op_resblock_np,
                                  reinterpret_cast<hipStream_t>(stream), nullptr, nullptr);
 }

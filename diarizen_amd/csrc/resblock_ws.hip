@@ -60,7 +60,9 @@ struct WsLayout {
 template <int C>
 __device__ __forceinline__ int ws_pix_off(int px, int kb, int chunk) { return WsLayout<C>::off(px, kb, chunk); }
 
-template <int C>
+// NP = 2: two fp16 terms per operand (three products); NP = 1 (r5, DZN_PREC_F16): the leading term only — one plane per ring,
+// half the weight registers, a third of the MFMAs; reads plane 0 of the same two-plane weight buffers.
+template <int C, int NP>
 __global__ __launch_bounds__(2 * (C / 16) * 64, C == 32 ? 2 : 1) void resblock_ws_kernel(const ResBlockWsArgs a) {
   constexpr int KB = C / 32;                     // k-blocks of 32 channels per tap
   constexpr int NWH = C / 16;                    // wavefronts per role
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(2 * (C / 16) * 64, C == 32 ? 2 : 1) void resblock_w
   constexpr int NKB = 9 * KB;                    // k-blocks of the whole 3x3 contraction
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sX = smem;                      // [plane][slot][66 px][KB][64 B]
-  unsigned char* sM = smem + 2 * PL;
+  unsigned char* sM = smem + NP * PL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave < NWH;              // wave-uniform role
@@ -83,18 +85,18 @@ __global__ __launch_bounds__(2 * (C / 16) * 64, C == 32 ? 2 : 1) void resblock_w
   const int nitem = nB * nstrip;
 
   // this wavefront's weight fragments (conv1 for producers, conv2 for consumers), bias, inverse row scales
-  u32x4 wf[NKB][2];
+  u32x4 wf[NKB][NP];
   {
     const u16* Wp = (producer ? a.W1 : a.W2) + (int64_t)(ocb * 16 + lr) * (NKB * 2 * 32) + lq * 8;
 #pragma unroll
     for (int t = 0; t < NKB; ++t)
 #pragma unroll
-      for (int p = 0; p < 2; ++p) wf[t][p] = *reinterpret_cast<const u32x4*>(Wp + t * 64 + p * 32);
+      for (int p = 0; p < NP; ++p) wf[t][p] = *reinterpret_cast<const u32x4*>(Wp + t * 64 + p * 32);
   }
   const float4 bv = *reinterpret_cast<const float4*>((producer ? a.b1 : a.b2) + ocb * 16 + lq * 4);
   const float4 cv = *reinterpret_cast<const float4*>((producer ? a.cs1 : a.cs2) + ocb * 16 + lq * 4);
 
-  for (int i = tid; i < 4 * PL / 16; i += NT) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < 2 * NP * PL / 16; i += NT) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
 
   // x staging (consumers): item = ptid + NWH * 64 * i, i < 2 -> (pixel = item / (4 KB), k-block, chunk c): channels
@@ -134,11 +136,11 @@ __global__ __launch_bounds__(2 * (C / 16) * 64, C == 32 ? 2 : 1) void resblock_w
       for (int i = 0; i < 2; ++i) {
         const int it = ptid + NWH * 64 * i;
         const int px = it / (4 * KB), kb = (it / 4) % KB, c = it & 3;
-        u32x4 pf[2];
-        split_np<2>((f32x4){xu[i].x, xu[i].y, xu[i].z, xu[i].w}, (f32x4){xv[i].x, xv[i].y, xv[i].z, xv[i].w}, xs, pf);
+        u32x4 pf[NP];
+        split_np<NP>((f32x4){xu[i].x, xu[i].y, xu[i].z, xu[i].w}, (f32x4){xv[i].x, xv[i].y, xv[i].z, xv[i].w}, xs, pf);
         const int off = ws_pix_off<C>(px, kb, c);
         *reinterpret_cast<u32x4*>(dst + off) = pf[0];
-        *reinterpret_cast<u32x4*>(dst + PL + off) = pf[1];
+        if constexpr (NP == 2) *reinterpret_cast<u32x4*>(dst + PL + off) = pf[1];
       }
     };
     // 4 pixel blocks x 9 taps x KB k-blocks against three ring rows
@@ -154,20 +156,20 @@ __global__ __launch_bounds__(2 * (C / 16) * 64, C == 32 ? 2 : 1) void resblock_w
             const int t = (dh * 3 + dw) * KB + kb;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {          // two pixel blocks at a time: 16 fragment registers live
-              u32x4 xf[2][2];
+              u32x4 xf[2][NP];
 #pragma unroll
               for (int m = 0; m < 2; ++m) {
                 const int px = (2 * g + m) * 16 + lr + dw;
                 const int off = rowoff[dh] + ws_pix_off<C>(px, kb, lq);
                 DZN_CHECK(off >= 0 && off + 16 <= PL, 0x501, off);                               // fragment read inside its ring plane
                 xf[m][0] = *reinterpret_cast<const u32x4*>(ring + off);
-                xf[m][1] = *reinterpret_cast<const u32x4*>(ring + PL + off);
+                if constexpr (NP == 2) xf[m][1] = *reinterpret_cast<const u32x4*>(ring + PL + off);
               }
 #pragma unroll
-              for (int tt = 0; tt < 3; ++tt)
+              for (int tt = 0; tt < SplitTerms<NP>::N; ++tt)
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                  acc[2 * g + m] = mfma_np<2>(wf[t][SplitTerms<2>::A[tt]], xf[m][SplitTerms<2>::B[tt]], acc[2 * g + m]);
+                  acc[2 * g + m] = mfma_np<NP>(wf[t][SplitTerms<NP>::A[tt]], xf[m][SplitTerms<NP>::B[tt]], acc[2 * g + m]);
             }
           }
     };
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(2 * (C / 16) * 64, C == 32 ? 2 : 1) void resblock_w
         store_row(q);
       }
     } else {
-      for (int i = tid; i < 2 * ROW / 16; i += NWH * 64) {
+      for (int i = tid; i < NP * ROW / 16; i += NWH * 64) {
         const int p = i / (ROW / 16), j = i - p * (ROW / 16);
         reinterpret_cast<float4*>(sM + p * PL)[j] = make_float4(0.f, 0.f, 0.f, 0.f);     // slot 0 = row -1
       }
@@ -217,12 +219,17 @@ __global__ __launch_bounds__(2 * (C / 16) * 64, C == 32 ? 2 : 1) void resblock_w
             // channels 16 ocb + 4 lq + e: k-block ocb / 2, chunk lq, bytes 8 (ocb % 2) .. + 7 of the chunk
             f32x2 x01 = {v[0], v[1]}, x23 = {v[2], v[3]};
             const f16x2 h01 = __builtin_convertvector(x01, f16x2), h23 = __builtin_convertvector(x23, f16x2);
-            const f32x2 f01 = __builtin_convertvector(h01, f32x2), f23 = __builtin_convertvector(h23, f32x2);
-            f32x2 r01 = {x01[0] - f01[0], x01[1] - f01[1]}, r23 = {x23[0] - f23[0], x23[1] - f23[1]};
-            const f16x2 l01 = __builtin_convertvector(r01, f16x2), l23 = __builtin_convertvector(r23, f16x2);
-            const int off = ws_pix_off<C>(j, ocb >> 1, lq) + (ocb & 1) * 8;
-            *reinterpret_cast<uint2*>(mdst + off) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-            *reinterpret_cast<uint2*>(mdst + PL + off) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+            if constexpr (NP == 2) {
+              const f32x2 f01 = __builtin_convertvector(h01, f32x2), f23 = __builtin_convertvector(h23, f32x2);
+              f32x2 r01 = {x01[0] - f01[0], x01[1] - f01[1]}, r23 = {x23[0] - f23[0], x23[1] - f23[1]};
+              const f16x2 l01 = __builtin_convertvector(r01, f16x2), l23 = __builtin_convertvector(r23, f16x2);
+              const int off = ws_pix_off<C>(j, ocb >> 1, lq) + (ocb & 1) * 8;
+              *reinterpret_cast<uint2*>(mdst + off) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+              *reinterpret_cast<uint2*>(mdst + PL + off) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+            } else {
+              const int off = ws_pix_off<C>(j, ocb >> 1, lq) + (ocb & 1) * 8;
+              *reinterpret_cast<uint2*>(mdst + off) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+            }
           }
         }
       } else {
@@ -264,19 +271,19 @@ __global__ __launch_bounds__(2 * (C / 16) * 64, C == 32 ? 2 : 1) void resblock_w
   }
 }
 
-template <int C>
+template <int C, int NP>
 int launch_ws(const ResBlockWsArgs& a, int B, int Ws, hipStream_t s) {
   constexpr int KB = C / 32;
-  const size_t lds = (size_t)2 * 2 * 4 * WS_PXR * WsLayout<C>::PITCH;
+  const size_t lds = (size_t)2 * NP * 4 * WS_PXR * WsLayout<C>::PITCH;
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_ws_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_ws_kernel<C, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   const int nstrip = (Ws + WS_OUT - 1) / WS_OUT;
   const int64_t nitem = (int64_t)B * nstrip;
   const int slots = C == 32 ? 512 : 256;                 // persistent: 2 / 1 workgroups per CU
   const int grid = (int)(nitem < slots ? nitem : slots);
-  hipLaunchKernelGGL(resblock_ws_kernel<C>, dim3(grid), dim3(2 * (C / 16) * 64), lds, s, a);
+  hipLaunchKernelGGL((resblock_ws_kernel<C, NP>), dim3(grid), dim3(2 * (C / 16) * 64), lds, s, a);
   return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
@@ -286,14 +293,15 @@ int launch_ws(const ResBlockWsArgs& a, int B, int Ws, hipStream_t s) {
 // folded [C][9 C] weights (dzn_op_split_weights_h2, k = (dh*3 + dw) * C + ci), cs = inverse row scales, b = folded BN shifts.
 int launch_resblock_ws(const float* in, float* out, const void* W1, const float* cs1, const float* b1, const void* W2,
                        const float* cs2, const float* b2, const float* amax_in, float* amax_out, float l1max1, float bmax1,
-                       int B, int Hs, int Ws, int C, hipStream_t s, const int* z_count, const int* z_list) {
+                       int B, int Hs, int Ws, int C, hipStream_t s, const int* z_count, const int* z_list, int np) {
   if (B <= 0 || Hs <= 0 || Ws <= 0) return DZN_OK;
-  if (!in || !out || !W1 || !W2 || !cs1 || !cs2 || !b1 || !b2 || !amax_in || (C != 32 && C != 64)) return DZN_E_INVALID;
+  if (!in || !out || !W1 || !W2 || !cs1 || !cs2 || !b1 || !b2 || !amax_in || (C != 32 && C != 64) || (np != 1 && np != 2)) return DZN_E_INVALID;
   ResBlockWsArgs a{in, out, static_cast<const u16*>(W1), static_cast<const u16*>(W2), b1, b2, cs1, cs2, amax_in, amax_out,
                    l1max1, bmax1, B, Hs, Ws, z_list ? z_count : nullptr, z_count ? z_list : nullptr};
-  const int pid = prof_begin(s, C == 32 ? "resblock32_ws_f32h" : "resblock64_ws_f32h",
+  const int pid = prof_begin(s, np == 2 ? (C == 32 ? "resblock32_ws_f32h" : "resblock64_ws_f32h") : (C == 32 ? "resblock32_ws_f16" : "resblock64_ws_f16"),
                              2.0 * 2.0 * B * Hs * (double)Ws * C * (9.0 * C), (double)B * Hs * Ws * C * 4.0 * 2.0);
-  const int rc = C == 32 ? launch_ws<32>(a, B, Ws, s) : launch_ws<64>(a, B, Ws, s);
+  const int rc = np == 2 ? (C == 32 ? launch_ws<32, 2>(a, B, Ws, s) : launch_ws<64, 2>(a, B, Ws, s))
+                         : (C == 32 ? launch_ws<32, 1>(a, B, Ws, s) : launch_ws<64, 1>(a, B, Ws, s));
   prof_end(pid, s);
   return rc;
 }
@@ -302,5 +310,5 @@ extern "C" int dzn_op_resblock_ws(const float* in, float* out, const void* W1, c
                                   const void* W2, const float* cs2, const float* b2, const float* amax_in, float l1max1,
                                   float bmax1, int32_t B, int32_t Hs, int32_t Ws, int32_t C, void* stream) {
   return launch_resblock_ws(in, out, W1, cs1, b1, W2, cs2, b2, amax_in, nullptr, l1max1, bmax1, B, Hs, Ws, C,
-                            reinterpret_cast<hipStream_t>(stream), nullptr, nullptr);
+                            reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, op_resblock_np());
 }

@@ -125,6 +125,11 @@ template <> struct SplitTerms<2> {
   static constexpr int A[3] = {1, 0, 0};
   static constexpr int B[3] = {0, 1, 0};
 };
+template <> struct SplitTerms<1> {     // leading fp16 term only (DZN_PREC_F16 single-term sites)
+  static constexpr int N = 1;
+  static constexpr int A[1] = {0};
+  static constexpr int B[1] = {0};
+};
 
 // 8 fp32 values -> NP fragments (hi, [mid,] lo); `scale` (exact power of two) applies to NP = 2 only
 template <int NP>
@@ -135,7 +140,9 @@ __device__ __forceinline__ void split_np(const f32x4& u, const f32x4& v, float s
     f[0] = __builtin_bit_cast(u32x4, h_);
     f[1] = __builtin_bit_cast(u32x4, m_);
     f[2] = __builtin_bit_cast(u32x4, l_);
-  } else {
+  } else if constexpr (NP == 2) {
     split8_h2(u, v, scale, f[0], f[1]);
+  } else {
+    cvt8_h1(u, v, scale, f[0]);
   }
 }

@@ -263,6 +263,16 @@ int dzn_vbx_estep(void* state, const double* h_alpha, const double* h_ck, const 
 int dzn_vbx_gamma(void* state, double* h_gamma);
 int dzn_vbx_destroy(void* state);
 
+/* Row f3, audio ingest: native FLAC decoder (csrc/flac.cpp, host code; the reference reads whatever torchaudio.load does,
+ * diarizen/pipelines/inference.py:127 — WAV is parsed in diarizen_amd/audio.py, FLAC here).  Frame-header CRC-8 and frame
+ * CRC-16 are verified while decoding; the caller checks the STREAMINFO MD5 (audio.load_flac does).
+ *   dzn_flac_info    stream parameters from STREAMINFO (any output pointer may be NULL); total_samples 0 = unknown
+ *   dzn_flac_decode  out = int32 [capacity_samples][channels], interleaved, sign-extended; *decoded = samples per channel.
+ * Returns DZN_OK, DZN_E_INVALID (not FLAC / corrupt / unsupported), DZN_E_NOMEM (capacity too small). */
+int dzn_flac_info(const uint8_t* data, size_t n, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample,
+                  int64_t* total_samples, uint8_t* md5_16);
+int dzn_flac_decode(const uint8_t* data, size_t n, int32_t* out, int64_t capacity_samples, int64_t* decoded);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,6 +137,10 @@ int dzn_op_resblock_ws(const float* in, float* out, const void* W1, const float*
                        const float* cs2, const float* b2, const float* amax_in, float l1max1, float bmax1, int32_t B,
                        int32_t Hs, int32_t Ws, int32_t C, void* stream);
 
+/* test knob: terms per operand the two entry points above run with — 2 (default, DZN_PREC_F32_H2) or 1 (the DZN_PREC_F16 form:
+ * leading fp16 term only, plane 0 of the same weight buffers) */
+int dzn_op_set_resblock_np(int32_t np);
+
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
 
 /* Exact 3-way bf16 split of fp32 weights for DZN_PREC_F32_SPLIT (csrc/gemm_split.hip):
