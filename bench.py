@@ -68,7 +68,7 @@ DTYPE_NOTE = {"f32": "f32 (fp32 MFMA v_mfma_f32_16x16x4_f32)",
                      "softmax, residual stream fp32"}
 PEAK_HBM_GBS = 8000.0
 TRAFFIC_SOURCE = ("committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x 2 "
-                  "correction; scripts/final_measure_r4.sh, final_measure_r4b.sh -> profiles/) — not measured in this run")
+                  "correction; scripts/final_measure_r5.sh -> profiles/) — not measured in this run")
 # what holds the results of this path to the reference's (tests/ -m gpu, all through the C ABI; fixtures made by
 # oracle/gen_golden.py from the reference's own code)
 PARITY_NOTE = {
@@ -116,8 +116,9 @@ PMC_SYMBOLS = {"conv0_ln_gelu": "conv0_kernel", "conv01_fused": "conv01_fused_ke
                "layernorm": "layernorm_v4_kernel<16", "row_stats": "row_stats_kernel<16>", "gate_ln_stats": "gate_stats_kernel",
                "ws_sum": "ws_sum_kernel", "stem_conv": "stem_conv_kernel", "glu_dwconv": "glu_dwconv_kernel",
                "stats_pool": "stats_pool_kernel", "pad_rows_split2": "pad_rows_split2_kernel",
-               "resblock32_fused_f32h": "resblock32_fused_kernel<2>", "resblock64_ws_f32h": "resblock_ws_kernel<64>",
-               "resblock32_ws_f32h": "resblock_ws_kernel<32>"}
+               "resblock32_fused_f32h": "resblock32_fused_kernel<2>", "resblock64_ws_f32h": "resblock_ws_kernel<64, 2>",
+               "resblock32_ws_f32h": "resblock_ws_kernel<32, 2>", "resblock32_fused_f16": "resblock32_fused_kernel<1>",
+               "resblock64_ws_f16": "resblock_ws_kernel<64, 1>", "resblock32_ws_f16": "resblock_ws_kernel<32, 1>"}
 
 
 class PowerSampler:
@@ -177,12 +178,12 @@ class PowerSampler:
                           "profiles/r4_power_cap.txt)"}
 
 
-def pmc_table(args):
+def pmc_table(args, precision=None):
     """HBM bytes per launch / MfmaUtil per kernel from the committed rocprofv3 --pmc passes of this same command
     (separate passes per counter, gfx950 FETCH_SIZE correction: scripts/pmc_traffic.py, scripts/pmc_mfma.py).
     bench.py cannot run rocprofv3 on itself, so the table is read from profiles/ and only when the workload matches
     the one the passes were taken on; otherwise `traffic` is null."""
-    found = sorted((ROOT / "profiles").glob(f"r*_pmc_{args.precision}_30min_b{args.batch}.json"))   # newest round last
+    found = sorted((ROOT / "profiles").glob(f"r*_pmc_{precision or args.precision}_30min_b{args.batch}.json"))   # newest round last
     if not found or args.minutes != 30.0 or args.model != "wavlm_large_s80_md" or args.window != 8.0:
         return None
     table = json.loads(found[-1].read_text())
@@ -194,7 +195,15 @@ def pmc_lookup(table, kernel_class: str, field: str):
     if not table:
         return None
     key = None
-    for tag, planes in (("gemm_f32h_pre_", 2), ("gemm_f32s_pre_", 3), ("gemm_f32h_", 2), ("gemm_f32s_", 3)):
+    if kernel_class.startswith("gemm_mx_"):          # gemm_mx_kernel<BM, BN, WGM, WGN, S, OCC, RPF>
+        bm, bn = kernel_class[len("gemm_mx_"):].split("_")[0].split("x")
+        for k in table:
+            if k.startswith("gemm_mx_kernel<"):
+                targs = [t.strip() for t in k[len("gemm_mx_kernel<"):].rstrip(">").split(",")]
+                if len(targs) >= 2 and targs[0] == bm and targs[1] == bn:
+                    return table[k].get(field)
+        return None
+    for tag, planes in (("gemm_f32h_pre_", 2), ("gemm_f32s_pre_", 3), ("gemm_f32h_", 2), ("gemm_f32s_", 3), ("gemm_f16_pre_", 1), ("gemm_f16_", 1)):
         if kernel_class.startswith(tag):
             bm, bn = kernel_class[len(tag):].split("x")
             sym = "gemm_split_pre_kernel" if "_pre_" in tag else "gemm_split_kernel"
@@ -972,6 +981,9 @@ def main():
                     red["roofline"] = {"kernel": top16["name"], "bound": "mfma", "achieved": round(ach16, 2),
                                        "peak": PEAK_TFLOPS["mx"], "unit": "TFLOP/s", "frac": round(ach16 / PEAK_TFLOPS["mx"], 4),
                                        "share_of_profiled": round(top16["ms"] / tot16, 4), "launches": top16["launches"],
+                                       "alg_bytes_per_launch": int(top16["bytes"] / top16["launches"]) if top16["bytes"] > 0 else None,
+                                       "pmc_mfma_util_pct": pmc_lookup(pmc_table(args, "f16"), top16["name"], "mfma_util_pct"),
+                                       "traffic": pmc_lookup(pmc_table(args, "f16"), top16["name"], "hbm_bytes_per_launch"),
                                        "avg_launch_ms": round(top16["ms"] / top16["launches"], 4),
                                        "note": "peak = the mix actually issued: per 32x32x64 block 4 fp16 MFMAs (8 passes) + 2 block-scaled "
                                                "fp8 MFMAs (16 passes) = 64 passes = fp16 dense peak / 2; the same mix issue-bound in a "

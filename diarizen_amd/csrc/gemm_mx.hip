@@ -481,6 +481,7 @@ int launch_gemm_mx(const dzn_gemm_desc& d, hipStream_t s) {
   if (force && !strcmp(force, "128x64")) return launch_mx_cfg<128, 64, 4, 1, 2, 3>(d, s);
   if (force && !strcmp(force, "128x128")) return launch_mx_cfg<128, 128, 4, 1, 2, 2>(d, s);
   if (force && !strcmp(force, "128x64rpf")) return launch_mx_cfg<128, 64, 4, 1, 2, 2, true>(d, s);
+  if (force && !strcmp(force, "256x128")) return launch_mx_cfg<256, 128, 8, 1, 2, 2>(d, s);     // probe: 8 wavefronts, one workgroup per CU
   if (narrow) return launch_mx_cfg<128, 64, 4, 1, 2, 3>(d, s);
   return launch_mx_cfg<128, 128, 4, 1, 2, 2>(d, s);
 }

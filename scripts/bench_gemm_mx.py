@@ -26,7 +26,8 @@ for spec in sys.argv[1:]:
             ("mx auto", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "auto"),
             ("mx 128x128", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "128x128"),
             ("mx 128x64", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "128x64"),
-            ("mx 128x64rpf", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "128x64rpf")]
+            ("mx 128x64rpf", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "128x64rpf"),
+            ("mx 256x128", 4, dict(base, Wmx=Wmx, col_scale_mx=csm), "256x128")]
     for name, prec, kw, force in runs:
         if force is not None:
             lib.dzn_op_set_gemm_mx_cfg(force.encode())
