@@ -48,12 +48,13 @@ import torch  # noqa: E402
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32s": 2500.0 / 6.0, "f32h": 2500.0 / 3.0, "f16": 2500.0, "mx": 2500.0 / 2.0}
 
 
-def prec_of(kernel_class: str) -> str:
-    """arithmetic of a profiled kernel class, from its name"""
+def prec_of(kernel_class: str, default: str = "f32") -> str:
+    """arithmetic of a profiled kernel class, from its name; classes whose name carries no tag (conv01_fused: conv1 on the split
+    MFMA forms of the engine mode) take `default`"""
     for tag in ("bf16", "f32s", "f32h", "mx", "f16"):
         if tag in kernel_class:
             return tag
-    return "f32"
+    return "f32" if "gemm_f32_" in kernel_class else default
 DTYPE_NOTE = {"f32": "f32 (fp32 MFMA v_mfma_f32_16x16x4_f32)",
               "f32s": "f32 (operands split exactly into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate)",
               "f32h": "f32 (operands split into 2 fp16 terms with exact power-of-two scaling = 22 significant bits, 3 fp16 MFMA "
@@ -401,10 +402,36 @@ def e2e_leg(args, dev, wave_host, sd, esd):
     host_s /= K
     audio_s = len(x) / 16000.0
     active = int((seg.sum(1) > 0).sum())
+    # the same object over a CORPUS (DiariZenPipeline.diarize_many, the reference's `for audio_file in audio_f:` loop,
+    # diarizen/pipelines/inference.py:365-368): K + 1 in-memory 16-bit WAV files of the recording, decode + upload + device
+    # stage of file i+1 beside the host stage of file i
+    import io
+    import wave as _wave
+    buf = io.BytesIO()
+    with _wave.open(buf, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes((np.clip(x, -1.0, 1.0) * 32767.0).astype("<i2").tobytes())
+    blob = buf.getvalue()
+    corpus = {}
+    for overlap in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_done = sum(1 for _ in pipe.diarize_many([blob] * (K + 1), sess_names=[f"bench{i}" for i in range(K + 1)], overlap=overlap))
+        torch.cuda.synchronize()
+        corpus["overlapped" if overlap else "serial"] = round(audio_s * n_done / (time.perf_counter() - t0), 1)
+    pipe.close()      # (r5) both engine handles now: the pipeline object sits in a reference cycle (runner -> engine factory -> pipeline)
+                      # and its 160 GB stayed allocated until the cycle collector ran — the configs[1] leg behind it then ran against
+                      # a nearly full HBM (3.7 k instead of 4.5 k audio-s/s in the first r5 runs; `--only-config1` read 4560)
     return {"audio_seconds_per_s": round(audio_s / (dev_s + host_s), 1), "steps": K, "s_per_step": per,
             "device_s": round(dev_s, 4), "host_s": round(host_s, 4), "upload_included": True,
             "speakers": len(ann.labels()), "rttm_lines": len(ann.to_rttm().splitlines()),
             "active_window_speakers": active,
+            "corpus_audio_seconds_per_s": corpus,
+            "corpus_note": f"DiariZenPipeline.diarize_many over {K + 1} in-memory 16-bit WAV copies of the recording (WAV decode + upload + "
+                           "device stage + host stage each): serial = one after the other as the reference's loop, overlapped = the host "
+                           "stage of file i in a worker thread beside the decode + device stage of file i+1",
             "note": "mean of `steps` passes of DiariZenPipeline: host->HBM upload + segmentation + masks + embeddings + D2H "
                     "(device_s), then host counting + AHC (centroid linkage) + constrained assignment + reconstruction + "
                     "RTTM (host_s); same recording and seeded turn-taking weights as the headline steps"}
@@ -626,6 +653,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi (package power, sclk) during the timed steps")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra steps in the other fp32 modes")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run every step's host stage serially behind its device stage (the steps of the first r5 runs)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (device + host AHC) leg")
     ap.add_argument("--e2e-steps", type=int, default=3, help="timed passes of the end-to-end leg (upload + device + host AHC)")
     ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE configs[1] leg (base-s80, 5 s x 32, segmentation only)")
@@ -735,7 +764,7 @@ def main():
                                          threshold=clu["ahc_threshold"])
     clustering.device = dev.index if dev.index is not None else 0
     chunks_sw = SlidingWindow(start=0.0, duration=args.window, step=0.1 * args.window)
-    acc = {"on": False, "device_s": 0.0, "host_s": 0.0, "speakers": 0, "rttm_lines": 0}
+    acc = {"on": False, "device_s": 0.0, "host_s": 0.0, "host_wait_s": 0.0, "speakers": 0, "rttm_lines": 0}
 
     def host(seg_t, emb_t):
         ann = run_host_stage(seg_t.numpy(), emb_t.numpy(), chunks=chunks_sw, clustering=clustering,
@@ -769,24 +798,51 @@ def main():
             return own
         return res.segmentations.cpu(), res.embeddings.cpu()
 
-    def step():
+    # (r5) consecutive steps form a two-stage software pipeline, as DiariZenPipeline.diarize_many does over a
+    # corpus: the host stage of step i runs in a worker thread WHILE the device stage of step i+1 executes (the host stage's
+    # device work has its own high-priority stream and arena: csrc/linkage.hip, postprocess.DevicePost).  Every step's host
+    # stage completes inside the timed region (drain() before the closing synchronise).  --no-overlap = the serial steps of the
+    # first r5 runs; `serial_ms_per_step` reports them from extra steps either way.
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dzn-host-stage") if full and not args.no_overlap else None
+    pending = [None]
+
+    def host_timed(seg_t, emb_t):
+        t = time.perf_counter()
+        host(seg_t, emb_t)
+        if acc["on"]:
+            acc["host_s"] += time.perf_counter() - t
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].result()
+            pending[0] = None
+
+    def step(serial=False):
         t_a = time.perf_counter()
         seg_t, emb_t = device_part()               # the .cpu() copies inside synchronise
         t_b = time.perf_counter()
         if full and seg_t is not None:
-            host(seg_t, emb_t)
+            if pool is None or serial:
+                drain()
+                host_timed(seg_t, emb_t)
+            else:
+                drain()                            # step i-1's host stage (ran beside this step's device stage)
+                pending[0] = pool.submit(host_timed, seg_t, emb_t)
         if acc["on"]:
             acc["device_s"] += t_b - t_a
-            acc["host_s"] += time.perf_counter() - t_b
+            acc["host_wait_s"] += time.perf_counter() - t_b
 
     for _ in range(args.warmup):
         step()
+    drain()
     # the in-situ HIP-event profiler runs INSIDE the timed steps (two event records per launch on the launch stream;
     # measured cost 1 % of the step, reported as `unprofiled_ms_per_step` from one extra step below)
     if not args.no_profile:
         # one untimed profiled step sizes the event pool: the timed region must not create HIP events
         _lib.profile_enable(True)
         step()
+        drain()
         launches = sum(p["launches"] for p in _lib.profile_collect())
         _lib.profile_reserve(2 * launches * args.steps + 1024)
     if dist is not None:
@@ -799,6 +855,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_tail = time.perf_counter()
+    drain()                                     # the last step's host stage: nothing left to hide it behind
+    acc["host_wait_s"] += time.perf_counter() - t_tail
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0           # this rank's own K steps (before it waits for the others)
     acc["on"] = False
@@ -823,9 +882,12 @@ def main():
         dev_max_s = acc["device_s"]
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    step()
+    for _ in range(2):
+        step(serial=True)                       # device stage, THEN host stage: the step of the first r5 runs, unprofiled
     torch.cuda.synchronize()
-    unprofiled_ms = (time.perf_counter() - t1) * 1e3
+    unprofiled_ms = (time.perf_counter() - t1) * 1e3 / 2
+    if pool is not None:
+        pool.shutdown(wait=True)
 
     strong_min = args.strong_minutes if args.strong_minutes is not None else (240.0 if world > 1 else 0.0)
     strong_res = None
@@ -856,7 +918,7 @@ def main():
                 # which roof the class sits under: algorithmic intensity against the ridge of ITS arithmetic (peak flops of the
                 # class's MFMA mix / 8 TB/s); classes below the ridge are priced against HBM, the others against the matrix pipe
                 if p["ms"] > 0 and (p["flops"] > 0 or p["bytes"] > 0):
-                    pk = PEAK_TFLOPS[prec_of(p["name"])]
+                    pk = PEAK_TFLOPS[prec_of(p["name"], {"f16": "f32h", "bf16": "bf16"}.get(args.precision, args.precision))]
                     mfma_bound = p["flops"] > 0 and (p["bytes"] <= 0 or p["flops"] / p["bytes"] >= pk * 1e12 / (PEAK_HBM_GBS * 1e9))
                     e["bound"] = "mfma" if mfma_bound else "hbm"
                     e["frac_of_bound"] = round((e["tflops"] / pk) if mfma_bound else (e.get("gbs", 0.0) / PEAK_HBM_GBS), 4)
@@ -947,11 +1009,17 @@ def main():
             "windows_per_s": round((1 if strong else world) * n_windows * args.steps / dt, 1),
             "device_value": round(device_value, 2) if device_value else None,
             "step_breakdown": {"device_ms": round(acc["device_s"] / args.steps * 1e3, 2), "host_ms": round(acc["host_s"] / args.steps * 1e3, 2),
+                               "host_exposed_ms": round(acc["host_wait_s"] / args.steps * 1e3, 2),
+                               "host_stage_overlapped": pool is not None,
                                "speakers": acc["speakers"], "rttm_lines": acc["rttm_lines"],
                                "note": "rank 0's own steps: device = hot path + D2H of the u8 decisions / f32 embeddings (+ the all-gather "
                                        "at N > 1), host = run_host_stage (device linkage / cdist / aggregations from their size "
-                                       "thresholds up) + RTTM text"},
+                                       "thresholds up) + RTTM text, as busy time of the worker thread; host_exposed = what the stepping "
+                                       "thread waited for it (step i's host stage runs beside step i+1's device stage; the last one of "
+                                       "the K is drained inside the timed region)"},
             "unprofiled_ms_per_step": round(unprofiled_ms, 2),
+            "serial_ms_per_step": round(unprofiled_ms, 2),
+            "serial_value": round(total_audio * 1e3 / unprofiled_ms, 2),
             "roofline": roofline,
             "power": power.result() if power else None,
             "roofline_extra": extra,
@@ -1025,7 +1093,9 @@ def main():
         if strong_res is not None:
             out["strong_scaling_e2e"] = strong_res
         if world == 1 and not args.no_config1:
-            eng = None
+            eng = runner = None
+            import gc
+            gc.collect()
             torch.cuda.empty_cache()
             out["config1"] = config1_leg(args, dev)
         if not args.no_cpu_baseline and world == 1 and full:

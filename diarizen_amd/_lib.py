@@ -159,6 +159,8 @@ def load() -> C.CDLL:
     sig("dzn_op_relpos_bucket", i32, [i32, i32, i32])
     sig("dzn_linkage_centroid", i32, [vp, i32, i32, vp, i32])
     sig("dzn_cdist_cosine", i32, [vp, i32, i32, vp, i32, vp, i32])
+    sig("dzn_host_workspace_release", i32, [i32])
+    sig("dzn_host_workspace_bytes", i64, [i32])
     sig("dzn_vbx_create", i32, [vp, vp, vp, i32, i32, i32, i32, C.POINTER(C.c_void_p)])
     sig("dzn_vbx_stats", i32, [vp, vp])
     sig("dzn_vbx_estep", i32, [vp, vp, vp, vp, C.c_double, C.POINTER(C.c_double)])
@@ -193,7 +195,8 @@ def load() -> C.CDLL:
 EXPORTED = [
     "dzn_create", "dzn_load_tensor", "dzn_finalize_weights", "dzn_num_frames",
     "dzn_segment_forward", "dzn_embed_forward", "dzn_prepare_masks", "dzn_speaker_count", "dzn_cluster_activations", "dzn_debug_fetch", "dzn_embed_skip_stats", "dzn_num_ignored",
-    "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid", "dzn_cdist_cosine",
+    "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid", "dzn_cdist_cosine", "dzn_host_workspace_release",
+    "dzn_host_workspace_bytes",
     "dzn_flac_info", "dzn_flac_decode", "dzn_vbx_create", "dzn_vbx_stats", "dzn_vbx_estep", "dzn_vbx_gamma", "dzn_vbx_destroy",
     "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_split_weights_mx", "dzn_op_set_gemm_mx_cfg", "dzn_checked_status", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_resblock32_fused", "dzn_op_resblock_ws", "dzn_op_set_resblock_np", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",
     "dzn_profile_enable", "dzn_profile_collect", "dzn_profile_reserve", "dzn_op_relpos_bucket",

@@ -71,6 +71,9 @@ constexpr int MX_SCALE_LO = 127 - 11;
 // 8 fp32 values of one k chunk (two float4), scaled by the exact power of two s  ->  the fp16 fragment, 8 bytes fp8(x s) and
 // 8 bytes fp8((x s - fp16(x s)) 2^11).  Per pair: 2 v_mul, v_cvt_pk_f16_f32 (nearest even), 2 v_cvt_f32_f16, 2 v_sub (exact),
 // 2 v_mul, 2 v_cvt_pk_fp8_f32.
+// (r5 probe, removed: applying the remainder's 2^11 through v_cvt_scalef32_pk_fp8_f32's scale operand — the conversion DIVIDES by
+// it — saves two of the eleven VALU operations per pair and measured +1 %, 314 -> 317 TFLOP/s at N = K = 1024:
+// profiles/r5_mx_cvtscale_probe.txt.  The kernel is bound by its LDS-DMA fill, not by this chain.)
 __device__ __forceinline__ void split8_mx(const f32x4& u, const f32x4& v, float s, u32x4& hi, int& h8a, int& h8b, int& l8a, int& l8b) {
   h8a = h8b = l8a = l8b = 0;
 #pragma unroll
@@ -80,12 +83,15 @@ __device__ __forceinline__ void split8_mx(const f32x4& u, const f32x4& v, float 
     x[1] = (p < 2 ? u[2 * p + 1] : v[2 * p - 3]) * s;
     const f16x2 h = __builtin_convertvector(x, f16x2);
     const f32x2 hf = __builtin_convertvector(h, f32x2);
-    const float r0 = (x[0] - hf[0]) * MX_LO_UP, r1 = (x[1] - hf[1]) * MX_LO_UP;
     hi[p] = __builtin_bit_cast(unsigned, h);
-    if (p == 0) { h8a = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], h8a, false); l8a = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, l8a, false); }
-    if (p == 1) { h8a = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], h8a, true);  l8a = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, l8a, true); }
-    if (p == 2) { h8b = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], h8b, false); l8b = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, l8b, false); }
-    if (p == 3) { h8b = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], h8b, true);  l8b = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, l8b, true); }
+    int& h8 = p < 2 ? h8a : h8b;
+    int& l8 = p < 2 ? l8a : l8b;
+    // (the word-select argument of the conversions must be a literal)
+    if (p & 1) h8 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], h8, true);
+    else h8 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], h8, false);
+    const float r0 = (x[0] - hf[0]) * MX_LO_UP, r1 = (x[1] - hf[1]) * MX_LO_UP;
+    if (p & 1) l8 = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, l8, true);
+    else l8 = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, l8, false);
   }
 }
 

@@ -26,7 +26,7 @@
 #include <stdio.h>
 
 #include <chrono>
-
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -534,20 +534,99 @@ __global__ __launch_bounds__(LB_BLK) void step_kernel(double* __restrict__ D, in
     if ((call) != hipSuccess) { rc = DZN_E_HIP; goto done; } \
   } while (0)
 
+
+
+// ---- the host stage's device context (r5) -----------------------------------------------------------------------------
+// The clustering entry points below are called from the HOST stage of the pipeline, which (pipeline.diarize_many, bench.py)
+// now runs in its own thread WHILE the engine executes the device stage of the next recording.  So they must not touch the
+// legacy null stream (its copies and launches order themselves behind every kernel the engine has queued) and must not
+// hipFree (a device-wide synchronisation: the host thread would sit out the engine's whole queue).  Per device:
+//   * one non-blocking stream of the highest priority the device offers — the single-workgroup-per-256-rows step kernels are
+//     latency bound, their workgroups are placed as soon as a CU of the engine's launches drains;
+//   * one grow-only arena that every call carves its buffers from (re-allocated only when a call needs more than any before
+//     it; dzn_host_workspace_release() returns it).  A mutex serialises the calls of one process.
+struct HostCtx {
+  hipStream_t stream = nullptr;
+  char* base = nullptr;
+  size_t cap = 0;
+};
+constexpr int MAX_DEV = 64;
+std::mutex g_host_mu;
+HostCtx g_host[MAX_DEV];
+
+// the context of the CURRENT device with an arena of at least `bytes` (g_host_mu held)
+int host_ctx(int device, size_t bytes, HostCtx** out) {
+  int dev = device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return DZN_E_HIP;
+  if (dev < 0 || dev >= MAX_DEV) return DZN_E_INVALID;
+  HostCtx& c = g_host[dev];
+  if (!c.stream) {
+    int lo = 0, hi = 0;      // "least" and "greatest" priority: numerically greatest = lowest
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+    if (hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi) != hipSuccess) {
+      c.stream = nullptr;
+      return DZN_E_HIP;
+    }
+  }
+  if (bytes > c.cap) {
+    if (c.base) {
+      (void)hipStreamSynchronize(c.stream);
+      (void)hipFree(c.base);
+      c.base = nullptr;
+      c.cap = 0;
+    }
+    const size_t want = bytes + bytes / 8;      // a little headroom: recordings of one corpus differ by a few rows
+    if (hipMalloc(&c.base, want) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipMalloc(&c.base, bytes) != hipSuccess) { (void)hipGetLastError(); c.base = nullptr; return DZN_E_NOMEM; }
+      c.cap = bytes;
+    } else {
+      c.cap = want;
+    }
+  }
+  *out = &c;
+  return DZN_OK;
+}
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(char* b) : base(b) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (count * sizeof(T) + 255) & ~(size_t)255;
+    return p;
+  }
+};
+
 }  // namespace
+
+extern "C" int dzn_host_workspace_release(int32_t device) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  for (int dev = 0; dev < MAX_DEV; ++dev) {
+    if (device >= 0 && dev != device) continue;
+    HostCtx& c = g_host[dev];
+    if (!c.base && !c.stream) continue;
+    DeviceGuard dg(dev);
+    if (!dg.ok) return DZN_E_HIP;
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    if (c.base) (void)hipFree(c.base);
+    c.base = nullptr;
+    c.cap = 0;
+  }
+  return DZN_OK;
+}
+
+extern "C" int64_t dzn_host_workspace_bytes(int32_t device) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  return device >= 0 && device < MAX_DEV ? (int64_t)g_host[device].cap : 0;
+}
 
 extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, double* h_Z, int32_t device) {
   if (!h_emb || !h_Z || n < 2 || dim < 1) return DZN_E_INVALID;
   int rc = DZN_OK;
-  float* E = nullptr;
-  double *D = nullptr, *lb = nullptr, *Z = nullptr, *bmin = nullptr, *hp_val = nullptr;
-  int *nb = nullptr, *size = nullptr, *cid = nullptr, *barg = nullptr, *hp_idx = nullptr;
   const int nblk = (n + LB_BLK - 1) / LB_BLK;
-  MergeState* st = nullptr;
-  StepState* st2 = nullptr;
-  StepRec* rec2 = nullptr;
-  StepPart* part2 = nullptr;
-  int* exf = nullptr;
   // DZN_LINKAGE_TWO_KERNEL=1: the r2 loop (one single-workgroup selection + one wide update per merge), kept for A/B timing
   const bool two_kernel = getenv("DZN_LINKAGE_TWO_KERNEL") != nullptr;
   std::vector<int> ones(n, 1), ids(n);
@@ -555,44 +634,62 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   MergeState st0{};
   DeviceGuard dg(device);      // restores the caller's device on every return path
   if (!dg.ok) return DZN_E_HIP;
-  if (hipMalloc(&D, (size_t)n * n * sizeof(double)) != hipSuccess) { rc = DZN_E_NOMEM; goto done; }
-  LCHK(hipMalloc(&E, (size_t)n * dim * sizeof(float)));
-  LCHK(hipMalloc(&lb, (size_t)n * sizeof(double)));
-  LCHK(hipMalloc(&Z, (size_t)(n - 1) * 4 * sizeof(double)));
-  LCHK(hipMalloc(&nb, (size_t)n * sizeof(int)));
-  LCHK(hipMalloc(&size, (size_t)n * sizeof(int)));
-  LCHK(hipMalloc(&cid, (size_t)n * sizeof(int)));
-  LCHK(hipMalloc(&st, sizeof(MergeState)));
-  LCHK(hipMalloc(&bmin, (size_t)nblk * sizeof(double)));
-  LCHK(hipMalloc(&hp_val, (size_t)nblk * sizeof(double)));
-  LCHK(hipMalloc(&barg, (size_t)nblk * sizeof(int)));
-  LCHK(hipMalloc(&hp_idx, (size_t)nblk * sizeof(int)));
-  LCHK(hipMemcpy(E, h_emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice));
-  LCHK(hipMemcpy(size, ones.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-  LCHK(hipMemcpy(cid, ids.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-  LCHK(hipMemcpy(st, &st0, sizeof(MergeState), hipMemcpyHostToDevice));
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  // the buffers of one call, carved from the arena (first pass: sizes only)
+  float* E = nullptr;
+  double *D = nullptr, *lb = nullptr, *Z = nullptr, *bmin = nullptr, *hp_val = nullptr;
+  int *nb = nullptr, *size = nullptr, *cid = nullptr, *barg = nullptr, *hp_idx = nullptr, *exf = nullptr;
+  MergeState* st = nullptr;
+  StepState* st2 = nullptr;
+  StepRec* rec2 = nullptr;
+  StepPart* part2 = nullptr;
+  auto carve = [&](char* base) {
+    Carver c(base);
+    D = c.take<double>((size_t)n * n);
+    E = c.take<float>((size_t)n * dim);
+    lb = c.take<double>(n);
+    Z = c.take<double>((size_t)(n - 1) * 4);
+    nb = c.take<int>(n);
+    size = c.take<int>(n);
+    cid = c.take<int>(n);
+    st = c.take<MergeState>(1);
+    bmin = c.take<double>(nblk);
+    hp_val = c.take<double>(nblk);
+    barg = c.take<int>(nblk);
+    hp_idx = c.take<int>(nblk);
+    st2 = c.take<StepState>(2);
+    rec2 = c.take<StepRec>((size_t)2 * nblk);
+    part2 = c.take<StepPart>((size_t)2 * nblk);
+    exf = c.take<int>(n);
+    return c.off;
+  };
+  HostCtx* ctx = nullptr;
+  rc = host_ctx(device, carve(nullptr), &ctx);
+  if (rc != DZN_OK) return rc;
+  carve(ctx->base);
+  hipStream_t s = ctx->stream;
+  LCHK(hipMemcpyAsync(E, h_emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, s));
+  LCHK(hipMemcpyAsync(size, ones.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+  LCHK(hipMemcpyAsync(cid, ids.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+  LCHK(hipMemcpyAsync(st, &st0, sizeof(MergeState), hipMemcpyHostToDevice, s));
   {
     const int tiles = (n + 63) / 64;
-    hipLaunchKernelGGL(pdist_kernel, dim3(tiles, tiles), dim3(256), 0, 0, E, n, dim, D);
-    hipLaunchKernelGGL(init_rows_kernel, dim3(n), dim3(256), 0, 0, D, n, lb, nb);
+    hipLaunchKernelGGL(pdist_kernel, dim3(tiles, tiles), dim3(256), 0, s, E, n, dim, D);
+    hipLaunchKernelGGL(init_rows_kernel, dim3(n), dim3(256), 0, s, D, n, lb, nb);
     if (two_kernel) {
-      hipLaunchKernelGGL(block_minima_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, lb, n, bmin, barg);
+      hipLaunchKernelGGL(block_minima_kernel, dim3(nblk), dim3(LB_BLK), 0, s, lb, n, bmin, barg);
       for (int k = 0; k < n - 1; ++k) {
-        hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, 0, D, n, lb, nb, size, cid, Z, st, bmin, barg, hp_val,
+        hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, s, D, n, lb, nb, size, cid, Z, st, bmin, barg, hp_val,
                            hp_idx);
-        hipLaunchKernelGGL(update_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, D, n, lb, nb, size, st, bmin, barg, hp_val,
+        hipLaunchKernelGGL(update_kernel, dim3(nblk), dim3(LB_BLK), 0, s, D, n, lb, nb, size, st, bmin, barg, hp_val,
                            hp_idx);
       }
     } else {
       // one launch per step (merge or rescan); the number of rescans is data dependent, so launches are queued in
       // batches sized from the merges still missing and the step descriptor is read back between batches (surplus
       // launches after the last merge return at once)
-      LCHK(hipMalloc(&st2, 2 * sizeof(StepState)));
-      LCHK(hipMalloc(&rec2, (size_t)2 * nblk * sizeof(StepRec)));
-      LCHK(hipMalloc(&part2, (size_t)2 * nblk * sizeof(StepPart)));
-      LCHK(hipMalloc(&exf, (size_t)n * sizeof(int)));
-      LCHK(hipMemset(st2, 0, 2 * sizeof(StepState)));
-      hipLaunchKernelGGL(init_rec_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, n, lb, nb, exf, rec2);
+      LCHK(hipMemsetAsync(st2, 0, 2 * sizeof(StepState), s));
+      hipLaunchKernelGGL(init_rec_kernel, dim3(nblk), dim3(LB_BLK), 0, s, n, lb, nb, exf, rec2);
       int64_t launched = 0;
       int remaining = n - 1;
       const auto t_loop = std::chrono::steady_clock::now();
@@ -600,11 +697,12 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
         if (round > 64 + n) { rc = DZN_E_INVALID; goto done; }   // cannot happen: every batch completes >= 1 merge
         const int batch = remaining + remaining / 2 + 32;
         for (int i = 0; i < batch; ++i, ++launched)
-          hipLaunchKernelGGL(step_kernel, dim3(nblk), dim3(LB_BLK), 0, 0, D, n, lb, nb, size, cid, exf, Z, st2, rec2, part2,
+          hipLaunchKernelGGL(step_kernel, dim3(nblk), dim3(LB_BLK), 0, s, D, n, lb, nb, size, cid, exf, Z, st2, rec2, part2,
                              (int)(launched & 1));
         LCHK(hipGetLastError());
         StepState hs;
-        LCHK(hipMemcpy(&hs, st2 + (launched & 1), sizeof(StepState), hipMemcpyDeviceToHost));
+        LCHK(hipMemcpyAsync(&hs, st2 + (launched & 1), sizeof(StepState), hipMemcpyDeviceToHost, s));
+        LCHK(hipStreamSynchronize(s));
         if (hs.kind == STEP_FAIL) { rc = DZN_E_INVALID; goto done; }   // non-finite distances
         remaining = hs.kind == STEP_DONE ? 0 : n - 1 - hs.k;
         if (remaining == 0 && getenv("DZN_LINKAGE_DEBUG"))
@@ -614,12 +712,9 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
     }
   }
   LCHK(hipGetLastError());
-  LCHK(hipMemcpy(h_Z, Z, (size_t)(n - 1) * 4 * sizeof(double), hipMemcpyDeviceToHost));
+  LCHK(hipMemcpyAsync(h_Z, Z, (size_t)(n - 1) * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
 done:
-  (void)hipFree(D); (void)hipFree(E); (void)hipFree(lb); (void)hipFree(Z);
-  (void)hipFree(nb); (void)hipFree(size); (void)hipFree(cid); (void)hipFree(st);
-  (void)hipFree(bmin); (void)hipFree(hp_val); (void)hipFree(barg); (void)hipFree(hp_idx);
-  (void)hipFree(st2); (void)hipFree(rec2); (void)hipFree(part2); (void)hipFree(exf);
+  (void)hipStreamSynchronize(s);       // the host vectors above (ones, ids, st0) are sources of queued copies
   return rc;
 }
 
@@ -691,24 +786,34 @@ extern "C" int dzn_cdist_cosine(const float* h_emb, int32_t n, int32_t dim, cons
                                 double* h_dist, int32_t device) {
   if (!h_emb || !h_cent || !h_dist || n < 1 || dim < 1 || k < 1) return DZN_E_INVALID;
   int rc = DZN_OK;
-  float* E = nullptr;
-  double *Cn = nullptr, *ne = nullptr, *nc = nullptr, *D = nullptr;
   DeviceGuard dg(device);      // restores the caller's device on every return path
   if (!dg.ok) return DZN_E_HIP;
-  if (hipMalloc(&E, (size_t)n * dim * sizeof(float)) != hipSuccess) { rc = DZN_E_NOMEM; goto done; }
-  LCHK(hipMalloc(&Cn, (size_t)k * dim * sizeof(double)));
-  LCHK(hipMalloc(&ne, (size_t)n * sizeof(double)));
-  LCHK(hipMalloc(&nc, (size_t)k * sizeof(double)));
-  LCHK(hipMalloc(&D, (size_t)n * k * sizeof(double)));
-  LCHK(hipMemcpy(E, h_emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice));
-  LCHK(hipMemcpy(Cn, h_cent, (size_t)k * dim * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(row_norm_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, E, n, dim, ne);
-  hipLaunchKernelGGL(row_norm_f64_kernel, dim3((k + 255) / 256), dim3(256), 0, 0, Cn, k, dim, nc);
-  hipLaunchKernelGGL(cdist_cosine_kernel, dim3((unsigned)(((int64_t)n * k + 255) / 256)), dim3(256), 0, 0, E, Cn, ne, nc,
+  std::lock_guard<std::mutex> lk(g_host_mu);       // own stream + arena: see "the host stage's device context" above
+  float* E = nullptr;
+  double *Cn = nullptr, *ne = nullptr, *nc = nullptr, *D = nullptr;
+  auto carve = [&](char* base) {
+    Carver c(base);
+    E = c.take<float>((size_t)n * dim);
+    Cn = c.take<double>((size_t)k * dim);
+    ne = c.take<double>(n);
+    nc = c.take<double>(k);
+    D = c.take<double>((size_t)n * k);
+    return c.off;
+  };
+  HostCtx* ctx = nullptr;
+  rc = host_ctx(device, carve(nullptr), &ctx);
+  if (rc != DZN_OK) return rc;
+  carve(ctx->base);
+  hipStream_t s = ctx->stream;
+  LCHK(hipMemcpyAsync(E, h_emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, s));
+  LCHK(hipMemcpyAsync(Cn, h_cent, (size_t)k * dim * sizeof(double), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(row_norm_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, E, n, dim, ne);
+  hipLaunchKernelGGL(row_norm_f64_kernel, dim3((k + 255) / 256), dim3(256), 0, s, Cn, k, dim, nc);
+  hipLaunchKernelGGL(cdist_cosine_kernel, dim3((unsigned)(((int64_t)n * k + 255) / 256)), dim3(256), 0, s, E, Cn, ne, nc,
                      n, dim, k, D);
   LCHK(hipGetLastError());
-  LCHK(hipMemcpy(h_dist, D, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost));
+  LCHK(hipMemcpyAsync(h_dist, D, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, s));
 done:
-  (void)hipFree(E); (void)hipFree(Cn); (void)hipFree(ne); (void)hipFree(nc); (void)hipFree(D);
+  (void)hipStreamSynchronize(s);
   return rc;
 }

@@ -13,6 +13,7 @@
 //   * class names are interned, records are plain structs.
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -35,6 +36,7 @@ std::unordered_map<std::string, int> g_name_id;
 int g_last_event = -1;              // index of the most recent end event
 hipStream_t g_last_stream = nullptr;
 std::chrono::steady_clock::time_point g_last_time;
+std::mutex g_mu;      // (r5) the host stage may run in a second thread beside the engine (pipeline.diarize_many)
 
 int new_event() {
   hipEvent_t e = nullptr;
@@ -61,6 +63,7 @@ bool prof_enabled() { return g_on; }
 
 int prof_begin(hipStream_t st, const char* cls, double flops, double bytes) {
   if (!g_on) return -1;
+  std::lock_guard<std::mutex> lk(g_mu);
   Rec r;
   const auto now = std::chrono::steady_clock::now();
   const bool chain = g_last_event >= 0 && g_last_stream == st &&
@@ -81,6 +84,8 @@ int prof_begin(hipStream_t st, const char* cls, double flops, double bytes) {
 }
 
 void prof_end(int id, hipStream_t st) {
+  if (id < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
   if (id < 0 || id >= (int)g_recs.size()) return;
   const int b = new_event();
   if (b < 0) return;
@@ -92,6 +97,7 @@ void prof_end(int id, hipStream_t st) {
 }
 
 extern "C" int dzn_profile_enable(int32_t on) {
+  std::lock_guard<std::mutex> lk(g_mu);
   g_on = on != 0;
   g_last_event = -1;
   return DZN_OK;
@@ -99,6 +105,7 @@ extern "C" int dzn_profile_enable(int32_t on) {
 
 // pre-create events so that the timed region never calls hipEventCreate
 extern "C" int dzn_profile_reserve(int32_t n_events) {
+  std::lock_guard<std::mutex> lk(g_mu);
   while ((int)g_pool.size() < n_events) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return DZN_E_HIP;
@@ -109,6 +116,7 @@ extern "C" int dzn_profile_reserve(int32_t n_events) {
 
 extern "C" int dzn_profile_collect(dzn_prof_entry* out, int32_t cap, int32_t* n) {
   if (hipDeviceSynchronize() != hipSuccess) return DZN_E_HIP;
+  std::lock_guard<std::mutex> lk(g_mu);
   std::map<std::string, dzn_prof_entry> agg;
   for (Rec& r : g_recs) {
     float ms = 0.f;

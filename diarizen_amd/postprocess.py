@@ -113,6 +113,20 @@ def _frame_grid(C: int, L: int, chunks: SlidingWindow, frames: SlidingWindow):
     return grid, starts, int(T)
 
 
+_HOST_STREAMS = {}
+
+
+def _host_stream(device):
+    """one high-priority non-blocking stream per device for the host stage's aggregations (the C side keeps its own for the
+    linkage / cdist calls, csrc/linkage.hip)"""
+    import torch
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _HOST_STREAMS.get(key)
+    if st is None:
+        st = _HOST_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)
+    return st
+
+
 class DevicePost:
     """speaker_count / reconstruct with their overlap-add aggregations on the HIP device (dzn_speaker_count,
     dzn_cluster_activations: integer atomics over the u8 decisions).  The decisions are uploaded once (3.6 MB per
@@ -132,7 +146,10 @@ class DevicePost:
         self.C, self.L, self.S = seg.shape
         self.chunks = chunks
         self.grid, starts, self.T = _frame_grid(self.C, self.L, chunks, frames)
-        with torch.cuda.device(self.device):
+        # (r5) the host stage's own stream: it may run in a second thread while the engine executes the next recording's
+        # device stage (pipeline.diarize_many), and work queued on the default stream would wait behind the engine's
+        self.stream = _host_stream(self.device)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             self.seg = torch.from_numpy(seg).to(self.device)
             self.starts = torch.from_numpy(starts).to(self.device)
 
@@ -141,7 +158,7 @@ class DevicePost:
 
     def speaker_count(self) -> SlidingWindowFeature:
         torch = self.torch
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             work = torch.empty(2 * self.T, device=self.device, dtype=torch.int32)
             out = torch.empty(self.T, device=self.device, dtype=torch.uint8)
             st = self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -154,7 +171,7 @@ class DevicePost:
         K = int(np.max(hard_clusters)) + 1 if hard_clusters.size else 0
         if K < 1 or K > 32:
             return None                                     # caller falls back to the numpy path
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             hard = torch.from_numpy(np.ascontiguousarray(hard_clusters, dtype=np.int8)).to(self.device)
             act = torch.empty((self.T, K), device=self.device, dtype=torch.int32)
             st = self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

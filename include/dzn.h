@@ -245,6 +245,14 @@ int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, double* h_Z
 int dzn_cdist_cosine(const float* h_emb, int32_t n, int32_t dim, const double* h_cent, int32_t k, double* h_dist,
                      int32_t device);
 
+/* (r5) dzn_linkage_centroid / dzn_cdist_cosine work on their OWN non-blocking, highest-priority stream and carve their
+ * buffers from one grow-only arena per device (they are called from the pipeline's host stage, which may run in a second
+ * thread while the engine executes the next recording's device stage: no null-stream ordering behind the engine's queue, no
+ * hipFree).  The arena is re-allocated only when a call needs more than any call before it; these return it / report it.
+ * device < 0 in dzn_host_workspace_release = every device.  No reference counterpart (scipy owns its host buffers). */
+int dzn_host_workspace_release(int32_t device);
+int64_t dzn_host_workspace_bytes(int32_t device);
+
 /* Row f1, VBx: the variational-Bayes mixture of diarizen/clustering/VBx.py:27-125 (loopProb = 0 branch :99-107, the
  * one VBxClustering.__call__ runs) with its two E-sized passes per iteration on the device (csrc/vbx.hip), float64.
  * The K x D statistics pass through the host, which keeps the reference's expressions for invL / alpha / ELBO and its

@@ -53,6 +53,15 @@ __global__ void cvt_kernel(const float* x, int n, uint32_t* out) {
   out[i] = (uint32_t)w;
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// 6. v_cvt_scalef32_pk_fp8_f32: does the conversion divide or multiply by its scale operand?
+__global__ void cvt_scale_kernel(const float* x, float scale, uint32_t* out) {
+  s16x2 r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, x[0], x[1], scale, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, x[2], x[3], scale, true);
+  out[0] = __builtin_bit_cast(uint32_t, r);
+}
+
 // one wavefront: D = mfma(A, B) with per-lane operand images a[64][8], b[64][8]; d[64][16]
 __global__ void mx32_kernel(const int* a, const int* b, float* d, int sa, int sb, int mode) {
   const int l = threadIdx.x;
@@ -257,6 +266,20 @@ int main() {
     time(rate_kernel<0>, "v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 x fp8)", 4 * 2.0 * 32 * 32 * 64);
     time(rate_kernel<1>, "v_mfma_f32_32x32x16_f16", 4 * 2.0 * 32 * 32 * 16);
     time(rate_kernel<2>, "4 x f16 + 2 x scaled fp8 (algorithmic 64 k)", 4 * 2.0 * 32 * 32 * 64);
+  }
+  // ---- 6. scaled conversion ----
+  {
+    const float xs[4] = {1.0f, -3.0f, 0.5f, 20.0f};
+    float* dx; uint32_t* dout;
+    CK(hipMalloc(&dx, 16)); CK(hipMalloc(&dout, 4));
+    CK(hipMemcpy(dx, xs, 16, hipMemcpyHostToDevice));
+    for (float sc : {1.0f, 4.0f, 0.25f}) {
+      hipLaunchKernelGGL(cvt_scale_kernel, dim3(1), dim3(1), 0, 0, dx, sc, dout);
+      uint32_t w;
+      CK(hipMemcpy(&w, dout, 4, hipMemcpyDeviceToHost));
+      printf("6. v_cvt_scalef32_pk_fp8_f32(1, -3, 0.5, 20; scale %g) -> %g %g %g %g  (divides by the scale if x / scale, multiplies if x * scale)\n", sc,
+             e4m3_decode(w & 0xff), e4m3_decode((w >> 8) & 0xff), e4m3_decode((w >> 16) & 0xff), e4m3_decode(w >> 24));
+    }
   }
   printf(bad ? "PROBE: %d assumption(s) FAILED\n" : "PROBE: all assumptions hold\n", bad);
   return bad ? 1 : 0;

@@ -819,3 +819,74 @@ def test_top_count_selection_equals_the_reference_call_on_tied_activations():
         a = r.integers(0, hi + 1, (n, K)).astype(np.float32)
         c = np.minimum(r.integers(0, maxc + 1, n), K).astype(np.int64)
         assert np.array_equal(_top_count_mask(a, c), reference(a, c)), (n, K)
+
+
+def test_diarize_many_pipelines_the_host_stage_behind_the_next_device_stage():
+    """(r5) DiariZenPipeline.diarize_many without a device: with the stages stubbed, the generator keeps input order, gives the
+    host stage of recording i and the device stage of recording i+1 to different threads AT THE SAME TIME, hands every device
+    result to exactly its own host stage, writes the RTTM files, propagates a host-stage exception, and overlap=False is the
+    reference's plain loop."""
+    import threading
+    import time
+    import types
+    from diarizen_amd.pipeline import DiariZenPipeline
+
+    class Ann:
+        def __init__(self, tag):
+            self.tag = tag
+
+        def to_rttm(self):
+            return f"SPEAKER {self.tag}\n"
+
+    log, in_host = [], threading.Event()
+    overlapped = []
+
+    def make(fail_at=None):
+        p = DiariZenPipeline.__new__(DiariZenPipeline)
+        p.rttm_out_dir = None
+        p.segmentation_model = types.SimpleNamespace(sample_rate=16000)
+        p._open = lambda rec: np.zeros(16000 * rec, dtype=np.float32)
+
+        def device_stage(wave, hook=None):
+            log.append(("dev", len(wave) // 16000, threading.current_thread().name))
+            time.sleep(0.02)
+            overlapped.append(in_host.is_set())
+            time.sleep(0.03)
+            return np.full((1,), len(wave) // 16000), np.full((1,), -(len(wave) // 16000))
+
+        def host_stage(seg, emb, name, hook=None):
+            assert int(seg[0]) == -int(emb[0])
+            in_host.set()
+            log.append(("host", int(seg[0]), threading.current_thread().name))
+            time.sleep(0.04)
+            in_host.clear()
+            if fail_at == int(seg[0]):
+                raise RuntimeError("host stage failed")
+            return Ann(f"{name}:{int(seg[0])}")
+        p.device_stage, p.host_stage = device_stage, host_stage
+        return p
+
+    p = make()
+    out = list(p.diarize_many([3, 1, 2, 5], sess_names=list("abcd")))
+    assert [(n, a.tag) for n, a in out] == [("a", "a:3"), ("b", "b:1"), ("c", "c:2"), ("d", "d:5")]
+    dev_threads = {t for k, _, t in log if k == "dev"}
+    host_threads = {t for k, _, t in log if k == "host"}
+    assert len(dev_threads) == 1 and len(host_threads) == 1 and dev_threads != host_threads
+    assert any(overlapped[1:]), "no device stage ever ran beside a host stage"
+    assert [t["sess_name"] for t in p.corpus_timings] == list("abcd") and p.corpus_timings[3]["audio_s"] == 5.0
+    # plain loop
+    p2 = make()
+    p2.__class__ = type("P", (DiariZenPipeline,), {"__call__": lambda self, rec, sess_name=None, hook=None: Ann(f"{sess_name}:{rec}")})
+    assert [(n, a.tag) for n, a in p2.diarize_many([3, 1], sess_names=["x", "y"], overlap=False)] == [("x", "x:3"), ("y", "y:1")]
+    # RTTM files + error propagation
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p3 = make(fail_at=2)
+        p3.rttm_out_dir = d
+        got = []
+        with pytest.raises(RuntimeError, match="host stage failed"):
+            for n, a in p3.diarize_many([4, 2, 7], sess_names=["r0", "r1", "r2"]):
+                got.append(n)
+        assert got == ["r0"] and open(os.path.join(d, "r0.rttm")).read() == "SPEAKER r0:4\n"
+    with pytest.raises(ValueError):
+        list(make().diarize_many([1, 2], sess_names=["only-one"]))

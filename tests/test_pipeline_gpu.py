@@ -262,3 +262,61 @@ def test_host_stage_30min_device_backends_equal_reference_golden(built_lib, gpu,
     print(json.dumps(res))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(res, open(f"gpurun_out/host30_{backends}.json", "w"))
+
+
+def test_diarize_many_overlapped_equals_serial_calls(built_lib, gpu, tmp_path):
+    """(r5) the corpus loop of the reference's entry points (diarizen/pipelines/inference.py:365-368) with the
+    host stage of recording i in a worker thread beside the device stage of recording i+1: same Annotation / RTTM per recording
+    as one `__call__` after the other, in input order, for recordings of different lengths (the host stage's device arena has to
+    grow and to be reused), and the golden RTTM of the 30 s fixture.  Also: the host stage's device calls really work on their
+    own stream while the default stream is busy."""
+    import copy
+    import io
+    import wave as wave_mod
+    from diarizen_amd import _lib, ops
+    from diarizen_amd.audio import first_channel_16k
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.pipeline import DiariZenPipeline
+    from oracle.gen_golden import E2E_CONFIG
+    from testkit.weights import emb_state_dict, turn_taking_state_dict
+    cfg = get_seg_config("wavlm_large_s80_md")
+    pipe = DiariZenPipeline(None, None, config=copy.deepcopy(E2E_CONFIG), device=gpu, precision="f32h",
+                            seg_state=turn_taking_state_dict(cfg, 0), emb_state=emb_state_dict(0))
+    x = first_channel_16k(WAV)
+
+    def wav_bytes(samples):
+        buf = io.BytesIO()
+        with wave_mod.open(buf, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(np.round(np.clip(samples, -1.0, 1.0) * 32767.0).astype("<i2").tobytes())
+        return buf.getvalue()
+
+    # 30 s, 90 s (the fixture three times with a gain change), 12 s, 30 s again; the first one from its file
+    recs = [WAV, wav_bytes(np.concatenate([x, 0.7 * x[::-1], x])), wav_bytes(x[:192000]), wav_bytes(x)]
+    names = ["a", "b", "c", "d"]
+    serial = [pipe(r, sess_name=n).to_rttm() for r, n in zip(recs, names)]
+    assert serial[0] == open(os.path.join(GOLD, "e2e_EN2002a_30s.rttm")).read().replace("EN2002a", "a")
+    pipe.rttm_out_dir = str(tmp_path)
+    got = list(pipe.diarize_many(recs, sess_names=names, overlap=True))
+    assert [n for n, _ in got] == names
+    assert [a.to_rttm() for _, a in got] == serial
+    assert [(tmp_path / f"{n}.rttm").read_text() for n in names] == serial
+    assert len(pipe.corpus_timings) == 4 and all(t["host_s"] > 0 for t in pipe.corpus_timings)
+    assert [a.to_rttm() for _, a in pipe.diarize_many(recs, sess_names=names, overlap=False)] == serial
+    # the linkage / cdist entry points on their own stream: results while the default stream is kept busy equal the idle ones
+    rng = np.random.default_rng(0)
+    e = rng.standard_normal((3000, 256)).astype(np.float32)
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    z_idle = ops.linkage_centroid(e, device=0)
+    big = torch.randn(8192, 8192, device=gpu)
+    for _ in range(40):
+        big = big @ big * 1e-4                      # ~45 ms of queued default-stream work
+    z_busy = ops.linkage_centroid(e, device=0)
+    torch.cuda.synchronize()
+    assert np.array_equal(z_idle, z_busy)
+    lib = _lib.load()
+    assert lib.dzn_host_workspace_bytes(0) >= 3000 * 3000 * 8
+    pipe.close()
+    assert lib.dzn_host_workspace_bytes(0) == 0
