@@ -128,10 +128,24 @@ class PowerSampler:
     (profiles/r4_power_cap.txt, DESIGN.md 4.5) — this puts that evidence into the line the driver records.  Never raises;
     `result()` is None when rocm-smi is missing or answers nothing."""
 
-    def __init__(self, period_s: float = 1.0, max_samples: int = 6):   # A/B on one box: 10 polls in a 4-step region cost 0.35 %
+    def __init__(self, period_s: float = 1.0, max_samples: int = 6, device=None):   # A/B on one box: 10 polls in a 4-step region cost 0.35 %
         import threading
         self.period, self.max = period_s, max_samples
         self.samples, self.cap = [], None
+        # (r5, ADVICE r4) which rocm-smi card is the torch device: matched by PCI bus id; unmatched (or HIP_VISIBLE_DEVICES hiding
+        # the mapping) = the first card, and the result says so
+        self.card, self.card_matched = None, False
+        try:
+            import subprocess
+            props = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device())
+            want = f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{getattr(props, 'pci_device_id', 0):02x}".lower()
+            out = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showbus", "--csv"], capture_output=True, text=True, timeout=15).stdout
+            for ln in out.splitlines():
+                f = [c.strip() for c in ln.split(",")]
+                if len(f) >= 2 and f[0].startswith("card") and f[1].lower().startswith(want):
+                    self.card, self.card_matched = f[0], True
+        except Exception:      # noqa: BLE001
+            pass
         self._stop = threading.Event()
         self._th = threading.Thread(target=self._run, daemon=True)
 
@@ -142,7 +156,8 @@ class PowerSampler:
                                  capture_output=True, text=True, timeout=15).stdout
             rows = [ln.split(",") for ln in out.splitlines() if ln.strip()]
             hdr = next(r for r in rows if r[0] == "device")
-            row = next(r for r in rows if r[0].startswith("card"))     # card0: the one device this process runs on
+            row = next(r for r in rows if (r[0] == self.card if self.card else r[0].startswith("card")))
+            self.card = self.card or row[0]
             col = {h.strip(): v for h, v in zip(hdr, row)}
             watts = float(next(v for h, v in col.items() if h.startswith("Current Socket Graphics Package Power")))
             sclk = next((v for h, v in col.items() if h.startswith("sclk clock speed")), "")
@@ -173,7 +188,7 @@ class PowerSampler:
         f = [s[1] for s in self.samples if s[1] > 0]
         return {"package_w": {"mean": round(sum(w) / len(w), 1), "max": round(max(w), 1)}, "cap_w": self.cap,
                 "sclk_mhz": {"mean": round(sum(f) / len(f)) if f else None, "min": min(f) if f else None},
-                "samples": len(w),
+                "samples": len(w), "card": self.card, "card_matched_by_pci_bus_id": self.card_matched,
                 "source": "rocm-smi polled from a thread while the timed steps ran (whole pipeline: every kernel, not only the "
                           "contraction; back to back the contraction alone holds 1400 W of 1400 W at 1.84-1.92 GHz, "
                           "profiles/r4_power_cap.txt)"}
@@ -848,7 +863,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    power = PowerSampler() if rank == 0 and not args.no_power else None
+    power = PowerSampler(device=dev) if rank == 0 and not args.no_power else None
     if power:
         power.start()
     acc["on"] = True

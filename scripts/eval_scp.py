@@ -45,6 +45,7 @@ def main(argv=None):
     ap.add_argument("--diarizen-hub", default=None, help="hub directory (config.toml, pytorch_model.bin, plda/)")
     ap.add_argument("--embedding-model", default=None)
     ap.add_argument("--precision", default="f32h", choices=["f32h", "f32s", "f32", "f16", "bf16"])
+    ap.add_argument("--serial", action="store_true", help="one recording after the other (no host-stage overlap across recordings)")
     ap.add_argument("--synthetic-weights", action="store_true",
                     help="seeded turn-taking weights + the e2e fixture's configuration (no checkpoints offline)")
     ap.add_argument("--seg_duration", type=float, default=None)
@@ -78,21 +79,28 @@ def main(argv=None):
     # ranks share only the output directory: a done-file per rank, named after THIS job (launcher run id + rendezvous port) so
     # that the leftovers of an aborted earlier run are not mistaken for this run's, removed before any work starts, and
     # written atomically (temp file + os.replace) so that rank 0 never reads half a file
-    job = f"{os.environ.get('TORCHELASTIC_RUN_ID', 'solo')}_{os.environ.get('MASTER_PORT', '0')}"
+    # (r5) without a launcher the key carries the pid — two solo jobs sharing an output directory no longer take each
+    # other's files — and only THIS job's leftovers are removed
+    if "TORCHELASTIC_RUN_ID" in os.environ:
+        job = f"{os.environ['TORCHELASTIC_RUN_ID']}_{os.environ.get('MASTER_PORT', '0')}"
+    else:
+        job = f"solo{os.getpid()}_{os.environ.get('MASTER_PORT', '0')}"
 
     def done_file(r):
         return Path(args.out_dir) / f".done_{job}_rank{r}.json"
-    for stale in Path(args.out_dir).glob(f".done_*_rank{rank}.json"):
-        stale.unlink(missing_ok=True)
+    done_file(rank).unlink(missing_ok=True)
     scp = load_scp(args.in_wav_scp)
     mine = list(scp.items())[rank::world]
-    audio_s = wall = 0.0
-    for rec, wav in mine:
-        t0 = time.perf_counter()
-        pipe(wav, sess_name=rec)
-        wall += time.perf_counter() - t0
-        audio_s += pipe.timings["audio_s"]
-        print(f"[rank {rank}] {rec}: {pipe.timings['audio_s']:.1f} s of audio in {time.perf_counter() - t0:.2f} s", flush=True)
+    audio_s = 0.0
+    # the corpus loop of the reference's entry point (diarizen/pipelines/inference.py:365-368), host stage of recording i beside
+    # the decode + device stage of recording i+1 (DiariZenPipeline.diarize_many); --serial = one `pipe(wav)` after the other
+    t_all = time.perf_counter()
+    for k, (rec, _) in enumerate(pipe.diarize_many([w for _, w in mine], sess_names=[r for r, _ in mine], overlap=not args.serial)):
+        t = pipe.corpus_timings[k] if not args.serial else pipe.timings
+        audio_s += t["audio_s"]
+        print(f"[rank {rank}] {rec}: {t['audio_s']:.1f} s of audio: load {t['load_s']:.2f} s, device {t['device_s']:.2f} s, "
+              f"host {t['host_s']:.2f} s", flush=True)
+    wall = time.perf_counter() - t_all
     tmp = done_file(rank).with_suffix(".tmp")
     tmp.write_text(json.dumps({"files": [r for r, _ in mine], "audio_s": audio_s, "wall_s": wall}))
     os.replace(tmp, done_file(rank))
