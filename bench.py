@@ -39,6 +39,7 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP call: see diarizen_amd/__init__.py (stream -> hardware-queue mapping)
 import torch  # noqa: E402
 
 # MI355X dense MFMA peaks (MI355X_MICROARCH.md).  "f32s" contractions run fp32 arithmetic as 6 bf16 MFMA
@@ -437,8 +438,7 @@ def e2e_leg(args, dev, wave_host, sd, esd):
         torch.cuda.synchronize()
         corpus["overlapped" if overlap else "serial"] = round(audio_s * n_done / (time.perf_counter() - t0), 1)
     pipe.close()      # (r5) both engine handles now: the pipeline object sits in a reference cycle (runner -> engine factory -> pipeline)
-                      # and its 160 GB stayed allocated until the cycle collector ran — the configs[1] leg behind it then ran against
-                      # a nearly full HBM (3.7 k instead of 4.5 k audio-s/s in the first r5 runs; `--only-config1` read 4560)
+                      # and would keep its ~180 GB until the cycle collector runs
     return {"audio_seconds_per_s": round(audio_s / (dev_s + host_s), 1), "steps": K, "s_per_step": per,
             "device_s": round(dev_s, 4), "host_s": round(host_s, 4), "upload_included": True,
             "speakers": len(ann.labels()), "rttm_lines": len(ann.to_rttm().splitlines()),
