@@ -74,21 +74,8 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 // RPF (r5): the residual of the whole wavefront tile is requested before the first operand tile (gemm_prefetch_residual): the
 // short-K launches' epilogue is then stores only.
 template <int BM, int BN, int WGM, int WGN, int S, int NP, int OCC = 1, int ABL = 0, bool RPF = false>
-__global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const dzn_gemm_desc d, const int ngroups_stagger) {
+__global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_split_kernel(const dzn_gemm_desc d, const int ngroups) {
   constexpr int NW = WGM * WGN;           // wavefronts per workgroup
-  const int ngroups = ngroups_stagger & 0xff;
-  // (r5 probe, DZN_GEMM_STAGGER="us[,mode]") the workgroups of the FIRST round start 0, 1, .. WPC-1 phase delays apart, so that the
-  // workgroups sharing a CU sit in different phases of their tile (K loop: LDS-DMA + MFMA; epilogue: HBM) instead of marching
-  // through them together.  mode 0: phase = (bid / 256) % WPC (breadth-first placement), 1: (bid / 8) % WPC, 2: a hash of bid
-  if (const int stagger = ngroups_stagger >> 8) {
-    constexpr int WPC = OCC * 4 / NW > 1 ? OCC * 4 / NW : 1;      // workgroups per CU the launch bounds allow
-    const int us = stagger & 0xff, mode = stagger >> 8;
-    const unsigned bid = blockIdx.x + blockIdx.y * gridDim.x;
-    if (bid < 256u * WPC) {
-      const int phase = mode == 0 ? (bid / 256) % WPC : mode == 1 ? (bid / 8) % WPC : ((bid * 2654435761u) >> 16) % WPC;
-      for (int i = 0; i < phase * us; ++i) __builtin_amdgcn_s_sleep(32);       // 2048 clocks, about 1 us
-    }
-  }
   constexpr int BK = 32;
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int MI = TM / 16, NI = TN / 16, MH = MI / 2;
@@ -741,16 +728,7 @@ int launch_split_cfg(const dzn_gemm_desc& d, hipStream_t s) {
     const double fl = d.alg_flops > 0 ? d.alg_flops * d.nz : 2.0 * d.M * d.N * d.K * d.nz;
     pid = prof_begin(s, cls, fl, gemm_alg_bytes(d, NP * 2));
   }
-  // DZN_GEMM_STAGGER (read once; probe): "us" or "us,mode" — applied to the narrow tiles only (the short-K class)
-  static const int stagger = [] {
-    const char* e = getenv("DZN_GEMM_STAGGER");
-    if (!e) return 0;
-    int us = 0, mode = 0;
-    sscanf(e, "%d,%d", &us, &mode);
-    return us > 0 ? ((us & 0xff) | ((mode & 3) << 8)) : 0;
-  }();
-  const int st = BN <= 64 ? stagger : 0;
-  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, d, choose_column_groups(d, tilesM, tilesN, BM, NP) | (st << 8));
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, d, choose_column_groups(d, tilesM, tilesN, BM, NP));
   prof_end(pid, s);
   if (hipGetLastError() != hipSuccess) return DZN_E_HIP;
   if (d.stat_partial && d.stat_final)
@@ -800,10 +778,8 @@ int launch_gemm_split_np(const dzn_gemm_desc& d, hipStream_t s) {
     if (!strcmp(force, "128x64")) return launch_split_cfg<128, 64, 4, 1, 2, NP, NP <= 2 ? 3 : 2>(d, s);
     if (!strcmp(force, "128x80")) return launch_split_cfg<128, 80, 4, 1, 2, NP, 2>(d, s);
     if (!strcmp(force, "128x32")) return launch_split_cfg<128, 32, 4, 1, 2, NP>(d, s);
-    if constexpr (NP == 2) {     // (r5 probe) more, smaller workgroups per CU for the short-K class whose time is its epilogue
-      if (!strcmp(force, "64x64w2")) return launch_split_cfg<64, 64, 2, 1, 2, NP, 3>(d, s);      // 2 wavefronts, 32 KB LDS: 5 workgroups = 10 wavefronts per CU
-      if (!strcmp(force, "128x32o4")) return launch_split_cfg<128, 32, 4, 1, 2, NP, 4>(d, s);    // 40 KB LDS: 4 per CU
-    }
+    // (r5 probes, measured negative and removed: 64x64 tiles of 2 wavefronts, 128x32 at 4 workgroups per CU, a first-round stagger of
+    //  the narrow tile — profiles/r5_short_k_probes.txt, code at commit 2a14565)
     if constexpr (NP == 3) {
       if (!strcmp(force, "128x128")) return launch_split_cfg<128, 128, 2, 2, 2, NP, 2>(d, s);
     } else {
