@@ -16,7 +16,10 @@ for every batch of windows  segmentation (WavLM + Conformer + powerset) -> media
 ResNet34 embeddings (trunk shared by the 4 local speakers), all through the C ABI of libdzn_hip.so; u8 decisions + f32
 embeddings copied to the host (and all-gathered over RCCL at N > 1); then the HOST stage — speaker counting, centroid-linkage
 AHC, constrained assignment, reconstruction, Binarize, RTTM text (diarizen/pipelines/inference.py:137-185) — through the
-product's run_host_stage.  `value` = audio of all ranks / max-over-ranks time of the K steps; `device_value` = the device hot
+product's run_host_stage.  Consecutive steps are a two-stage software pipeline, as DiariZenPipeline.diarize_many runs a corpus: the
+host stage of step i executes in a worker thread (own HIP stream / arena) beside the device stage of step i+1, and every step's host
+stage completes inside the timed region (`--no-overlap`, `serial_value`: the serial steps).  `value` = audio of all ranks /
+max-over-ranks time of the K steps; `device_value` = the device hot
 path of the same steps alone (what r1-r4 called `value`); `e2e` = the same pipeline through the DiariZenPipeline object incl.
 the host -> HBM upload of the recording.
 
@@ -1014,7 +1017,7 @@ def main():
                                     f"assignment + reconstruction + Binarize + RTTM)" if full else f"{args.model} segmentation only") +
                                    f", {args.minutes:g} min synthetic 16 kHz mono {'sharded over the ranks' if strong else 'per GPU'}, "
                                    f"recording resident in HBM, window {args.window:g} s, step {0.1 * args.window:g} s, "
-                                   f"{n_windows} windows, batch {args.batch}; `device_value` = the device hot path alone "
+                                   f"{n_windows} windows, batch {args.batch}; host stage of step i {'pipelined beside the device stage of step i+1' if pool is not None else 'serially behind its device stage'}; `device_value` = the device hot path alone "
                                    f"(r1-r4's `value`), `e2e` = the same through DiariZenPipeline incl. the host -> HBM upload",
                        "cpu_baseline_kind": None,
                        "windows_per_step": n_windows, "batch": args.batch, "launches": batches_note(n_windows, args.batch),
