@@ -181,6 +181,7 @@ def load() -> C.CDLL:
     sig("dzn_op_resblock_ws", i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, i32, vp])
     sig("dzn_op_resblock32_fused", i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp])
     sig("dzn_op_set_resblock_np", i32, [i32])
+    sig("dzn_op_set_attention_noskip", i32, [i32])
     sig("dzn_op_conv3x3_c32_h2", i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp])
     sig("dzn_op_layernorm", i32, [vp, i64, vp, i64, vp, vp, i64, i32, i32, f32, i32, vp])
     sig("dzn_op_gate", i32, [vp, i64, vp, vp, vp, vp, i64, i32, vp])
@@ -198,7 +199,7 @@ EXPORTED = [
     "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid", "dzn_cdist_cosine", "dzn_host_workspace_release",
     "dzn_host_workspace_bytes",
     "dzn_flac_info", "dzn_flac_decode", "dzn_vbx_create", "dzn_vbx_stats", "dzn_vbx_estep", "dzn_vbx_gamma", "dzn_vbx_destroy",
-    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_split_weights_mx", "dzn_op_set_gemm_mx_cfg", "dzn_checked_status", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_resblock32_fused", "dzn_op_resblock_ws", "dzn_op_set_resblock_np", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",
+    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_split_weights_mx", "dzn_op_set_gemm_mx_cfg", "dzn_checked_status", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_resblock32_fused", "dzn_op_resblock_ws", "dzn_op_set_resblock_np", "dzn_op_set_attention_noskip", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",
     "dzn_profile_enable", "dzn_profile_collect", "dzn_profile_reserve", "dzn_op_relpos_bucket",
 ]
 

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
                                                          const float* __restrict__ table,
                                                          const int32_t* __restrict__ head_idx, int B, int L,
                                                          int h, int Htot, int ldqkv, int ldo, float scale,
-                                                         const float* __restrict__ amax) {
+                                                         const float* __restrict__ amax, const int noskip) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;                     // NP planes [64 keys][64 d]
   unsigned char* sV = smem + NP * ATT_PLANE;    // NP planes [64 d][64 keys in MFMA order]
@@ -138,6 +138,15 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
   // measured: 132 / 134 TFLOP/s against 138 for this form in the same run (profiles/r4_attention_qw_probe.txt; the
   // templated kernel is in the history at 2ee-series commit "attention: query blocks per workgroup templated"), step
   // unchanged.  The re-reads are L2 / MALL hits and the split is not what the loop waits for; the kernel stays as it was.
+  // (r5) L = 399 = 6 x 64 + 15: the seventh query tile has 15 queries and its wavefronts 1-3 own none.  They still stage and take the
+  // barriers but skip scores, softmax and P.V (rows that are never stored): same stored bits (`noskip` = the r2-r4 kernel, for the
+  // test), 6 registers fewer, 10.7 % of the kernel's matrix work gone — and the SAME time (62.3 ms per step either way,
+  // profiles/r5_attention_skip.txt): the tile loop is bound by the latency of its global fetch -> split -> LDS chain, not by the
+  // matrix / softmax work.  Skipping the three fully masked key blocks of the last key tile as well needs a second copy of the tile
+  // body (compile-time block count: run-time guards spill 61 registers); that form spills 10 and measured 3 % slower — removed.
+  // Also probed and removed: requesting the NEXT tile's K / V rows in the middle of the tile (after the scores, when the K
+  // fragments are dead) so that the fetch overlaps softmax + P.V — 14-16 spilled registers, 16 % slower (r5_attention_skip.txt).
+  const bool wave_on = noskip || __builtin_amdgcn_readfirstlane(qt * 64 + wave * 16) < L;
   for (int kt = 0; kt < nkt; ++kt) {
     fetch(kt);
     __syncthreads();  // previous tile fully consumed
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
       }
     }
     __syncthreads();
-
+    if (!wave_on) continue;
     // ---- S^T = K Q^T : 4 key blocks x 2 halves of d, six products each ----
     f32x4 s[4];
 #pragma unroll
@@ -278,12 +287,20 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_split_kernel(const float* _
   }
 }
 
+int g_att_noskip = getenv("DZN_ATT_NOSKIP") != nullptr;     // environment: A/B of whole runs; dzn_op_set_attention_noskip: tests
 }  // namespace
+
+// test switch: 1 = the query-less wavefronts of a partial last query tile compute as r2-r4 did (same stored bits)
+extern "C" int dzn_op_set_attention_noskip(int32_t on) {
+  g_att_noskip = on != 0;
+  return DZN_OK;
+}
 
 int launch_attention_split(const float* qkv, float* out, const float* gate, const float* table,
                            const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
                            float scale, hipStream_t s, const float* amax) {
   if (h <= 0 || B <= 0 || L <= 0) return DZN_OK;
+  const int noskip = g_att_noskip;
   if ((ldqkv & 3) || (reinterpret_cast<uintptr_t>(qkv) & 15)) return DZN_E_INVALID;
   const bool bias = gate && table && head_idx;
   const int np = amax ? 2 : 3;
@@ -301,7 +318,7 @@ int launch_attention_split(const float* qkv, float* out, const float* gate, cons
                              (double)B * L * h * 64.0 * 4.0 * 4.0 + (gate ? (double)B * L * Htot * 4.0 : 0.0));   // q, k, v in + out, once
 #define DZN_ATT(BV, NPV)                                                                                            \
   hipLaunchKernelGGL((attn_split_kernel<BV, NPV>), grid, dim3(256), lds, s, qkv, out, gate, table, head_idx, B, L, h, \
-                     Htot, ldqkv, ldo, scale, amax)
+                     Htot, ldqkv, ldo, scale, amax, noskip)
   if (bias && amax) DZN_ATT(true, 2);
   else if (bias) DZN_ATT(true, 3);
   else if (amax) DZN_ATT(false, 2);

@@ -140,6 +140,9 @@ int dzn_op_resblock_ws(const float* in, float* out, const void* W1, const float*
 /* test knob: terms per operand the two entry points above run with — 2 (default, DZN_PREC_F32_H2) or 1 (the DZN_PREC_F16 form:
  * leading fp16 term only, plane 0 of the same weight buffers) */
 int dzn_op_set_resblock_np(int32_t np);
+/* (r5) test switch of the attention kernels (csrc/attention_split.hip): 1 = the wavefronts of a partial last query tile that own no
+ * query compute scores / softmax / P.V as r2-r4 did; the stored bits are the same. */
+int dzn_op_set_attention_noskip(int32_t on);
 
 int dzn_op_gemm(const dzn_gemm_desc* d, void* stream);
 

@@ -329,6 +329,34 @@ def test_attention_gated_relpos(built_lib, gpu, L, prec):
     assert (out.cpu().double() - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("prec", F32_MODES)
+@pytest.mark.parametrize("L", [15, 64, 99, 399])
+def test_attention_query_less_wavefronts_skip_with_the_same_bits(built_lib, gpu, L, prec):
+    """(r5) L = 399 = 6 x 64 + 15: wavefronts of the last query tile that own no query skip scores / softmax / P.V
+    (csrc/attention_split.hip).  Stored bits equal the kernel that computes them (dzn_op_set_attention_noskip), with and without
+    the gated relative-position bias, for lengths with a partial last tile of every shape (15, 99, 399) and without one (64)."""
+    from diarizen_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7 * L + 1)
+    B, Htot = 3, 16
+    heads = [0, 3, 7, 12, 15]
+    h = len(heads)
+    qkv = (torch.randn(B * L, 3 * h * 64, generator=g) * 1.7).to(gpu)
+    gate = (torch.rand(B * L, Htot, generator=g) * 2).to(gpu)
+    table = torch.randn(Htot, 2 * L - 1, generator=g).to(gpu)
+    hidx = torch.tensor(heads, dtype=torch.int32, device=gpu)
+    for kw in ({}, dict(gate=gate, table=table, head_idx=hidx, Htot=Htot)):
+        try:
+            lib.dzn_op_set_attention_noskip(1)
+            full = ops.attention(qkv, B, L, h, precision=prec, **kw).clone()
+        finally:
+            lib.dzn_op_set_attention_noskip(0)
+        skip = ops.attention(qkv, B, L, h, precision=prec, **kw)
+        torch.cuda.synchronize()
+        assert torch.isfinite(skip).all()
+        assert torch.equal(full, skip)
+
+
 def test_gate(built_lib, gpu):
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(11)
