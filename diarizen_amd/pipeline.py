@@ -283,9 +283,9 @@ class DiariZenPipeline:
         """The loop the reference's entry points run over a corpus (diarizen/pipelines/inference.py:365-368: `for audio_file in
         audio_f: diarizen_pipeline(audio_file, sess_name=...)`; recipes/diar_ssl/infer_avg.py:334-338), as a generator of
         (sess_name, Annotation) in input order, with the SAME result per recording as `__call__`.
-        overlap=True (r5): a two-stage software pipeline over the recordings — the host stage of recording i (counting, AHC /
-        VBx, assignment, reconstruction, RTTM) runs in a worker thread while this thread decodes recording i+1 and runs its
-        device stage.  The host stage's device work has its own high-priority stream and workspace (csrc/linkage.hip,
+        overlap=True (r5): a software pipeline over the recordings — recording i+1 is decoded by a loader thread and the host
+        stage of recording i-1 (counting, AHC / VBx, assignment, reconstruction, RTTM) runs in a worker thread while this thread
+        uploads recording i and runs its device stage (at most two decoded recordings are alive at a time).  The host stage's device work has its own high-priority stream and workspace (csrc/linkage.hip,
         postprocess.DevicePost), so neither side queues behind the other; on the 30-min workload the host stage is 70 ms
         against 1.04 s of device stage, i.e. the corpus rate becomes the device rate.  At most one finished device stage
         waits for the worker (its seg / emb arrays: a few MB per hour of audio).  With torch.distributed initialised every
@@ -314,24 +314,33 @@ class DiariZenPipeline:
                     f.write(res.to_rttm())
             return res, time.perf_counter() - t
 
+        def load(rec):
+            t = time.perf_counter()
+            w = self._open(rec)
+            return w, time.perf_counter() - t
+
         self.corpus_timings = []
         pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dzn-host-stage")
+        loader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dzn-decode")      # recording i+1 is decoded beside device stage i
         pending = None                                   # (future, name, load_s, device_s, audio_s)
         try:
-            for rec, name in zip(recordings, sess_names):
-                t0 = time.perf_counter()
-                waveform = self._open(rec)
+            nxt = loader.submit(load, recordings[0]) if recordings else None
+            for i, name in enumerate(sess_names):
+                waveform, load_s = nxt.result()
+                nxt = loader.submit(load, recordings[i + 1]) if i + 1 < len(recordings) else None
                 n = int(waveform.num_samples) if hasattr(waveform, "num_samples") else len(waveform)
                 t1 = time.perf_counter()
                 seg, emb = self.device_stage(waveform)
                 t2 = time.perf_counter()
+                del waveform
                 if pending is not None:                  # recording i-1's host stage ran beside this device stage
                     yield self._collect(pending)
                 fut = pool.submit(host, seg, emb, name) if rank0 else None
-                pending = (fut, name, t1 - t0, t2 - t1, n / self.segmentation_model.sample_rate)
+                pending = (fut, name, load_s, t2 - t1, n / self.segmentation_model.sample_rate)
             if pending is not None:
                 yield self._collect(pending)
         finally:
+            loader.shutdown(wait=True, cancel_futures=True)
             pool.shutdown(wait=True)
 
     def _collect(self, pending):

@@ -845,7 +845,10 @@ def test_diarize_many_pipelines_the_host_stage_behind_the_next_device_stage():
         p = DiariZenPipeline.__new__(DiariZenPipeline)
         p.rttm_out_dir = None
         p.segmentation_model = types.SimpleNamespace(sample_rate=16000)
-        p._open = lambda rec: np.zeros(16000 * rec, dtype=np.float32)
+        def _open(rec):
+            log.append(("open", rec, threading.current_thread().name))
+            return np.zeros(16000 * rec, dtype=np.float32)
+        p._open = _open
 
         def device_stage(wave, hook=None):
             log.append(("dev", len(wave) // 16000, threading.current_thread().name))
@@ -873,6 +876,11 @@ def test_diarize_many_pipelines_the_host_stage_behind_the_next_device_stage():
     host_threads = {t for k, _, t in log if k == "host"}
     assert len(dev_threads) == 1 and len(host_threads) == 1 and dev_threads != host_threads
     assert any(overlapped[1:]), "no device stage ever ran beside a host stage"
+    # recording i+1 is decoded by the loader thread, and its decode is requested before device stage i ends
+    opens = [(j, e) for j, e in enumerate(log) if e[0] == "open"]
+    assert [e[1] for _, e in opens] == [3, 1, 2, 5] and all(e[2].startswith("dzn-decode") for _, e in opens)
+    first_host = min(j for j, e in enumerate(log) if e[0] == "host")
+    assert opens[1][0] < first_host, "the second recording was not opened while the first was on the device"
     assert [t["sess_name"] for t in p.corpus_timings] == list("abcd") and p.corpus_timings[3]["audio_s"] == 5.0
     # plain loop
     p2 = make()
