@@ -101,6 +101,20 @@ ALT_STEPS = 5          # timed steps of every comparison leg (other fp32 modes, 
 REDUCED_PARITY_FILE = ROOT / "profiles" / "r5_reduced_mode_parity.json"
 
 
+def other_roof(p, prec):
+    """the OTHER roof of a matrix kernel class with declared algorithmic bytes: its rate against HBM, and which of the two roofs its
+    algorithmic intensity puts lower (`binding_roof`).  The reduced contraction (half the matrix passes of plain fp16, same bytes as
+    f32h) sits just on the HBM side of its ridge: 141 FLOP/B against 1250 / 8 = 156."""
+    if p["bytes"] <= 0 or p["ms"] <= 0:
+        return {}
+    gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+    intensity = p["flops"] / p["bytes"]
+    ridge = PEAK_TFLOPS[prec] * 1e12 / (PEAK_HBM_GBS * 1e9)
+    return {"alg_intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+            "binding_roof": "mfma" if intensity >= ridge else "hbm",
+            "alg_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4)}
+
+
 def reduced_parity():
     try:
         rec = json.loads(REDUCED_PARITY_FILE.read_text())
@@ -949,6 +963,7 @@ def main():
                 roofline = {"kernel": top["name"], "bound": "mfma", "achieved": round(ach, 2),
                             "peak": round(PEAK_TFLOPS[prec], 1), "unit": "TFLOP/s",
                             "frac": round(ach / PEAK_TFLOPS[prec], 4),
+                            **other_roof(top, prec),
                             "traffic": pmc_lookup(traffic, top["name"], "hbm_bytes_per_launch"),
                             "traffic_source": f"{TRAFFIC_SOURCE} [{traffic.get('_file')}]" if traffic else None,
                             "launches": top["launches"],
@@ -1066,6 +1081,7 @@ def main():
                     ach16 = top16["flops"] / (top16["ms"] * 1e-3) / 1e12
                     red["roofline"] = {"kernel": top16["name"], "bound": "mfma", "achieved": round(ach16, 2),
                                        "peak": PEAK_TFLOPS["mx"], "unit": "TFLOP/s", "frac": round(ach16 / PEAK_TFLOPS["mx"], 4),
+                                       **other_roof(top16, "mx"),
                                        "share_of_profiled": round(top16["ms"] / tot16, 4), "launches": top16["launches"],
                                        "alg_bytes_per_launch": int(top16["bytes"] / top16["launches"]) if top16["bytes"] > 0 else None,
                                        "pmc_mfma_util_pct": pmc_lookup(pmc_table(args, "f16"), top16["name"], "mfma_util_pct"),
