@@ -861,7 +861,7 @@ def test_diarize_many_pipelines_the_host_stage_behind_the_next_device_stage():
             assert int(seg[0]) == -int(emb[0])
             in_host.set()
             log.append(("host", int(seg[0]), threading.current_thread().name))
-            time.sleep(0.04)
+            time.sleep(0.08)
             in_host.clear()
             if fail_at == int(seg[0]):
                 raise RuntimeError("host stage failed")
