@@ -127,6 +127,12 @@ int launch_pad_rows_split2(const float* x, void* planes, int64_t plane_stride, i
                            const float* amax, float* snapshot, hipStream_t st, int cg = 0, int cgp = 0);
 int launch_split_weights(const float* W, int64_t rows, int K, int64_t ldw, void* W3, hipStream_t s);
 int launch_split_weights_h2(const float* W, int64_t rows, int K, int64_t ldw, void* W2, float* col_scale, hipStream_t s);
+// linkage.hip (r5): the host stage's device context — one non-blocking highest-priority stream per device, and a second grow-only
+// arena for an opaque STATE that lives across several calls (vbx.hip): leased to one state at a time.  host_state_lease returns
+// DZN_OK with *base == nullptr when the arena is already leased (the caller then owns a plain allocation); device < 0 = current.
+int host_stage_stream(int device, hipStream_t* stream);
+int host_state_lease(int device, size_t bytes, hipStream_t* stream, char** base);
+void host_state_release(int device);
 int launch_gemm_mx(const dzn_gemm_desc& d, hipStream_t s);   // gemm_mx.hip: fp16 hi*hi + fp8 cross terms (DZN_PREC_F16)
 int launch_split_weights_mx(const float* W, int64_t rows, int K, int64_t ldw, void* Wmx, float* col_scale, hipStream_t s);
 int launch_amax(const float* x, int64_t n, float* amax, hipStream_t s);

@@ -549,6 +549,9 @@ struct HostCtx {
   hipStream_t stream = nullptr;
   char* base = nullptr;
   size_t cap = 0;
+  char* sbase = nullptr;      // second arena: a STATE that lives across calls (vbx.hip), leased to one state at a time
+  size_t scap = 0;
+  bool sleased = false;
 };
 constexpr int MAX_DEV = 64;
 std::mutex g_host_mu;
@@ -567,6 +570,10 @@ int host_ctx(int device, size_t bytes, HostCtx** out) {
       c.stream = nullptr;
       return DZN_E_HIP;
     }
+  }
+  if (bytes == 0) {      // stream only
+    *out = &c;
+    return DZN_OK;
   }
   if (bytes > c.cap) {
     if (c.base) {
@@ -602,25 +609,72 @@ struct Carver {
 
 }  // namespace
 
+int host_stage_stream(int device, hipStream_t* stream) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  HostCtx* c = nullptr;
+  const int rc = host_ctx(device, 0, &c);
+  if (rc == DZN_OK) *stream = c->stream;
+  return rc;
+}
+
+int host_state_lease(int device, size_t bytes, hipStream_t* stream, char** base) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  HostCtx* c = nullptr;
+  const int rc = host_ctx(device, 0, &c);
+  if (rc != DZN_OK) return rc;
+  *stream = c->stream;
+  *base = nullptr;
+  if (c->sleased) return DZN_OK;                 // a second live state: the caller allocates for itself
+  if (bytes > c->scap) {
+    if (c->sbase) {
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(c->sbase);
+      c->sbase = nullptr;
+      c->scap = 0;
+    }
+    if (hipMalloc(&c->sbase, bytes + bytes / 8) == hipSuccess) c->scap = bytes + bytes / 8;
+    else {
+      (void)hipGetLastError();
+      if (hipMalloc(&c->sbase, bytes) != hipSuccess) { (void)hipGetLastError(); c->sbase = nullptr; return DZN_E_NOMEM; }
+      c->scap = bytes;
+    }
+  }
+  c->sleased = true;
+  *base = c->sbase;
+  return DZN_OK;
+}
+
+void host_state_release(int device) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  int dev = device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return;
+  if (dev >= 0 && dev < MAX_DEV) g_host[dev].sleased = false;
+}
+
 extern "C" int dzn_host_workspace_release(int32_t device) {
   std::lock_guard<std::mutex> lk(g_host_mu);
   for (int dev = 0; dev < MAX_DEV; ++dev) {
     if (device >= 0 && dev != device) continue;
     HostCtx& c = g_host[dev];
-    if (!c.base && !c.stream) continue;
+    if (!c.base && !c.sbase && !c.stream) continue;
     DeviceGuard dg(dev);
     if (!dg.ok) return DZN_E_HIP;
     if (c.stream) (void)hipStreamSynchronize(c.stream);
     if (c.base) (void)hipFree(c.base);
     c.base = nullptr;
     c.cap = 0;
+    if (c.sbase && !c.sleased) {      // a live state keeps its arena
+      (void)hipFree(c.sbase);
+      c.sbase = nullptr;
+      c.scap = 0;
+    }
   }
   return DZN_OK;
 }
 
 extern "C" int64_t dzn_host_workspace_bytes(int32_t device) {
   std::lock_guard<std::mutex> lk(g_host_mu);
-  return device >= 0 && device < MAX_DEV ? (int64_t)g_host[device].cap : 0;
+  return device >= 0 && device < MAX_DEV ? (int64_t)(g_host[device].cap + g_host[device].scap) : 0;
 }
 
 extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, double* h_Z, int32_t device) {

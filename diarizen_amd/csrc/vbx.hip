@@ -123,14 +123,27 @@ struct VbState {
   int E = 0, D = 0, K = 0, nchunk = 0, device = -1;
   double *rho = nullptr, *G = nullptr, *gamma = nullptr, *partial = nullptr, *stats = nullptr, *alpha = nullptr,
          *ck = nullptr, *lpi = nullptr, *lpx = nullptr, *lpx_part = nullptr;
+  // (r5) every array above is carved from ONE block: the host stage's state arena (linkage.hip: no hipMalloc / hipFree per
+  // recording, and hipFree is a device-wide synchronisation that a host stage running beside the engine must not take), or, when
+  // another state holds the arena, a block of its own.  All work runs on the host stage's stream.
+  hipStream_t stream = nullptr;
+  char* own_block = nullptr;
+  bool leased = false;
 };
 
 void vb_free(VbState* s) {
   if (!s) return;
-  (void)hipFree(s->rho); (void)hipFree(s->G); (void)hipFree(s->gamma); (void)hipFree(s->partial);
-  (void)hipFree(s->stats); (void)hipFree(s->alpha); (void)hipFree(s->ck); (void)hipFree(s->lpi); (void)hipFree(s->lpx);
-  (void)hipFree(s->lpx_part);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->leased) host_state_release(s->device);
+  if (s->own_block) (void)hipFree(s->own_block);
   delete s;
+}
+
+template <typename T>
+T* vb_take(char* base, size_t& off, size_t count) {
+  T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+  off += (count * sizeof(T) + 255) & ~(size_t)255;
+  return p;
 }
 
 }  // namespace
@@ -145,27 +158,42 @@ extern "C" int dzn_vbx_create(const double* h_X, const double* h_Phi, const doub
   VbState* s = new VbState();
   double *X = nullptr, *Phi = nullptr;
   s->E = E; s->D = D; s->K = K; s->device = device;
+  if (device < 0 && hipGetDevice(&s->device) != hipSuccess) { delete s; *out_state = nullptr; return DZN_E_HIP; }
   s->nchunk = (E + VB_CHUNK - 1) / VB_CHUNK;
-  if (hipMalloc(&X, (size_t)E * D * 8) != hipSuccess) { rc = DZN_E_NOMEM; goto done; }
-  VCHK(hipMalloc(&Phi, (size_t)D * 8));
-  VCHK(hipMalloc(&s->rho, (size_t)E * D * 8));
-  VCHK(hipMalloc(&s->G, (size_t)E * 8));
-  VCHK(hipMalloc(&s->gamma, (size_t)E * K * 8));
-  VCHK(hipMalloc(&s->partial, (size_t)s->nchunk * K * (D + 1) * 8));
-  VCHK(hipMalloc(&s->stats, (size_t)K * (D + 1) * 8));
-  VCHK(hipMalloc(&s->alpha, (size_t)K * D * 8));
-  VCHK(hipMalloc(&s->ck, (size_t)K * 8));
-  VCHK(hipMalloc(&s->lpi, (size_t)K * 8));
-  VCHK(hipMalloc(&s->lpx, (size_t)E * 8));
-  VCHK(hipMalloc(&s->lpx_part, (size_t)s->nchunk * 8));
-  VCHK(hipMemcpy(X, h_X, (size_t)E * D * 8, hipMemcpyHostToDevice));
-  VCHK(hipMemcpy(Phi, h_Phi, (size_t)D * 8, hipMemcpyHostToDevice));
-  VCHK(hipMemcpy(s->gamma, h_gamma0, (size_t)E * K * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(vb_setup_kernel, dim3((E + 3) / 4), dim3(256), 0, 0, X, Phi, E, D, s->rho, s->G);
+  auto carve = [&](char* base) {
+    size_t off = 0;
+    s->rho = vb_take<double>(base, off, (size_t)E * D);
+    s->G = vb_take<double>(base, off, E);
+    s->gamma = vb_take<double>(base, off, (size_t)E * K);
+    s->partial = vb_take<double>(base, off, (size_t)s->nchunk * K * (D + 1));
+    s->stats = vb_take<double>(base, off, (size_t)K * (D + 1));
+    s->alpha = vb_take<double>(base, off, (size_t)K * D);
+    s->ck = vb_take<double>(base, off, K);
+    s->lpi = vb_take<double>(base, off, K);
+    s->lpx = vb_take<double>(base, off, E);
+    s->lpx_part = vb_take<double>(base, off, s->nchunk);
+    X = vb_take<double>(base, off, (size_t)E * D);        // setup only
+    Phi = vb_take<double>(base, off, D);
+    return off;
+  };
+  const size_t bytes = carve(nullptr);
+  char* base = nullptr;
+  rc = host_state_lease(s->device, bytes, &s->stream, &base);
+  if (rc != DZN_OK) { delete s; *out_state = nullptr; return rc; }
+  if (base) {
+    s->leased = true;
+  } else {                                                 // the arena belongs to another live state
+    if (hipMalloc(&s->own_block, bytes) != hipSuccess) { (void)hipGetLastError(); rc = DZN_E_NOMEM; goto done; }
+    base = s->own_block;
+  }
+  carve(base);
+  VCHK(hipMemcpyAsync(X, h_X, (size_t)E * D * 8, hipMemcpyHostToDevice, s->stream));
+  VCHK(hipMemcpyAsync(Phi, h_Phi, (size_t)D * 8, hipMemcpyHostToDevice, s->stream));
+  VCHK(hipMemcpyAsync(s->gamma, h_gamma0, (size_t)E * K * 8, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(vb_setup_kernel, dim3((E + 3) / 4), dim3(256), 0, s->stream, X, Phi, E, D, s->rho, s->G);
   VCHK(hipGetLastError());
-  VCHK(hipDeviceSynchronize());
+  VCHK(hipStreamSynchronize(s->stream));
 done:
-  (void)hipFree(X); (void)hipFree(Phi);
   if (rc != DZN_OK) { vb_free(s); s = nullptr; }
   *out_state = s;
   return rc;
@@ -179,10 +207,11 @@ extern "C" int dzn_vbx_stats(void* state, double* h_stats) {
   const int n = s->K * (s->D + 1);
   DeviceGuard dg(s->device);
   if (!dg.ok) return DZN_E_HIP;
-  hipLaunchKernelGGL(vb_accum_kernel, dim3(s->nchunk), dim3(256), 0, 0, s->gamma, s->rho, s->E, s->D, s->K, s->partial);
-  hipLaunchKernelGGL(vb_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, s->partial, s->nchunk, n, s->stats);
+  hipLaunchKernelGGL(vb_accum_kernel, dim3(s->nchunk), dim3(256), 0, s->stream, s->gamma, s->rho, s->E, s->D, s->K, s->partial);
+  hipLaunchKernelGGL(vb_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->partial, s->nchunk, n, s->stats);
   VCHK(hipGetLastError());
-  VCHK(hipMemcpy(h_stats, s->stats, (size_t)n * 8, hipMemcpyDeviceToHost));
+  VCHK(hipMemcpyAsync(h_stats, s->stats, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+  VCHK(hipStreamSynchronize(s->stream));
 done:
   return rc;
 }
@@ -197,16 +226,17 @@ extern "C" int dzn_vbx_estep(void* state, const double* h_alpha, const double* h
   double total = 0.0;
   DeviceGuard dg(s->device);
   if (!dg.ok) return DZN_E_HIP;
-  VCHK(hipMemcpy(s->alpha, h_alpha, (size_t)s->K * s->D * 8, hipMemcpyHostToDevice));
-  VCHK(hipMemcpy(s->ck, h_ck, (size_t)s->K * 8, hipMemcpyHostToDevice));
-  VCHK(hipMemcpy(s->lpi, h_lpi, (size_t)s->K * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(vb_estep_kernel, dim3((s->E + 3) / 4), dim3(256), 0, 0, s->rho, s->G, s->alpha, s->ck, s->lpi, Fa,
+  VCHK(hipMemcpyAsync(s->alpha, h_alpha, (size_t)s->K * s->D * 8, hipMemcpyHostToDevice, s->stream));
+  VCHK(hipMemcpyAsync(s->ck, h_ck, (size_t)s->K * 8, hipMemcpyHostToDevice, s->stream));
+  VCHK(hipMemcpyAsync(s->lpi, h_lpi, (size_t)s->K * 8, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(vb_estep_kernel, dim3((s->E + 3) / 4), dim3(256), 0, s->stream, s->rho, s->G, s->alpha, s->ck, s->lpi, Fa,
                      s->E, s->D, s->K, s->gamma, s->lpx);
   // sum of log_px: chunk partials (vb_accum with K = 1, D = 0 reads "gamma" = lpx and sums it), then in-order reduce
-  hipLaunchKernelGGL(vb_accum_kernel, dim3(s->nchunk), dim3(256), 0, 0, s->lpx, s->rho, s->E, 0, 1, s->lpx_part);
-  hipLaunchKernelGGL(vb_reduce_kernel, dim3(1), dim3(256), 0, 0, s->lpx_part, s->nchunk, 1, s->stats);
+  hipLaunchKernelGGL(vb_accum_kernel, dim3(s->nchunk), dim3(256), 0, s->stream, s->lpx, s->rho, s->E, 0, 1, s->lpx_part);
+  hipLaunchKernelGGL(vb_reduce_kernel, dim3(1), dim3(256), 0, s->stream, s->lpx_part, s->nchunk, 1, s->stats);
   VCHK(hipGetLastError());
-  VCHK(hipMemcpy(&total, s->stats, 8, hipMemcpyDeviceToHost));
+  VCHK(hipMemcpyAsync(&total, s->stats, 8, hipMemcpyDeviceToHost, s->stream));
+  VCHK(hipStreamSynchronize(s->stream));
   *h_total = total;
 done:
   return rc;
@@ -217,7 +247,8 @@ extern "C" int dzn_vbx_gamma(void* state, double* h_gamma) {
   if (!s || !h_gamma) return DZN_E_INVALID;
   DeviceGuard dg(s->device);
   if (!dg.ok) return DZN_E_HIP;
-  return hipMemcpy(h_gamma, s->gamma, (size_t)s->E * s->K * 8, hipMemcpyDeviceToHost) == hipSuccess ? DZN_OK : DZN_E_HIP;
+  if (hipMemcpyAsync(h_gamma, s->gamma, (size_t)s->E * s->K * 8, hipMemcpyDeviceToHost, s->stream) != hipSuccess) return DZN_E_HIP;
+  return hipStreamSynchronize(s->stream) == hipSuccess ? DZN_OK : DZN_E_HIP;
 }
 
 extern "C" int dzn_vbx_destroy(void* state) {

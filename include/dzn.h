@@ -249,6 +249,8 @@ int dzn_cdist_cosine(const float* h_emb, int32_t n, int32_t dim, const double* h
  * buffers from one grow-only arena per device (they are called from the pipeline's host stage, which may run in a second
  * thread while the engine executes the next recording's device stage: no null-stream ordering behind the engine's queue, no
  * hipFree).  The arena is re-allocated only when a call needs more than any call before it; these return it / report it.
+ * A dzn_vbx_* state is carved from a second arena of the same context (leased to one state at a time — a second live state gets a
+ * block of its own — and kept while a state holds it) and works on the same stream.
  * device < 0 in dzn_host_workspace_release = every device.  No reference counterpart (scipy owns its host buffers). */
 int dzn_host_workspace_release(int32_t device);
 int64_t dzn_host_workspace_bytes(int32_t device);

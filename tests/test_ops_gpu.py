@@ -607,6 +607,57 @@ def test_vbx_gmm_equals_numpy(built_lib, gpu, E, K):
     assert np.abs(g1_dev - g1_ref).max() <= 1e-11
 
 
+def test_vbx_states_share_the_host_arena_or_own_a_block(built_lib, gpu):
+    """(r5) csrc/vbx.hip carves a state from the host stage's state arena (csrc/linkage.hip: no hipMalloc / hipFree per recording,
+    own stream); a SECOND state created while the first lives gets a block of its own.  Both give the statistics of their own
+    responsibilities (column sums of gamma, gamma^T rho) while the default stream is busy, the arena is reused by the next state
+    and returned by dzn_host_workspace_release once no state holds it."""
+    import ctypes as C
+    import numpy as np
+    from diarizen_amd import _lib
+    from oracle.gen_golden import synth_vbx_case
+    lib = _lib.load()
+
+    def create(E, K):
+        X, Phi, q0 = synth_vbx_case(E, K)
+        X, Phi, q0 = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Phi, q0))
+        st = C.c_void_p()
+        _lib.check(lib.dzn_vbx_create(X.ctypes.data_as(C.c_void_p), Phi.ctypes.data_as(C.c_void_p), q0.ctypes.data_as(C.c_void_p),
+                                      E, X.shape[1], K, 0, C.byref(st)), None, "dzn_vbx_create")
+        return st, X, Phi, q0
+
+    def stats(st, X, Phi, q0):
+        K, D = q0.shape[1], X.shape[1]
+        out = np.empty((K, D + 1))
+        _lib.check(lib.dzn_vbx_stats(st, out.ctypes.data_as(C.c_void_p)), None, "dzn_vbx_stats")
+        rho = X * np.sqrt(Phi)
+        assert np.allclose(out[:, :D], q0.T @ rho, rtol=1e-12, atol=1e-10) and np.allclose(out[:, D], q0.sum(0), rtol=1e-12)
+
+    lib.dzn_host_workspace_release(0)
+    assert lib.dzn_host_workspace_bytes(0) == 0
+    a = create(5000, 7)
+    held = lib.dzn_host_workspace_bytes(0)
+    assert held >= 5000 * 128 * 8 * 2
+    b = create(3000, 5)                               # the arena is leased: a block of its own
+    assert lib.dzn_host_workspace_bytes(0) == held
+    big = torch.randn(8192, 8192, device=gpu)
+    for _ in range(20):
+        big = big @ big * 1e-4                        # default-stream work in flight while the states are used
+    stats(*b)
+    stats(*a)
+    torch.cuda.synchronize()
+    lib.dzn_host_workspace_release(0)                 # a live state keeps its arena
+    assert lib.dzn_host_workspace_bytes(0) == held
+    lib.dzn_vbx_destroy(a[0])
+    lib.dzn_vbx_destroy(b[0])
+    c = create(4000, 6)                               # reuses the arena (no growth)
+    assert lib.dzn_host_workspace_bytes(0) == held
+    stats(*c)
+    lib.dzn_vbx_destroy(c[0])
+    lib.dzn_host_workspace_release(0)
+    assert lib.dzn_host_workspace_bytes(0) == 0
+
+
 def test_clustering_backends_agree(built_lib, gpu):
     """AHC and VBx-style AHC initialisation through both linkage backends and both cdist backends: identical hard
     clusters."""
