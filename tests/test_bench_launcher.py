@@ -105,3 +105,49 @@ def test_power_sampler_reads_the_rocm_smi_csv(monkeypatch):
     silent = bench.PowerSampler()
     silent._poll()
     assert silent.result() is None
+
+
+def test_power_sampler_picks_the_card_of_the_torch_device(monkeypatch):
+    """(r5, ADVICE r4) the sampled rocm-smi card is the one whose PCI bus id is the torch device's (`rocm-smi --showbus --csv`);
+    without a match the first card is sampled and the result says so."""
+    import subprocess
+    import torch
+    import bench
+    line = next(ln for ln in (ROOT / "profiles" / "r4_power_cap.txt").read_text().splitlines() if ln.startswith("[f32h K1024 random] device"))
+    power_csv = line.split("] ", 1)[1].replace(" | ", "\n")
+    hdr, row = power_csv.splitlines()[0], power_csv.splitlines()[1]
+    two_cards = "\n".join([hdr, row.replace("card0", "card0", 1).replace("1400.0", "90.0", 1), row.replace("card0", "card3", 1)])
+
+    class Done:
+        def __init__(self, out):
+            self.stdout = out
+
+    def fake_run(cmd, *a, **k):
+        return Done("device,PCI Bus\ncard0,0000:05:00.0\ncard3,0000:C5:00.0\n") if "--showbus" in cmd else Done(two_cards)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "get_device_properties",
+                        lambda d: SimpleNamespace(pci_domain_id=0, pci_bus_id=0xC5, pci_device_id=0))
+    ps = bench.PowerSampler(device=0)
+    assert ps.card == "card3" and ps.card_matched
+    ps._poll()
+    res = ps.result()
+    assert res["card"] == "card3" and res["card_matched_by_pci_bus_id"] is True
+    monkeypatch.setattr(torch.cuda, "get_device_properties",
+                        lambda d: SimpleNamespace(pci_domain_id=0, pci_bus_id=0x11, pci_device_id=0))
+    ps2 = bench.PowerSampler(device=0)
+    assert ps2.card is None and not ps2.card_matched
+    ps2._poll()
+    assert ps2.result()["card"] == "card0" and ps2.result()["card_matched_by_pci_bus_id"] is False
+
+
+def test_other_roof_names_the_binding_roof():
+    """bench.py's second roof of a matrix class: the reduced contraction (268 GFLOP over 1.90 GB per launch) is below the ridge of
+    its 1250 TFLOP/s peak, the f32h contraction (405 GFLOP over 2.39 GB) above the ridge of 833."""
+    import bench
+    mx = bench.other_roof({"flops": 268.168e9, "bytes": 1.90215e9, "ms": 0.985}, "mx")
+    assert mx["binding_roof"] == "hbm" and abs(mx["alg_intensity_flop_per_byte"] - 141.0) < 0.1 and abs(mx["ridge_flop_per_byte"] - 156.2) < 0.1
+    assert abs(mx["frac_of_hbm_peak"] - 1.90215e9 / 0.985e-3 / 8e12) < 1e-3
+    h2 = bench.other_roof({"flops": 404.677e9, "bytes": 2.393908e9, "ms": 1.3288}, "f32h")
+    assert h2["binding_roof"] == "mfma" and h2["ridge_flop_per_byte"] == 104.2
+    assert bench.other_roof({"flops": 1e9, "bytes": 0.0, "ms": 1.0}, "f32h") == {}
