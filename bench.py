@@ -225,6 +225,15 @@ def pmc_table(args, precision=None):
     return table
 
 
+def rocprof_trace_name(args):
+    """the committed `rocprofv3 --kernel-trace --stats` summary of this same command whose average duration of the dominant
+    kernel `roofline.avg_launch_ms` is to be compared with (newest round last)"""
+    found = sorted((ROOT / "profiles").glob(f"r*_kernel_stats_{args.precision}_30min_b{args.batch}.csv"))
+    if not found or args.minutes != 30.0 or args.model != "wavlm_large_s80_md" or args.window != 8.0:
+        return None
+    return f"profiles/{found[-1].name}"
+
+
 def pmc_lookup(table, kernel_class: str, field: str):
     if not table:
         return None
@@ -814,19 +823,12 @@ def main():
                 S, L = eng.seg.max_speakers_per_chunk, runner.num_frames
                 seg_l = res.segmentations if res is not None else torch.empty((0, L, S), device=dev, dtype=torch.uint8)
                 emb_l = res.embeddings if res is not None else torch.empty((0, S, eng.emb.embed_dim), device=dev)
-                seg_g, emb_g = gather_windows(seg_l, emb_l)
-                return (seg_g.cpu(), emb_g.cpu()) if rank == 0 else (None, None)
+                seg_g, emb_g = gather_windows(seg_l, emb_l, expected_total=n_windows, to_host=rank == 0)
+                return (seg_g, emb_g) if rank == 0 else (None, None)
             own = (res.segmentations.cpu(), res.embeddings.cpu())       # this rank's recording: its own host stage below
-            if dist.get_backend() != "nccl":       # single-GPU rehearsal of the N > 1 path (gloo: host staging)
-                seg_g, emb_g = gather_windows(res.segmentations, res.embeddings)
-                _ = (seg_g.cpu(), emb_g.cpu()) if rank == 0 else None
-                return own
-            segs = [torch.empty_like(res.segmentations) for _ in range(world)]
-            embs = [torch.empty_like(res.embeddings) for _ in range(world)]
-            dist.all_gather(segs, res.segmentations)
-            dist.all_gather(embs, res.embeddings)
-            if rank == 0:
-                _ = torch.cat(segs).cpu(), torch.cat(embs).cpu()
+            # the path's one exchange (dist.py): ONE all_gather_into_tensor of the packed per-window results; every rank holds
+            # n_windows of them, so the partition the gather verifies is the equal-block one; rank 0 takes the corpus to the host
+            _ = gather_windows(res.segmentations, res.embeddings, expected_total=world * n_windows, to_host=rank == 0)
             return own
         return res.segmentations.cpu(), res.embeddings.cpu()
 
@@ -880,6 +882,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    skip0 = eng.embed_skip_stats() if full else (0, 0)        # device counters, read OUTSIDE the timed region (before / after)
     power = PowerSampler(device=dev) if rank == 0 and not args.no_power else None
     if power:
         power.start()
@@ -898,6 +901,7 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    skip1 = eng.embed_skip_stats() if full else (0, 0)
     prof = [] if args.no_profile else _lib.profile_collect()
     _lib.profile_enable(False)
     per_rank_ms = [round(dt / args.steps * 1e3, 2)]
@@ -966,6 +970,7 @@ def main():
                             **other_roof(top, prec),
                             "traffic": pmc_lookup(traffic, top["name"], "hbm_bytes_per_launch"),
                             "traffic_source": f"{TRAFFIC_SOURCE} [{traffic.get('_file')}]" if traffic else None,
+                            "rocprof_kernel_trace": rocprof_trace_name(args),
                             "launches": top["launches"],
                             "avg_launch_ms": round(top["ms"] / top["launches"], 4),
                             "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 3),
@@ -1035,6 +1040,14 @@ def main():
                                    f"{n_windows} windows, batch {args.batch}; host stage of step i {'pipelined beside the device stage of step i+1' if pool is not None else 'serially behind its device stage'}; `device_value` = the device hot path alone "
                                    f"(r1-r4's `value`), `e2e` = the same through DiariZenPipeline incl. the host -> HBM upload",
                        "cpu_baseline_kind": None,
+                       # audit keys, inside `config` because the driver keeps this object whole:
+                       "device_value": round(device_value, 2) if device_value else None,
+                       "serial_value": round(total_audio * 1e3 / unprofiled_ms, 2),
+                       "emb_windows_per_step": (skip1[0] - skip0[0]) // max(args.steps, 1) if full else None,
+                       "emb_trunk_skipped_per_step": (skip1[1] - skip0[1]) // max(args.steps, 1) if full else None,
+                       "emb_note": "windows handed to dzn_embed_forward per step / windows whose ResNet34 trunk was skipped because no "
+                                   "local speaker was active (dzn_embed_skip_stats, device counters read before and after the timed "
+                                   "region): 36.18 of the 104.9 algorithmic GFLOP per window are executed only for the others",
                        "windows_per_step": n_windows, "batch": args.batch, "launches": batches_note(n_windows, args.batch),
                        "weights": ("seeded turn-taking weights (testkit/weights.py: random init + Hann depthwise taps + calibrated "
                                    "classifier -> many powerset classes, both mask branches; no checkpoints offline)"

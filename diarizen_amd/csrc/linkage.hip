@@ -768,7 +768,9 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   LCHK(hipGetLastError());
   LCHK(hipMemcpyAsync(h_Z, Z, (size_t)(n - 1) * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
 done:
-  (void)hipStreamSynchronize(s);       // the host vectors above (ones, ids, st0) are sources of queued copies
+  // the host vectors above (ones, ids, st0) are sources of queued copies; an asynchronous fault of a step kernel or of the final
+  // copy surfaces HERE, and h_Z is garbage then: it must not return DZN_OK
+  if (hipStreamSynchronize(s) != hipSuccess && rc == DZN_OK) rc = DZN_E_HIP;
   return rc;
 }
 
@@ -868,6 +870,6 @@ extern "C" int dzn_cdist_cosine(const float* h_emb, int32_t n, int32_t dim, cons
   LCHK(hipGetLastError());
   LCHK(hipMemcpyAsync(h_dist, D, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, s));
 done:
-  (void)hipStreamSynchronize(s);
+  if (hipStreamSynchronize(s) != hipSuccess && rc == DZN_OK) rc = DZN_E_HIP;   // h_dist is only valid after a clean drain
   return rc;
 }

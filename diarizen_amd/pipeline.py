@@ -259,9 +259,11 @@ class DiariZenPipeline:
             S = self.engine.seg.max_speakers_per_chunk
             seg_l = torch.empty((0, r.num_frames, S), device=self.device, dtype=torch.uint8)
             emb_l = torch.empty((0, S, self.engine.emb.embed_dim), device=self.device, dtype=torch.float32)
-        seg, emb = dz_dist.gather_windows(seg_l, emb_l, expected_total=C)
-        torch.cuda.synchronize(self.device)
-        return seg.cpu().numpy(), emb.cpu().numpy()
+        # one packed all-gather + ONE device-to-host copy; the copy waits for the CURRENT stream only, which run() joined with the
+        # handles' streams - not a device-wide synchronise, which would also wait for the host stage of the previous recording
+        # on its own high-priority stream (diarize_many)
+        seg, emb = dz_dist.gather_windows(seg_l, emb_l, expected_total=C, to_host=True)
+        return seg.numpy(), emb.numpy()
 
     def host_stage(self, seg: np.ndarray, emb: np.ndarray, sess_name: Optional[str] = None, hook=None) -> Annotation:
         """counting -> clustering -> reconstruction -> Annotation (inference.py:137-185)."""

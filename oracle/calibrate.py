@@ -15,6 +15,8 @@ transitions in every window, smallest top-2 logit margin >= 3e-4 (so fp32 re-ass
 ~1e-5 cannot flip a decision of the fixture itself).
 
     python oracle/calibrate.py                 # all configs -> testkit/data/cal_<config>_seed0.npz
+    python oracle/calibrate.py --outlier       # the planted-massive-activation weights (testkit/weights.py:outlier_state_dict)
+                                               # -> cal_<config>_outlier_seed0.npz: classifier + the LayerNorm sigma table
 
 Calibration audio: tests/golden/EN2002a_30s.wav (the reference's example file) plus a few windows of
 the synthetic bench recording, cut into windows of the config's fixture length.
@@ -33,7 +35,8 @@ sys.path.insert(0, str(ROOT))
 from oracle.wav import first_channel_pcm16 as first_channel_16k  # noqa: E402
 from oracle.configs import get_seg_config  # noqa: E402
 from testkit.synth import synth_recording  # noqa: E402
-from testkit.weights import CAL_DIR, seg_state_dict, turn_taking_head  # noqa: E402
+from testkit.weights import (CAL_DIR, outlier_ln_sites, outlier_plan, plant_outliers, seg_state_dict,  # noqa: E402
+                             turn_taking_head)
 from oracle import seg_model  # noqa: E402
 from oracle.pipeline import slide_windows  # noqa: E402
 
@@ -100,6 +103,54 @@ def fit_classifier(F: np.ndarray, n_classes: int, n_real: int, k: int = 8, gain:
     return best[1], best[2], best[3]
 
 
+def fit_ln_sigma(sd_base, cfg, windows: torch.Tensor, seed: int = 0) -> np.ndarray:
+    """One oracle pass over `windows` with the planted weights in which every LayerNorm that reads the outlier-carrying stream
+    measures the std of the TYPICAL channels of its input and rescales its gamma for them on the spot (sites are visited in
+    forward order, so each measurement already sees the calibrated sites before it).  -> sigma per site of outlier_ln_sites(cfg),
+    rounded to 4 significant digits so that the table, not a machine-dependent reduction order, defines the weights."""
+    import torch.nn.functional as F
+    chans, mags, rms, sigma = outlier_plan(cfg, seed)
+    sd = plant_outliers(sd_base, cfg, seed, {})
+    sites = outlier_ln_sites(cfg)
+    by_ptr = {sd[k + ".weight"].data_ptr(): k for k in sites}
+    typ = torch.ones(cfg.embed_dim, dtype=torch.bool)
+    typ[chans] = False
+    table = {}
+    orig = F.layer_norm
+
+    def measuring(x, shape, weight=None, bias=None, eps=1e-5):
+        k = by_ptr.get(weight.data_ptr()) if weight is not None else None
+        if k is not None and k not in table:
+            s_ = float(f"{float(x[..., typ].std()):.4g}")
+            table[k] = s_
+            weight[typ] *= sigma / s_
+        return orig(x, shape, weight, bias, eps)
+
+    F.layer_norm = measuring
+    try:
+        with torch.inference_mode(False), torch.no_grad():
+            seg_model.encoder(sd, cfg, seg_model.feature_extractor(sd, cfg, windows))
+    finally:
+        F.layer_norm = orig
+    return np.array([table[k] for k in sites], dtype=np.float64)
+
+
+def calibrate_outlier(name: str, seed: int = 0, verbose: bool = True):
+    cfg = get_seg_config(name)
+    base = turn_taking_head(seg_state_dict(cfg, seed), cfg, seed)
+    windows, n_real = calibration_windows(name)
+    ln_sigma = fit_ln_sigma(base, cfg, windows[:4], seed)
+    sd = plant_outliers(base, cfg, seed, dict(zip(outlier_ln_sites(cfg), ln_sigma.tolist())))
+    F = head_features(sd, cfg, windows)
+    W, b, rep = fit_classifier(F, cfg.n_classes, n_real)
+    path = CAL_DIR / f"cal_{name}_outlier_seed{seed}.npz"
+    np.savez(path, W=W.astype(np.float32), b=b.astype(np.float32), ln_sigma=ln_sigma, report=np.array(repr(rep)))
+    if verbose:
+        print(name, "ln_sigma", ln_sigma.round(3).tolist())
+        print(name, rep, "->", path.relative_to(ROOT))
+    return path
+
+
 def calibrate(name: str, seed: int = 0, verbose: bool = True):
     cfg = get_seg_config(name)
     sd = turn_taking_head(seg_state_dict(cfg, seed), cfg, seed)
@@ -116,5 +167,10 @@ def calibrate(name: str, seed: int = 0, verbose: bool = True):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for nm in (sys.argv[1:] or list(PLAN)):
-        calibrate(nm)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--outlier" in sys.argv:
+        for nm in (args or ["wavlm_large_s80_md", "wavlm_base_s80_md", "tiny_ln", "tiny_gn"]):
+            calibrate_outlier(nm)
+    else:
+        for nm in (args or list(PLAN)):
+            calibrate(nm)

@@ -177,6 +177,83 @@ def gen_seg_tt():
                             logp=logp.numpy(), min_margin=margin.min())
 
 
+# planted massive activations (testkit/weights.py:outlier_state_dict): config -> (N, window starts)
+OUTLIER_CASES = {
+    "tiny_ln": (8000, [32000, 96000]),
+    "tiny_gn": (8000, [48000, 160000]),
+    "wavlm_large_s80_md": (128000, [0, 192000]),
+    "wavlm_base_s80_md": (80000, [40000 * i for i in range(8)]),
+}
+
+
+def gen_seg_outlier():
+    """Reference modules (strict load) with the planted-outlier weights on real audio.  Also runs the SAME reference modules in
+    float64 and stores that result: |fp32 - fp64| of the reference itself says how much of the 1e-3 bar the fixture leaves to
+    an implementation whose fp32 operations are merely ordered differently (asserted <= 3e-4)."""
+    from testkit.weights import outlier_plan, outlier_state_dict
+    for name, (N, starts) in OUTLIER_CASES.items():
+        cfg = get_seg_config(name)
+        sd = outlier_state_dict(cfg, 0)
+        fwd = build_reference_seg(cfg, sd)
+        wave = tt_windows(starts, N)
+        outs = [fwd(wave[b0:b0 + 8]) for b0 in range(0, len(starts), 8)]
+        logp = torch.cat([o[0] for o in outs])
+        rep_last = torch.cat([o[1][-1] for o in outs])
+        chans, mags, rms, sigma = outlier_plan(cfg, 0)
+        typ = torch.ones(cfg.embed_dim, dtype=torch.bool)
+        typ[chans] = False
+        ratio = float(rep_last[..., chans].abs().max() / rep_last[..., typ].std())
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        torch.set_default_dtype(torch.float64)
+        try:
+            fwd64 = build_reference_seg(cfg, sd64)
+            logp64 = torch.cat([fwd64(wave[b0:b0 + 8].double())[0] for b0 in range(0, len(starts), 8)])
+        finally:
+            torch.set_default_dtype(torch.float32)
+        ref_noise = float((logp.double() - logp64).abs().max())
+        am = logp.argmax(-1).numpy()
+        hist = np.bincount(am.ravel(), minlength=cfg.n_classes)
+        srt = np.sort(logp.numpy(), -1)
+        margin = srt[..., -1] - srt[..., -2]
+        print(f"seg_outlier_{name}: logp {tuple(logp.shape)} argmax hist {hist.tolist()} transitions/window "
+              f"{(am[:, 1:] != am[:, :-1]).sum(1).mean():.1f} min top-2 margin {margin.min():.2e}; last layer: massive / typical "
+              f"= {ratio:.0f}; reference fp32 vs its own float64 run: {ref_noise:.2e}")
+        assert (hist > 0).sum() >= 5, "degenerate fixture"
+        assert ratio >= 256, "the outliers did not survive to the last layer"
+        assert ref_noise <= 3e-4, "fixture too ill-conditioned for a 1e-3 bar"
+        np.savez_compressed(GOLD / f"seg_outlier_{name}.npz", N=N, starts=np.array(starts), weight_seed=0,
+                            logp=logp.numpy(), logp64=logp64.numpy(), min_margin=margin.min(), chans=chans.numpy(),
+                            massive_over_typical=ratio, ref_fp32_vs_fp64=ref_noise,
+                            rep_last_outlier=rep_last[..., chans].numpy())
+
+
+# loudness extremes in ONE batch: per-window operand scales must not leak between windows.  window 0 as recorded, 1 near-silent
+# (x 1e-4: below the eps of the waveform LayerNorm and of conv0's channel norm), 2 clipped (x 8, clamped to +-1), 3 digital silence
+LOUD_CASES = {"tiny_ln": (8000, 32000), "tiny_gn": (8000, 48000), "wavlm_large_s80_md": (128000, 192000),
+              "wavlm_base_s80_md": (80000, 120000)}
+
+
+def loud_windows(N: int, start: int) -> torch.Tensor:
+    w = tt_windows([start], N)[0]
+    return torch.stack([w, w * 1e-4, (w * 8.0).clamp(-1.0, 1.0), torch.zeros_like(w)])
+
+
+def gen_seg_loud():
+    from testkit.weights import turn_taking_state_dict
+    for name, (N, start) in LOUD_CASES.items():
+        cfg = get_seg_config(name)
+        sd = turn_taking_state_dict(cfg, 0)
+        fwd = build_reference_seg(cfg, sd)
+        wave = loud_windows(N, start)
+        logp = fwd(wave)[0]
+        alone = torch.cat([fwd(wave[b:b + 1])[0] for b in range(4)])
+        print(f"seg_loud_{name}: logp {tuple(logp.shape)} classes per window "
+              f"{[len(np.unique(logp[b].argmax(-1).numpy())) for b in range(4)]}; batch vs one-by-one in the reference "
+              f"{(logp - alone).abs().max():.1e}; finite {bool(torch.isfinite(logp).all())}")
+        assert torch.isfinite(logp).all()
+        np.savez_compressed(GOLD / f"seg_loud_{name}.npz", N=N, start=start, weight_seed=0, logp=logp.numpy())
+
+
 # ------------------------------------------------------------------ embedding model
 def load_reference_resnet():
     """wespeaker/resnet.py + blocks/pooling.py + utils/receptive_field.py by file path, with
@@ -222,6 +299,39 @@ def gen_emb():
     print("emb_resnet:", tuple(embs.shape), "multi-vs-single max diff",
           (embs - multi).abs().max().item(), "zero-mask == bias:",
           (embs[0, 2] - sd["resnet.seg_1.bias"]).abs().max().item())
+
+
+def gen_emb_outlier():
+    """The reference ResNet34 with planted BatchNorm outliers (testkit/weights.py:emb_outlier_state_dict) on the inputs of
+    gen_emb; the float64 run of the same module says what the fixture leaves of the bar."""
+    import warnings
+    from oracle import emb_model
+    from testkit.weights import emb_outlier_state_dict
+    resnet, pooling = load_reference_resnet()
+    sd = emb_outlier_state_dict(0)
+    net = resnet.ResNet34(80, 256, pooling_func="TSTP", two_emb_layer=False)
+    net.load_state_dict({k[len("resnet."):]: v for k, v in sd.items()}, strict=True)
+    net.eval()
+    B, N, L = 2, 24000, 74
+    wave = synth_wave(B, N, 31)
+    fb = emb_model.compute_fbank(wave)
+    g = torch.Generator().manual_seed(5)
+    masks = (torch.rand(B, 4, L, generator=g) > 0.5).float()
+    masks[0, 2] = 0.0
+    masks[1, 3, 5:] = 0.0
+    with torch.inference_mode(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        embs = torch.stack([net(fb.clone(), weights=masks[:, s])[1] for s in range(4)], dim=1)
+        net64 = net.double()
+        embs64 = torch.stack([net64(fb.double(), weights=masks[:, s].double())[1] for s in range(4)], dim=1)
+    rel = float((embs.double() - embs64).abs().max() / embs64.abs().max())
+    taps = {}
+    trunk = emb_model.resnet_trunk(sd, fb)
+    print("emb_resnet_outlier:", tuple(embs.shape), "reference fp32 vs its own float64 run, rel:", f"{rel:.1e}",
+          "|emb| max", float(embs.abs().max()), "trunk out max", float(trunk.abs().max()))
+    assert rel < 2e-5
+    np.savez_compressed(GOLD / "emb_resnet_outlier.npz", B=B, N=N, L=L, wave_seed=31, weight_seed=0,
+                        masks=masks.numpy(), emb=embs.numpy(), emb64=embs64.numpy(), ref_fp32_vs_fp64_rel=rel)
 
 
 def gen_statspool_powerset():
@@ -778,7 +888,8 @@ def gen_host30(src: str = "gpurun_out/host30.npz"):
 
 
 GENERATORS = {"host30": gen_host30, "linkage_scale": gen_linkage_scale, "configs": gen_configs, "seg": gen_seg, "seg_tt": gen_seg_tt, "emb": gen_emb, "kat": gen_statspool_powerset, "host": gen_host,
-              "e2e": gen_e2e, "host_ref": gen_host_ref, "host_forced": gen_host_forced, "f4": gen_f4}
+              "e2e": gen_e2e, "host_ref": gen_host_ref, "host_forced": gen_host_forced, "f4": gen_f4,
+              "seg_outlier": gen_seg_outlier, "seg_loud": gen_seg_loud, "emb_outlier": gen_emb_outlier}
 
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)

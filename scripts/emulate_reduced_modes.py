@@ -4,6 +4,7 @@ SURVEY 8d's reduced bar (max |dlogp| <= 5e-2, argmax >= 99.5 %) on the non-degen
     python scripts/emulate_reduced_modes.py [model=wavlm_large_s80_md] [windows=2]
     python scripts/emulate_reduced_modes.py embedding [windows=2]
     python scripts/emulate_reduced_modes.py wavlm_large_s80_md 2 sweep     # + one contraction class at a time at the other scheme
+    python scripts/emulate_reduced_modes.py wavlm_large_s80_md 2 outlier   # on the planted-massive-activation weights (r6)
 
 Every linear layer / 1x1 conv / positional conv of oracle/seg_model.py is replaced by an emulated contraction (products of
 rounded operands are exact in fp32, accumulation in fp32 — what the MFMA forms do); the conv stack, the gate, attention products
@@ -112,13 +113,14 @@ class Scheme:
         return y if b is None else y + b
 
 
-def run(model: str, n_windows: int, sweep: bool = False):
+def run(model: str, n_windows: int, sweep: bool = False, weights: str = "tt"):
+    """weights = "tt" (turn-taking weights) | "outlier" (the same + planted massive activations, testkit/weights.py)"""
     from diarizen_amd.configs import get_seg_config
     from oracle import seg_model
     from oracle.gen_golden import TT_CASES, tt_windows
-    from testkit.weights import turn_taking_state_dict
+    from testkit.weights import outlier_state_dict, turn_taking_state_dict
     cfg = get_seg_config(model)
-    sd = turn_taking_state_dict(cfg, 0)
+    sd = outlier_state_dict(cfg, 0) if weights == "outlier" else turn_taking_state_dict(cfg, 0)
     N, starts = TT_CASES[model]
     starts = list(starts)
     while len(starts) < n_windows:
@@ -240,4 +242,4 @@ if __name__ == "__main__":
         run_embedding(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
     else:
         run(sys.argv[1] if len(sys.argv) > 1 else "wavlm_large_s80_md", int(sys.argv[2]) if len(sys.argv) > 2 else 2,
-            sweep=len(sys.argv) > 3 and sys.argv[3] == "sweep")
+            sweep="sweep" in sys.argv[3:], weights="outlier" if "outlier" in sys.argv[3:] else "tt")

@@ -189,3 +189,121 @@ def turn_taking_state_dict(cfg: SegConfig, seed: int = 0, calibration=None) -> D
     assert W.shape == sd["classifier.weight"].shape and b.shape == sd["classifier.bias"].shape
     sd["classifier.weight"], sd["classifier.bias"] = W.contiguous(), b.contiguous()
     return sd
+
+
+# ---------------------------------------------------------------------------- planted massive activations
+# Trained WavLM / wav2vec 2.0 encoders carry "massive activations": a handful of residual-stream channels sit 10^3 - 10^4 x above
+# the typical magnitude from an early layer onwards, almost constant over time, and every LayerNorm / linear layer downstream has
+# learned to live with them (small gamma / small weight columns on those channels).  Seeded Gaussian weights have nothing of the kind,
+# so every |max| tracker, power-of-two operand scale, fp8 block scale and LayerNorm statistic of the engine would only ever meet
+# well-conditioned rows.  `outlier_state_dict` plants them (VERDICT r5 "next round" item 1):
+#   * OUTLIER_CHANNELS residual channels become massive at the END of encoder layer 2 (1 for the tiny encoders): magnitudes 2^10 ... 2^13 x the
+#     typical std (mixed signs), plus a token-varying part 2^6 x typical -
+#       pre-norm encoders (large; W2V/components.py:920-935): bias + weight row of that layer's `feed_forward.output_dense`
+#       (:805-813) - the residual stream is never normalised, so the channels stay massive to the last layer and in the layer sum;
+#       post-norm encoders (base; :937-942): beta / gamma of that layer's `final_layer_norm`, and every later LayerNorm of the stream
+#       re-emits them (gamma = the row rms, which an outlier-dominated row normalises to +-rms^-1 * M).
+#   * every consumer is "trained" for them: LayerNorms that read the stream scale typical channels back to O(1) (gamma x rms / sigma)
+#     and the massive ones down (pre-norm) ; linear layers that read the stream directly (post-norm q/k/v, FFN-in; `proj` after the
+#     layer sum) get columns / M on those channels.  The relative-position gate (`gru_rel_pos_linear`, :702-710) is left alone: its
+#     sigmoid saturates on the head that owns a massive channel, which is what a real checkpoint does to it too.
+# The rest is `turn_taking_state_dict` with its own classifier calibration (testkit/data/cal_<config>_outlier_seed<seed>.npz).
+OUTLIER_CHANNELS = 4
+OUTLIER_MAGS = (2.0 ** 10, -2.0 ** 11, -1.25 * 2.0 ** 12, 2.0 ** 13)     # x sigma; their sum (2^11) shifts every row mean by 2-3 sigma
+
+
+def outlier_layer(cfg: SegConfig) -> int:
+    return min(2, cfg.n_layers // 2 - 1)
+
+
+def outlier_plan(cfg: SegConfig, seed: int = 0):
+    """-> (channels [4], signed magnitudes [4], rms of an outlier-dominated row, typical sigma of the stream)"""
+    g = torch.Generator().manual_seed(9000 + seed)
+    D = cfg.embed_dim
+    chans = torch.randperm(D, generator=g)[:OUTLIER_CHANNELS]
+    sigma = 2.0 if cfg.layer_norm_first else 1.0
+    mags = sigma * torch.tensor(OUTLIER_MAGS)
+    rms = float(torch.sqrt((mags ** 2).sum() / D))
+    return chans, mags, rms, sigma
+
+
+def outlier_ln_sites(cfg: SegConfig):
+    """state_dict keys (without .weight) of the LayerNorms that read the stream once it carries the massive channels"""
+    tp = f"{P}encoder.transformer.layers"
+    sites = []
+    for i in range(outlier_layer(cfg) + 1, cfg.n_layers):
+        if cfg.remaining_heads[i] or not cfg.layer_norm_first:
+            sites.append(f"{tp}.{i}.layer_norm")
+        sites.append(f"{tp}.{i}.final_layer_norm")
+    return sites
+
+
+def plant_outliers(sd: Dict[str, torch.Tensor], cfg: SegConfig, seed: int = 0, ln_sigma=None) -> Dict[str, torch.Tensor]:
+    """`ln_sigma`: {LayerNorm key: std of the TYPICAL channels of its input} - the calibration (oracle/calibrate.py --outlier
+    measures it site by site in one pass and stores it next to the classifier); a site without an entry takes `sigma`."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    ln_sigma = ln_sigma or {}
+    chans, mags, rms, sigma = outlier_plan(cfg, seed)
+    tp = f"{P}encoder.transformer.layers"
+    p = outlier_layer(cfg)
+    inv = sigma / mags.abs()
+    if cfg.layer_norm_first:
+        sd[f"{tp}.{p}.feed_forward.output_dense.weight"][chans] *= 64.0
+        sd[f"{tp}.{p}.feed_forward.output_dense.bias"][chans] = mags
+    else:
+        sd[f"{tp}.{p}.final_layer_norm.weight"][chans] = 64.0
+        sd[f"{tp}.{p}.final_layer_norm.bias"][chans] = mags
+        for i in range(p + 1, cfg.n_layers):
+            lp = f"{tp}.{i}"
+            if cfg.remaining_heads[i]:
+                for nm in ("q_proj", "k_proj", "v_proj"):
+                    sd[f"{lp}.attention.{nm}.weight"][:, chans] *= inv
+            sd[f"{lp}.feed_forward.intermediate_dense.weight"][:, chans] *= inv
+    for key in outlier_ln_sites(cfg):
+        w, b = sd[key + ".weight"], sd[key + ".bias"]
+        g_c = w[chans].clone()
+        w *= rms / float(ln_sigma.get(key, sigma))                   # typical channels: x / rms  ->  x / sigma_site
+        if cfg.layer_norm_first:
+            w[chans] = g_c * rms * inv                               # massive ones: M / rms  ->  O(sigma)
+        else:
+            w[chans] = rms                                            # +-M / rms  ->  +-M again
+            b[chans] = 0.0
+    sd["proj.weight"][:, chans] *= inv
+    return sd
+
+
+def outlier_state_dict(cfg: SegConfig, seed: int = 0, calibration=None) -> Dict[str, torch.Tensor]:
+    """turn-taking weights + planted massive activations; classifier from cal_<config>_outlier_seed<seed>.npz"""
+    import numpy as np
+    if calibration is None:
+        calibration = CAL_DIR / f"cal_{cfg.name}_outlier_seed{seed}.npz"
+    if not isinstance(calibration, dict):
+        if not __import__("os").path.exists(calibration):
+            raise FileNotFoundError(f"{calibration}: run `python oracle/calibrate.py --outlier` (build container) first")
+        calibration = dict(np.load(calibration))
+    ln_sigma = dict(zip(outlier_ln_sites(cfg), np.asarray(calibration["ln_sigma"], dtype=np.float64).tolist()))
+    sd = plant_outliers(turn_taking_head(seg_state_dict(cfg, seed), cfg, seed), cfg, seed, ln_sigma)
+    sd["classifier.weight"] = torch.as_tensor(np.asarray(calibration["W"], dtype=np.float32)).contiguous()
+    sd["classifier.bias"] = torch.as_tensor(np.asarray(calibration["b"], dtype=np.float32)).contiguous()
+    return sd
+
+
+def emb_outlier_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """`emb_state_dict` with planted BatchNorm outliers: two channels of the 32-plane stream (from layer1.0 on: the fused
+    BasicBlock kernels) and two of the 128-plane stream (from layer3.0 on: the generic contractions over NHWC images) sit 2^10 x
+    above the typical activation to the end of their stage (identity shortcuts carry them), with a token-varying part 2^5 x
+    typical; every convolution that reads them has its input-channel slice / 2^10, as a trained network's would be."""
+    sd = {k: v.clone() for k, v in emb_state_dict(seed).items()}
+    g = torch.Generator().manual_seed(9100 + seed)
+
+    def plant(block, planes, typical, readers):
+        ch = torch.randperm(planes, generator=g)[:2]
+        sd[f"resnet.{block}.bn2.weight"][ch] *= 32.0
+        sd[f"resnet.{block}.bn2.bias"][ch] = torch.tensor([1.0, 1.5]) * typical * 1024.0
+        for r in readers:
+            sd[f"resnet.{r}.weight"][:, ch] /= 1024.0
+        return ch
+
+    plant("layer1.0", 32, 2.0, ["layer1.1.conv1", "layer1.2.conv1", "layer2.0.conv1", "layer2.0.shortcut.0"])
+    plant("layer3.0", 128, 32.0, [f"layer3.{j}.conv1" for j in range(1, 6)] + ["layer4.0.conv1", "layer4.0.shortcut.0"])
+    return sd

@@ -114,6 +114,37 @@ def test_embedding_16s_window_and_masks_kernel(built_lib, gpu):
     assert rel < 1e-4
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32s", "f32h", "f16"])
+def test_embedding_planted_batchnorm_outliers(built_lib, gpu, precision):
+    """The reference ResNet34 with PLANTED BatchNorm outliers (testkit/weights.py:emb_outlier_state_dict; golden
+    emb_resnet_outlier.npz from oracle/gen_golden.py:gen_emb_outlier): two channels of the 32-plane stream (the fused BasicBlock
+    kernels, whose intermediate is split under an a-priori |max| bound) and two of the 128-plane stream (generic contractions) sit
+    2^10 x above the typical activation to the end of their stage.  fp32 modes: rel 1e-4 + cosine 0.9999 (the bar of the plain
+    golden); reduced mode: cosine 0.999."""
+    from diarizen_amd.configs import RESNET34, get_seg_config
+    from diarizen_amd.engine import Engine
+    from oracle import seg_model
+    from oracle.gen_golden import synth_wave
+    from testkit.weights import emb_outlier_state_dict
+    g = np.load(os.path.join(GOLD, "emb_resnet_outlier.npz"))
+    B, N = int(g["B"]), int(g["N"])
+    cfg = get_seg_config("tiny_ln")
+    esd = emb_outlier_state_dict(int(g["weight_seed"]))
+    eng = Engine(cfg, seg_model.seg_state_dict(cfg, 0), RESNET34, esd, max_batch=B, max_samples=N, precision=precision, device=gpu)
+    emb = eng.embed(synth_wave(B, N, int(g["wave_seed"])).to(gpu), torch.from_numpy(g["masks"]).to(gpu))
+    torch.cuda.synchronize()
+    emb = emb.cpu()
+    ref = torch.from_numpy(g["emb"])
+    rel = (emb - ref).abs().max().item() / ref.abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(emb.reshape(-1, 256), ref.reshape(-1, 256), dim=-1).min().item()
+    print(f"[emb outlier {precision}] rel err {rel:.2e} min cosine {cos:.7f} (reference fp32 vs float64: {float(g['ref_fp32_vs_fp64_rel']):.1e})")
+    if precision == "f16":
+        assert cos > 0.999
+    else:
+        assert rel < 1e-4 and cos > 0.9999
+    assert torch.equal(emb[0, 2], esd["resnet.seg_1.bias"])
+
+
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
 def test_embedding_reduced_precision_engines(built_lib, gpu, precision):
     """bf16 engine mode (bf16 ResNet images / operands, fp32 accumulate, fbank + pooling + seg_1 fp32) and f16 mode

@@ -254,6 +254,12 @@ def _worker(rank, world, port, C, out_dir):
         raised = False
     except RuntimeError:
         raised = True
+    # the same exchange without the recording's window count (counts exchanged first), straight to the host, with a row size
+    # that is not a multiple of 4 bytes (u8 [c, 5, 3]) and without embeddings
+    hs, he = dz.gather_windows(seg[:, :, :3].contiguous(), emb, to_host=True)
+    assert torch.equal(hs, gs[:, :, :3]) and torch.equal(he, ge)
+    only, none = dz.gather_windows(seg, None, expected_total=C)
+    assert none is None and torch.equal(only, gs)
     torch.save((gs, ge, raised), os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -272,7 +278,7 @@ def test_window_sharding_and_gather_gloo_world2(C, tmp_path):
     for r in range(2):
         gs, ge, raised = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
         assert raised                                           # the short block of rank 0 was refused on both ranks
-        assert gs.shape == (C, 5, 4) and ge.shape == (C, 4, 8)
+        assert gs.shape == (C, 5, 4) and ge.shape == (C, 4, 8) and gs.dtype == torch.uint8 and ge.dtype == torch.float32
         assert torch.equal(ge[:, 0, 0], torch.arange(C, dtype=torch.float32))   # window order kept
         assert torch.equal(gs[:, 0, 0].long(), torch.arange(C) % 251)
 

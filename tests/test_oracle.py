@@ -159,6 +159,56 @@ def test_seg_oracle_matches_reference_modules_turn_taking(name):
     assert np.array_equal(logp.numpy().argmax(-1), g["logp"].argmax(-1))
 
 
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
+def test_seg_oracle_matches_reference_modules_planted_outliers(name):
+    """(r6) the planted-massive-activation goldens: the oracle restatement reproduces the reference modules' logp and argmax,
+    the weights rebuilt here from the committed calibration table equal what the generator used (the last layer's massive
+    channels are compared), and the fixture is what it says: massive / typical >= 256 at the LAST layer, >= 5 classes."""
+    from diarizen_amd.configs import get_seg_config
+    from testkit.weights import outlier_state_dict
+    from oracle import seg_model
+    from oracle.gen_golden import tt_windows
+    cfg = get_seg_config(name)
+    g = np.load(os.path.join(GOLD, f"seg_outlier_{name}.npz"))
+    assert len(np.unique(g["logp"].argmax(-1))) >= 5 and float(g["massive_over_typical"]) >= 256
+    assert float(g["ref_fp32_vs_fp64"]) <= 3e-4
+    sd = outlier_state_dict(cfg, int(g["weight_seed"]))
+    wave = tt_windows(g["starts"].tolist(), int(g["N"]))[:4]
+    taps = {}
+    logp = seg_model.seg_forward(sd, cfg, wave, taps)
+    n = logp.shape[0]
+    assert np.abs(logp.numpy() - g["logp"][:n]).max() < 5e-4
+    assert np.array_equal(logp.numpy().argmax(-1), g["logp"][:n].argmax(-1))
+    last = taps[f"layer{cfg.n_layers - 1}"].numpy()[..., g["chans"]]
+    assert np.abs(last - g["rep_last_outlier"][:n]).max() <= 1e-5 * np.abs(g["rep_last_outlier"]).max()
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
+def test_seg_oracle_matches_reference_modules_loudness_extremes(name):
+    """(r6) as recorded / x 1e-4 / clipped / digital silence in one batch: finite, and the oracle equals the reference modules"""
+    from diarizen_amd.configs import get_seg_config
+    from testkit.weights import turn_taking_state_dict
+    from oracle import seg_model
+    from oracle.gen_golden import loud_windows
+    cfg = get_seg_config(name)
+    g = np.load(os.path.join(GOLD, f"seg_loud_{name}.npz"))
+    assert np.isfinite(g["logp"]).all()
+    logp = seg_model.seg_forward(turn_taking_state_dict(cfg, int(g["weight_seed"])), cfg, loud_windows(int(g["N"]), int(g["start"])))
+    assert np.abs(logp.numpy() - g["logp"]).max() < 5e-4
+    assert np.array_equal(logp.numpy().argmax(-1), g["logp"].argmax(-1))
+
+
+def test_emb_oracle_matches_reference_resnet_planted_outliers():
+    from oracle import emb_model
+    from oracle.gen_golden import synth_wave
+    from testkit.weights import emb_outlier_state_dict
+    g = np.load(os.path.join(GOLD, "emb_resnet_outlier.npz"))
+    sd = emb_outlier_state_dict(int(g["weight_seed"]))
+    emb = emb_model.emb_forward(sd, synth_wave(int(g["B"]), int(g["N"]), int(g["wave_seed"])), torch.from_numpy(g["masks"]))
+    assert np.abs(emb.numpy() - g["emb"]).max() < 1e-5 * np.abs(g["emb"]).max()
+    assert float(g["ref_fp32_vs_fp64_rel"]) < 2e-5
+
+
 # ---------------------------------------------------------------- architecture tables: product vs the reference-derived oracle table
 @pytest.mark.parametrize("name", ["wavlm_base", "wavlm_large", "wavlm_base_s80_md", "wavlm_large_s80_md", "tiny_ln", "tiny_gn"])
 def test_product_config_table_equals_reference_derived_table(name):

@@ -112,6 +112,115 @@ def test_seg_fp32_matches_reference_golden_turn_taking(built_lib, gpu, name, pre
     assert torch.equal(ml, seg_model.to_multilabel(ref, cfg).to(torch.uint8))
 
 
+def _outlier_case(name, gpu, precision):
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from testkit.weights import outlier_state_dict
+    from oracle.gen_golden import tt_windows
+    cfg = get_seg_config(name)
+    g = np.load(os.path.join(GOLD, f"seg_outlier_{name}.npz"))
+    wave = tt_windows(g["starts"].tolist(), int(g["N"]))
+    os.environ["DZN_DEBUG_TAPS"] = "1"
+    try:
+        eng = Engine(cfg, outlier_state_dict(cfg, int(g["weight_seed"])), max_batch=wave.shape[0], max_samples=int(g["N"]),
+                     precision=precision, device=gpu)
+    finally:
+        os.environ.pop("DZN_DEBUG_TAPS", None)
+    logp, ml = eng.segment(wave.to(gpu))
+    torch.cuda.synchronize()
+    return cfg, g, eng, logp.cpu(), ml.cpu()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32s", "f32h"])
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
+def test_seg_fp32_matches_reference_golden_planted_outliers(built_lib, gpu, name, precision):
+    """Reference-made goldens with PLANTED MASSIVE ACTIVATIONS (testkit/weights.py:outlier_state_dict): four
+    residual-stream channels 2^10 ... 2^13 x the typical magnitude from encoder layer 2 to the last layer and in the layer sum
+    (pre-norm large: W2V/components.py:920-935 via `output_dense` :805-813; post-norm base: every LayerNorm re-emits them), as
+    trained WavLM checkpoints have them.  What they meet here: the per-window power-of-two operand scales of the f32h / f32s
+    splits (typical elements sit 2^10 ... 2^13 below the window |max|), the folded-LayerNorm epilogue (rstd * (x W' - mean
+    colsum): the row mean is 2-3 sigma, the rstd 2^-9), the row statistics, the deferred layer sum and `proj`.  STRICT bar: max
+    |dlogp| <= 1e-3, every argmax and u8 decision identical.  The reference's own fp32-vs-float64 distance on the fixture is
+    stored in it (2e-4): the bar leaves 5 x that."""
+    from oracle import seg_model
+    cfg, g, eng, logp, ml = _outlier_case(name, gpu, precision)
+    ref = torch.from_numpy(g["logp"])
+    assert float(g["massive_over_typical"]) >= 256 and len(torch.unique(ref.argmax(-1))) >= 5
+    # the engine's last encoder layer really carries the massive channels (the fixture is not silently defused on the way in)
+    last = eng.debug_fetch(f"layer{cfg.n_layers - 1}").reshape(ref.shape[0], ref.shape[1], cfg.embed_dim)
+    got_out = last[..., g["chans"]]
+    assert np.abs(got_out - g["rep_last_outlier"]).max() <= 2e-4 * np.abs(g["rep_last_outlier"]).max()
+    err = (logp - ref).abs().max().item()
+    err64 = (logp.double() - torch.from_numpy(g["logp64"])).abs().max().item()
+    print(f"[outlier {name} {precision}] max|dlogp| vs the reference fp32 {err:.2e}, vs its float64 run {err64:.2e} "
+          f"(reference fp32 vs float64: {float(g['ref_fp32_vs_fp64']):.2e}); massive / typical = {float(g['massive_over_typical']):.0f}")
+    assert err <= 1e-3
+    assert torch.equal(logp.argmax(-1), ref.argmax(-1))
+    assert torch.equal(ml, seg_model.to_multilabel(ref, cfg).to(torch.uint8))
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
+def test_seg_f16_planted_outliers_meet_the_reduced_bar(built_lib, gpu, name):
+    """The reduced mode (fp16 hi*hi + fp8 cross terms, csrc/gemm_mx.hip) on the planted-outlier goldens: its fp8 operands share ONE
+    power-of-two scale per window / weight row, so typical elements sit 10-13 binades under the |max| that sets it - e4m3 spans
+    17.  Reduced bar of SURVEY 8d: max |dlogp| <= 5e-2, argmax >= 99.5 %."""
+    import json
+    cfg, g, eng, logp, ml = _outlier_case(name, gpu, "f16")
+    ref = torch.from_numpy(g["logp"])
+    err = (logp - ref).abs().max().item()
+    agree = (logp.argmax(-1) == ref.argmax(-1)).float().mean().item()
+    rec = {"fixture": f"seg_outlier_{name}", "frames": int(ref.shape[0] * ref.shape[1]), "max_abs_dlogp": err,
+           "argmax_agreement": agree, "massive_over_typical": float(g["massive_over_typical"])}
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = "gpurun_out/f16_outlier_bar.json"
+    allrec = json.load(open(path)) if os.path.exists(path) else {}
+    allrec[name] = rec
+    json.dump(allrec, open(path, "w"), indent=1)
+    print(json.dumps(rec))
+    top2 = ref.topk(2, dim=-1).values
+    flipped = logp.argmax(-1) != ref.argmax(-1)
+    near_tie = (not flipped.any()) or float((top2[..., 0] - top2[..., 1])[flipped].max()) <= 2 * err
+    assert err <= 5e-2 and (agree >= 0.995 or (ref.shape[0] * ref.shape[1] < 200 and near_tie)), rec
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32s", "f32h", "f16"])
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_gn", "wavlm_large_s80_md", "wavlm_base_s80_md"])
+def test_seg_loudness_extremes_in_one_batch(built_lib, gpu, name, precision):
+    """One batch of four windows: as recorded, near-silent (x 1e-4: under the eps of the waveform LayerNorm and of conv0's
+    channel norm), clipped (x 8 clamped to +-1) and DIGITAL SILENCE (all zeros: every |max| tracker of the window reads 0).
+    Reference-made golden (oracle/gen_golden.py:gen_seg_loud).  Every operand scale is per window, so (a) each window meets its
+    bar next to the others and (b) a window's bits do not depend on its neighbours: the batch equals four single-window calls."""
+    from diarizen_amd.configs import get_seg_config
+    from diarizen_amd.engine import Engine
+    from testkit.weights import turn_taking_state_dict
+    from oracle import seg_model
+    from oracle.gen_golden import loud_windows
+    cfg = get_seg_config(name)
+    g = np.load(os.path.join(GOLD, f"seg_loud_{name}.npz"))
+    ref = torch.from_numpy(g["logp"])
+    wave = loud_windows(int(g["N"]), int(g["start"]))
+    eng = Engine(cfg, turn_taking_state_dict(cfg, int(g["weight_seed"])), max_batch=4, max_samples=int(g["N"]),
+                 precision=precision, device=gpu)
+    logp, ml = eng.segment(wave.to(gpu))
+    torch.cuda.synchronize()
+    logp, ml = logp.cpu().clone(), ml.cpu().clone()
+    assert torch.isfinite(logp).all()
+    errs = [(logp[b] - ref[b]).abs().max().item() for b in range(4)]
+    print(f"[loud {name} {precision}] max|dlogp| as recorded / x1e-4 / clipped / zeros: " + " ".join(f"{e:.2e}" for e in errs))
+    if precision == "f16":
+        assert max(errs) <= 5e-2
+        agree = (logp.argmax(-1) == ref.argmax(-1)).float().mean().item()
+        assert agree >= 0.995 or ref.shape[1] < 50
+    else:
+        assert max(errs) <= 1e-3
+        assert torch.equal(logp.argmax(-1), ref.argmax(-1))
+        assert torch.equal(ml, seg_model.to_multilabel(ref, cfg).to(torch.uint8))
+    for b in range(4):
+        one, one_ml = eng.segment(wave[b:b + 1].to(gpu))
+        torch.cuda.synchronize()
+        assert torch.equal(one.cpu()[0], logp[b]) and torch.equal(one_ml.cpu()[0], ml[b]), f"window {b} depends on its neighbours"
+
+
 @pytest.mark.parametrize("name", ["tiny_ln", "wavlm_large_s80_md"])
 def test_seg_bf16_within_tolerance(built_lib, gpu, name):
     from conftest import needs_bf16_mode
