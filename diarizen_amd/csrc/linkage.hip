@@ -529,6 +529,310 @@ __global__ __launch_bounds__(LB_BLK) void step_kernel(double* __restrict__ D, in
   if (in && sz_dirty) size[z] = my_sz;
 }
 
+// ---- r6: the step loop with TWO remembered neighbours per row ----------------------------------------------------------
+// In step_kernel's loop 1.9-2.2 of every 3 launches are RESCANS: a merge retires the remembered neighbour of every row that
+// pointed at `lo` or `hi`, those rows are the likeliest next winners, and each of them costs a whole launch (a row scan spread
+// over the chip) before it can merge.  step2_kernel keeps the TWO nearest neighbours of every row:
+//   I1: l1 <= D[z][c] for every active c != z;          e1: D[z][n1] == l1 (the exact minimum)
+//   I2: l2 <= D[z][c] for every active c not in {z, n1}; e2: D[z][n2] == l2 (the exact second minimum, given e1)
+// When a merge retires n1, the row's new minimum is min(new distance to the union, l2) and it is EXACT whenever e2 held (or the
+// new distance undercuts the bound): the row merges without a rescan; the second slot then only keeps its bound (e2 = 0) until
+// the next scan of the row refills both.  A numpy model of the rules is checked against scipy on the CPU
+// (tests/test_design_math.py::test_linkage_top2_model_equals_scipy); on the 4 h recording's 20 888 embeddings the loop needs
+// 1.1-1.3 launches per merge instead of 2.9 (profiles/r6_linkage_top2.txt).  Same structure otherwise: one launch per step,
+// every workgroup reduces the same published records, state double-buffered by launch parity, single-owner words fixed up by
+// the owner at the start of the next launch.  The partial results of a row scan are top-2 pairs.
+struct StepPart2 {    // per workgroup: the two smallest of its slice of a row (the merged row / the rescanned row)
+  double v1, v2;
+  int i1, i2;
+};
+
+__device__ __forceinline__ bool pair_lt(double a, int ai, double b, int bi) { return a < b || (a == b && ai < bi); }
+
+// (v1, i1, v2, i2) <- the two smallest of {v1, v2, b1, b2} by (value, index); both inputs sorted, their elements distinct.
+// Written as selects on values: the branchy form (assignments through references) was lowered to indexed SCRATCH stores -
+// 64 B per lane of private memory and a memory round trip per merge, 10.8 us per launch where this form has 6.x.
+__device__ __forceinline__ void top2_merge(double& v1, int& i1, double& v2, int& i2, double b1, int bi1, double b2, int bi2) {
+  const double a1 = v1, a2 = v2;
+  const int ai1 = i1, ai2 = i2;
+  const bool bf = pair_lt(b1, bi1, a1, ai1);              // b's first is the overall first
+  const double c1 = bf ? a1 : b1, c2 = bf ? b2 : a2;      // the two candidates for the second place
+  const int ci1 = bf ? ai1 : bi1, ci2 = bf ? bi2 : ai2;
+  const bool cs = pair_lt(c1, ci1, c2, ci2);
+  v1 = bf ? b1 : a1;
+  i1 = bf ? bi1 : ai1;
+  v2 = cs ? c1 : c2;
+  i2 = cs ? ci1 : ci2;
+}
+
+// Cross-lane moves of the wave reductions below as DPP controls (VALU data path, a few cycles) instead of `__shfl_xor`, which
+// hipcc lowers to ds_bpermute_b32 (a round trip through the LDS crossbar per dword and stage: 108 of them chained in twelve
+// dependent stages were ~1 us of every launch of a latency-bound kernel).  quad_perm [1,0,3,2] / [2,3,0,1], row_ror:4 / :8 give
+// every lane of a 16-lane row the row's result (each stage joins DISJOINT lane sets, which top2_merge requires); row_bcast:15
+// (into rows 1, 3) and row_bcast:31 (into rows 2, 3) carry it across rows - lanes outside the row mask receive `idle`, the
+// identity of the reduction - and lane 63 ends up with the wave's result, read back with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int idle, int v) {
+  return __builtin_amdgcn_update_dpp(idle, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double idle, double v) {
+  const int lo = dpp_i<CTRL, ROW_MASK>(__double2loint(idle), __double2loint(v));
+  const int hi = dpp_i<CTRL, ROW_MASK>(__double2hiint(idle), __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane63_d(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void top2_min_stage(double& a1, int& ai1, double& a2, int& ai2, double& m, int& mi) {
+  const double b1 = dpp_d<CTRL, ROW_MASK>(DINF, a1), b2 = dpp_d<CTRL, ROW_MASK>(DINF, a2), bm = dpp_d<CTRL, ROW_MASK>(DINF, m);
+  const int bi1 = dpp_i<CTRL, ROW_MASK>(0x7fffffff, ai1), bi2 = dpp_i<CTRL, ROW_MASK>(0x7fffffff, ai2),
+            bmi = dpp_i<CTRL, ROW_MASK>(0x7fffffff, mi);
+  top2_merge(a1, ai1, a2, ai2, b1, bi1, b2, bi2);
+  if (pair_lt(bm, bmi, m, mi)) { m = bm; mi = bmi; }
+}
+
+// block-wide: the top-2 of per-thread sorted pairs (a1, ai1, a2, ai2) AND the minimum of per-thread (m, mi); valid in every
+// thread.  sval: 12 doubles, sidx: 12 ints.
+__device__ __forceinline__ void block_top2_min(double a1, int ai1, double a2, int ai2, double m, int mi, double& o1, int& oi1,
+                                               double& o2, int& oi2, double& om, int& omi, double* sval, int* sidx) {
+  top2_min_stage<0xB1, 0xf>(a1, ai1, a2, ai2, m, mi);      // quad_perm [1,0,3,2]
+  top2_min_stage<0x4E, 0xf>(a1, ai1, a2, ai2, m, mi);      // quad_perm [2,3,0,1]
+  top2_min_stage<0x124, 0xf>(a1, ai1, a2, ai2, m, mi);     // row_ror:4
+  top2_min_stage<0x128, 0xf>(a1, ai1, a2, ai2, m, mi);     // row_ror:8
+  top2_min_stage<0x142, 0xa>(a1, ai1, a2, ai2, m, mi);     // row_bcast:15 -> rows 1, 3
+  top2_min_stage<0x143, 0xc>(a1, ai1, a2, ai2, m, mi);     // row_bcast:31 -> rows 2, 3
+  a1 = readlane63_d(a1); a2 = readlane63_d(a2); m = readlane63_d(m);
+  ai1 = __builtin_amdgcn_readlane(ai1, 63); ai2 = __builtin_amdgcn_readlane(ai2, 63); mi = __builtin_amdgcn_readlane(mi, 63);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;   // nw <= 4
+  __syncthreads();
+  if (lane == 0) {
+    sval[wave] = a1; sval[4 + wave] = a2; sval[8 + wave] = m;
+    sidx[wave] = ai1; sidx[4 + wave] = ai2; sidx[8 + wave] = mi;
+  }
+  __syncthreads();
+  a1 = sval[0]; a2 = sval[4]; m = sval[8];
+  ai1 = sidx[0]; ai2 = sidx[4]; mi = sidx[8];
+  for (int w = 1; w < nw; ++w) {
+    top2_merge(a1, ai1, a2, ai2, sval[w], sidx[w], sval[4 + w], sidx[4 + w]);
+    if (pair_lt(sval[8 + w], sidx[8 + w], m, mi)) { m = sval[8 + w]; mi = sidx[8 + w]; }
+  }
+  o1 = a1; oi1 = ai1; o2 = a2; oi2 = ai2; om = m; omi = mi;
+}
+
+// initial state: the exact two nearest neighbours of every row (one workgroup per row) — the diagonal holds +inf
+__global__ __launch_bounds__(256) void init_rows2_kernel(const double* __restrict__ D, int n, double* __restrict__ l1a,
+                                                         double* __restrict__ l2a, int* __restrict__ n1a,
+                                                         int* __restrict__ n2a, int* __restrict__ fla) {
+  __shared__ double sval[12];
+  __shared__ int sidx[12];
+  const int z = blockIdx.x;
+  const double* p = D + (int64_t)z * n;
+  double v1 = DINF, v2 = DINF;
+  int i1 = 0x7fffffff, i2 = 0x7fffffff;
+  for (int i0 = threadIdx.x; i0 < n; i0 += SCAN_U * blockDim.x) {
+    double xs[SCAN_U];
+#pragma unroll
+    for (int u = 0; u < SCAN_U; ++u) {
+      const int i = i0 + u * blockDim.x;
+      xs[u] = i < n ? p[i] : DINF;
+    }
+#pragma unroll
+    for (int u = 0; u < SCAN_U; ++u) {
+      const int i = i0 + u * blockDim.x;     // ascending per thread: strict comparisons keep the first occurrence
+      if (xs[u] < v1) { v2 = v1; i2 = i1; v1 = xs[u]; i1 = i; }
+      else if (xs[u] < v2) { v2 = xs[u]; i2 = i; }
+    }
+  }
+  double o1, o2, om;
+  int oi1, oi2, omi;
+  block_top2_min(v1, i1, v2, i2, DINF, 0x7fffffff, o1, oi1, o2, oi2, om, omi, sval, sidx);
+  if (threadIdx.x == 0) {
+    const bool h1 = o1 < DINF, h2 = o2 < DINF;
+    l1a[z] = o1; l2a[z] = o2; n1a[z] = h1 ? oi1 : -1; n2a[z] = h2 ? oi2 : -1; fla[z] = (h1 ? 1 : 0) | (h2 ? 2 : 0);
+  }
+}
+
+__global__ __launch_bounds__(LB_BLK) void init_rec2_kernel(int n, const double* __restrict__ l1a, const int* __restrict__ n1a,
+                                                           StepRec* __restrict__ rec) {
+  __shared__ double sval[4];
+  __shared__ int sidx[4];
+  const int z = blockIdx.x * LB_BLK + threadIdx.x;
+  double v;
+  int x;
+  block_min_pair(z < n ? l1a[z] : DINF, z < n ? z : 0x7fffffff, v, x, sval, sidx);
+  if (z == x) {
+    StepRec r;
+    r.v = v; r.x = x; r.y = n1a[x]; r.exact = r.y >= 0; r.pad = 0;
+    rec[blockIdx.x] = r;
+  }
+}
+
+__global__ __launch_bounds__(LB_BLK) void step2_kernel(double* __restrict__ D, int n, double* __restrict__ l1a,
+                                                       double* __restrict__ l2a, int* __restrict__ n1a, int* __restrict__ n2a,
+                                                       int* __restrict__ fla, int* __restrict__ size, int* __restrict__ cid,
+                                                       double* __restrict__ Z, StepState* __restrict__ st2,
+                                                       StepRec* __restrict__ rec2, StepPart2* __restrict__ part2, int parity) {
+  __shared__ double sval[12];
+  __shared__ int sidx[12];
+  __shared__ int sy[2];
+  const int G = gridDim.x, w = blockIdx.x, t = threadIdx.x;
+  const int z = w * LB_BLK + t;
+  const bool in = z < n;
+  const StepRec* rec = rec2 + (int64_t)parity * G;
+  StepRec* rec_out = rec2 + (int64_t)(parity ^ 1) * G;
+  const StepPart2* part = part2 + (int64_t)parity * G;
+  StepPart2* part_out = part2 + (int64_t)(parity ^ 1) * G;
+  StepState* st_out = st2 + (parity ^ 1);
+  // ---- (1) everything that does not depend on the decision: ONE round trip ----
+  const StepState prev = st2[parity];
+  StepRec r0;
+  r0.v = DINF; r0.x = 0x7fffffff; r0.y = -1; r0.exact = 0;
+  StepPart2 p0;
+  p0.v1 = p0.v2 = DINF; p0.i1 = p0.i2 = 0x7fffffff;
+  if (t < G) { r0 = rec[t]; p0 = part[t]; }
+  double my_l1 = in ? l1a[z] : DINF, my_l2 = in ? l2a[z] : DINF;
+  int my_n1 = in ? n1a[z] : -1, my_n2 = in ? n2a[z] : -1, my_fl = in ? fla[z] : 0;
+  int my_sz = in ? size[z] : 0;
+  if (prev.kind == STEP_DONE || prev.kind == STEP_FAIL) {   // surplus launch: keep both copies of the descriptor final
+    if (w == 0 && t == 0) *st_out = prev;
+    return;
+  }
+  const bool owed = prev.kind == STEP_MERGE || prev.kind == STEP_RESCAN;
+  // ---- (2) the two neighbours owed to the row of the previous step + the winner over the records ----
+  double a1 = owed ? p0.v1 : DINF, a2 = owed ? p0.v2 : DINF, uv = r0.v;
+  int ai1 = owed ? p0.i1 : 0x7fffffff, ai2 = owed ? p0.i2 : 0x7fffffff, ui = r0.x;
+  for (int i = t + LB_BLK; i < G; i += LB_BLK) {            // n > 65 536 only
+    const StepRec r = rec[i];
+    const StepPart2 p = part[i];
+    if (owed) top2_merge(a1, ai1, a2, ai2, p.v1, p.i1, p.v2, p.i2);
+    if (pair_lt(r.v, r.x, uv, ui)) { uv = r.v; ui = r.x; }
+  }
+  double ev1, ev2, d;
+  int eid1, eid2, x;
+  block_top2_min(a1, ai1, a2, ai2, uv, ui, ev1, eid1, ev2, eid2, d, x, sval, sidx);
+  const int ex = !owed ? 0x7fffffff : prev.kind == STEP_MERGE ? prev.hi : prev.x;   // the row left out of the records
+  const int ey = ev1 < DINF ? eid1 : -1;
+  bool dirty = false, sz_dirty = false;
+  if (owed && z == ex) {
+    my_l1 = ev1; my_n1 = ey; my_l2 = ev2; my_n2 = ev2 < DINF ? eid2 : -1;
+    my_fl = (my_n1 >= 0 ? 1 : 0) | (my_n2 >= 0 ? 2 : 0);
+    dirty = true;
+  }
+  if (prev.kind == STEP_MERGE) {
+    if (z == prev.hi) { my_sz = prev.nlo + prev.nhi; cid[z] = n + prev.k - 1; sz_dirty = true; }
+    if (z == prev.lo) { my_sz = 0; sz_dirty = true; }
+  }
+  const int k = prev.k;
+  int y;
+  bool exact;
+  const bool extra_wins = owed && pair_lt(ev1, ex, d, x);
+  if (extra_wins) {
+    d = ev1; x = ex; y = ey; exact = ey >= 0;
+  } else {
+    __syncthreads();
+    if (t < G && r0.x == x && r0.v == d) { sy[0] = r0.y; sy[1] = r0.exact; }
+    for (int i = t + LB_BLK; i < G; i += LB_BLK)
+      if (rec[i].x == x && rec[i].v == d) { sy[0] = rec[i].y; sy[1] = rec[i].exact; }
+    __syncthreads();
+    y = sy[0];
+    exact = sy[1] != 0 && y >= 0;
+  }
+  if (!(d < DINF) || x < 0 || x >= n) {    // NaN / inf distances: no pair left to merge
+    if (w == 0 && t == 0) { StepState s = prev; s.kind = STEP_FAIL; *st_out = s; }
+    return;
+  }
+  double pv = DINF;       // this thread's element of the row whose two smallest the step publishes
+  int excl = -1;          // row left out of this step's records
+  if (!exact) {
+    // ---- RESCAN: this workgroup's slice of row x over the active columns (D[x][x] is +inf) ----
+    if (w == 0 && t == 0) {
+      StepState s = prev;
+      s.kind = STEP_RESCAN; s.x = x; s.k = k; s.pad = prev.pad + 1;   // pad counts the rescans (diagnostics)
+      *st_out = s;
+    }
+    if (in && my_sz != 0) pv = D[(int64_t)x * n + z];
+    excl = x;
+  } else {
+    // ---- MERGE: Lance-Williams update of this workgroup's columns ----
+    const int lo = x < y ? x : y, hi = x < y ? y : x;
+    const bool sub = prev.kind == STEP_MERGE;    // words of the previous pair are being rewritten by their owners
+    const int nlo = sub && lo == prev.hi ? prev.nlo + prev.nhi : size[lo];   // (lo / hi are active: never prev.lo)
+    const int nhi = sub && hi == prev.hi ? prev.nlo + prev.nhi : size[hi];
+    if (w == 0 && t == 0) {
+      const int ia = sub && lo == prev.hi ? n + prev.k - 1 : cid[lo];
+      const int ib = sub && hi == prev.hi ? n + prev.k - 1 : cid[hi];
+      Z[4 * k + 0] = (double)(ia < ib ? ia : ib);
+      Z[4 * k + 1] = (double)(ia < ib ? ib : ia);
+      Z[4 * k + 2] = d;
+      Z[4 * k + 3] = (double)(nlo + nhi);
+      StepState s;
+      s.kind = k + 1 >= n - 1 ? STEP_DONE : STEP_MERGE;
+      s.lo = lo; s.hi = hi; s.nlo = nlo; s.nhi = nhi; s.k = k + 1; s.x = -1; s.pad = prev.pad; s.dist = d;
+      *st_out = s;
+    }
+    if (in) {
+      if (z == hi) {
+        D[(int64_t)hi * n + lo] = DINF;
+        my_l1 = my_l2 = DINF; my_n1 = my_n2 = -1; my_fl = 0; dirty = true;   // both neighbours at the start of the next launch
+      } else if (z == lo) {
+        my_l1 = my_l2 = DINF; my_fl = 0; dirty = true;                       // retired
+      } else if (my_sz != 0) {
+        const double dxi = D[(int64_t)lo * n + z], dyi = D[(int64_t)hi * n + z];
+        // scipy _hierarchy_distance_update.pxi, _centroid(d_xi, d_yi, d_xy, size_x, size_y, size_i), same order
+        const double v = sqrt((((nlo * dxi * dxi) + (nhi * dyi * dyi)) - (nlo * nhi * d * d) / (nlo + nhi)) / (nlo + nhi));
+        D[(int64_t)hi * n + z] = v;
+        D[(int64_t)z * n + hi] = v;              // column lo is NOT blanked: readers of a row mask by size[]
+        pv = v;
+        // columns lo and (old) hi leave the row, column hi re-enters with v: the rules of the header (I1 / I2 / e1 / e2)
+        const bool d1 = my_n1 == lo || my_n1 == hi, d2 = my_n2 == lo || my_n2 == hi;
+        const bool e1 = my_fl & 1, e2 = my_fl & 2;
+        if (!d1) {
+          if (v < my_l1) {                       // the union is the new nearest: exact whatever l1 was
+            my_l2 = my_l1; my_n2 = my_n1; my_fl = 1 | (e1 ? 2 : 0);
+            my_l1 = v; my_n1 = hi; dirty = true;
+          } else if (!d2) {
+            if (v < my_l2) { my_l2 = v; my_n2 = hi; my_fl |= 2; dirty = true; }
+          } else if (v <= my_l2) {               // second slot retired, everything else is >= l2 >= v
+            my_l2 = v; my_n2 = hi; my_fl |= 2; dirty = true;
+          } else {
+            my_n2 = hi; my_fl &= ~2; dirty = true;       // l2 stays a lower bound of the rest
+          }
+        } else {
+          dirty = true;
+          if (!d2 && e2) {                       // nearest retired, the exact second takes over unless the union undercuts it
+            if (v < my_l2) { my_l1 = v; my_n1 = hi; my_fl = 3; }
+            else { my_l1 = my_l2; my_n1 = my_n2; my_n2 = hi; my_fl = 1; }
+          } else {                               // only bounds left: exact iff the union is under the bound of the rest
+            if (v <= my_l2) { my_l1 = v; my_n1 = hi; my_fl = 1; }
+            else { my_l1 = my_l2; my_n1 = hi; my_fl = 0; }
+            if (d2) my_n2 = hi;
+          }
+        }
+      }
+    }
+  }
+  // ---- (4) publish: the two smallest of the new / rescanned row's slice, the record of this workgroup's rows ----
+  double b1, b2, rv;
+  int bi1, bi2, rx;
+  block_top2_min(pv, in ? z : 0x7fffffff, DINF, 0x7fffffff, (in && z != excl) ? my_l1 : DINF, in ? z : 0x7fffffff, b1, bi1, b2,
+                 bi2, rv, rx, sval, sidx);
+  if (t == 0) {
+    StepPart2 p;
+    p.v1 = b1; p.v2 = b2; p.i1 = bi1; p.i2 = bi2;
+    part_out[w] = p;
+  }
+  if (z == rx) {          // rx is always a row of this workgroup (every thread contributes its own index)
+    StepRec r;
+    r.v = rv; r.x = rx; r.y = rv < DINF ? my_n1 : -1; r.exact = rv < DINF && (my_fl & 1) != 0 && my_n1 >= 0; r.pad = 0;
+    rec_out[w] = r;
+  }
+  if (in && dirty) { l1a[z] = my_l1; l2a[z] = my_l2; n1a[z] = my_n1; n2a[z] = my_n2; fla[z] = my_fl; }
+  if (in && sz_dirty) size[z] = my_sz;
+}
+
 #define LCHK(call)                                   \
   do {                                               \
     if ((call) != hipSuccess) { rc = DZN_E_HIP; goto done; } \
@@ -681,8 +985,10 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   if (!h_emb || !h_Z || n < 2 || dim < 1) return DZN_E_INVALID;
   int rc = DZN_OK;
   const int nblk = (n + LB_BLK - 1) / LB_BLK;
-  // DZN_LINKAGE_TWO_KERNEL=1: the r2 loop (one single-workgroup selection + one wide update per merge), kept for A/B timing
+  // DZN_LINKAGE_TWO_KERNEL=1: the r2 loop (one single-workgroup selection + one wide update per merge), kept for A/B timing;
+  // DZN_LINKAGE_TOP1=1: r3-r5's step loop with ONE remembered neighbour per row (step_kernel) instead of r6's two
   const bool two_kernel = getenv("DZN_LINKAGE_TWO_KERNEL") != nullptr;
+  const bool top2 = !two_kernel && getenv("DZN_LINKAGE_TOP1") == nullptr;
   std::vector<int> ones(n, 1), ids(n);
   for (int i = 0; i < n; ++i) ids[i] = i;
   MergeState st0{};
@@ -697,6 +1003,9 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   StepState* st2 = nullptr;
   StepRec* rec2 = nullptr;
   StepPart* part2 = nullptr;
+  StepPart2* part22 = nullptr;
+  double* l2a = nullptr;
+  int* n2a = nullptr;
   auto carve = [&](char* base) {
     Carver c(base);
     D = c.take<double>((size_t)n * n);
@@ -715,6 +1024,9 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
     rec2 = c.take<StepRec>((size_t)2 * nblk);
     part2 = c.take<StepPart>((size_t)2 * nblk);
     exf = c.take<int>(n);
+    part22 = c.take<StepPart2>((size_t)2 * nblk);
+    l2a = c.take<double>(n);
+    n2a = c.take<int>(n);
     return c.off;
   };
   HostCtx* ctx = nullptr;
@@ -729,7 +1041,8 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   {
     const int tiles = (n + 63) / 64;
     hipLaunchKernelGGL(pdist_kernel, dim3(tiles, tiles), dim3(256), 0, s, E, n, dim, D);
-    hipLaunchKernelGGL(init_rows_kernel, dim3(n), dim3(256), 0, s, D, n, lb, nb);
+    if (top2) hipLaunchKernelGGL(init_rows2_kernel, dim3(n), dim3(256), 0, s, D, n, lb, l2a, nb, n2a, exf);
+    else hipLaunchKernelGGL(init_rows_kernel, dim3(n), dim3(256), 0, s, D, n, lb, nb);
     if (two_kernel) {
       hipLaunchKernelGGL(block_minima_kernel, dim3(nblk), dim3(LB_BLK), 0, s, lb, n, bmin, barg);
       for (int k = 0; k < n - 1; ++k) {
@@ -743,16 +1056,24 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
       // batches sized from the merges still missing and the step descriptor is read back between batches (surplus
       // launches after the last merge return at once)
       LCHK(hipMemsetAsync(st2, 0, 2 * sizeof(StepState), s));
-      hipLaunchKernelGGL(init_rec_kernel, dim3(nblk), dim3(LB_BLK), 0, s, n, lb, nb, exf, rec2);
+      if (top2) hipLaunchKernelGGL(init_rec2_kernel, dim3(nblk), dim3(LB_BLK), 0, s, n, lb, nb, rec2);
+      else hipLaunchKernelGGL(init_rec_kernel, dim3(nblk), dim3(LB_BLK), 0, s, n, lb, nb, exf, rec2);
       int64_t launched = 0;
       int remaining = n - 1;
       const auto t_loop = std::chrono::steady_clock::now();
       for (int round = 0; remaining > 0; ++round) {
         if (round > 64 + n) { rc = DZN_E_INVALID; goto done; }   // cannot happen: every batch completes >= 1 merge
-        const int batch = remaining + remaining / 2 + 32;
-        for (int i = 0; i < batch; ++i, ++launched)
-          hipLaunchKernelGGL(step_kernel, dim3(nblk), dim3(LB_BLK), 0, s, D, n, lb, nb, size, cid, exf, Z, st2, rec2, part2,
-                             (int)(launched & 1));
+        // surplus launches return at once but still cost a kernel boundary each: size the batch for the expected rescans
+        // (1.1-1.3 launches per merge with two remembered neighbours, 2-3 with one) and let the next round finish the rest
+        const int batch = top2 ? remaining + remaining / 8 + 32 : remaining + remaining / 2 + 32;
+        for (int i = 0; i < batch; ++i, ++launched) {
+          if (top2)
+            hipLaunchKernelGGL(step2_kernel, dim3(nblk), dim3(LB_BLK), 0, s, D, n, lb, l2a, nb, n2a, exf, size, cid, Z, st2,
+                               rec2, part22, (int)(launched & 1));
+          else
+            hipLaunchKernelGGL(step_kernel, dim3(nblk), dim3(LB_BLK), 0, s, D, n, lb, nb, size, cid, exf, Z, st2, rec2, part2,
+                               (int)(launched & 1));
+        }
         LCHK(hipGetLastError());
         StepState hs;
         LCHK(hipMemcpyAsync(&hs, st2 + (launched & 1), sizeof(StepState), hipMemcpyDeviceToHost, s));
@@ -760,8 +1081,8 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
         if (hs.kind == STEP_FAIL) { rc = DZN_E_INVALID; goto done; }   // non-finite distances
         remaining = hs.kind == STEP_DONE ? 0 : n - 1 - hs.k;
         if (remaining == 0 && getenv("DZN_LINKAGE_DEBUG"))
-          fprintf(stderr, "linkage: n %d, %lld launches in %d batches, %d rescans, loop %.1f ms\n", n, (long long)launched,
-                  round + 1, hs.pad, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count());
+          fprintf(stderr, "linkage[%s]: n %d, %lld launches in %d batches, %d rescans, loop %.1f ms\n",
+                  top2 ? "two neighbours" : "one neighbour", n, (long long)launched, round + 1, hs.pad, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count());
       }
     }
   }

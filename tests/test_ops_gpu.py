@@ -536,10 +536,14 @@ def test_linkage_step_loop_equals_two_kernel_loop(built_lib, gpu, monkeypatch):
         if n >= 255:
             e[7] = e[3]
             e[100] = e[3]
-        Za = ops.linkage_centroid(e)
+        Za = ops.linkage_centroid(e)                 # r6 default: the step loop with two remembered neighbours per row
         monkeypatch.setenv("DZN_LINKAGE_TWO_KERNEL", "1")
         Zb = ops.linkage_centroid(e)
         monkeypatch.delenv("DZN_LINKAGE_TWO_KERNEL")
+        monkeypatch.setenv("DZN_LINKAGE_TOP1", "1")  # r3-r5: the step loop with one remembered neighbour
+        Zc = ops.linkage_centroid(e)
+        monkeypatch.delenv("DZN_LINKAGE_TOP1")
+        assert np.array_equal(Zc, Zb), n
         assert np.array_equal(Za, Zb), n
 
 
