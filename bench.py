@@ -641,10 +641,25 @@ def self_launch(args, argv, one_device: bool) -> int:
     return subprocess.call(launcher_command(args, argv, port), env=env)
 
 
+def visible_device_ids():
+    """the physical device list this process tree may see, as HIP numbers it: HIP_VISIBLE_DEVICES (or ROCR_ / CUDA_) entries in
+    order - torch's `cuda:i` is entry i.  None = no restriction (cuda:i is physical device i)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return [t.strip() for t in v.split(",") if t.strip() != ""], var
+    return None, None
+
+
 def rendezvous_check(args, rank: int, world: int):
-    """launcher self-test (no GPU needed): the ranks `--gpus N` started form ONE gloo group of N, every rank contributes
-    to an all-reduce, rank 0 prints what came up."""
+    """`--rendezvous-check`: the N-rank job WITHOUT a GPU.  The ranks `--gpus N` started form
+    ONE gloo group of N and every rank contributes to an all-reduce; then the dry run of what the timed job does per rank:
+    rank -> `cuda:LOCAL_RANK` -> physical device under the HIP_VISIBLE_DEVICES permutation in force (must be N distinct
+    devices), the strong leg's window blocks and sample ranges of the 4 h recording (must tile it, halo included), and the
+    path's one exchange - the packed all-gather of diarizen_amd/dist.py with the partition check - on a stand-in payload whose
+    values are the global window indices.  Rank 0 prints what came up; a violated check is a non-zero exit on every rank."""
     import torch.distributed as dist
+    from diarizen_amd.dist import gather_windows, shard_range
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")          # only reached without a launcher at --gpus 1
     os.environ.setdefault("RANK", str(rank))
@@ -654,12 +669,44 @@ def rendezvous_check(args, rank: int, world: int):
         raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ids, var = visible_device_ids()
+    if ids is not None and local_rank >= len(ids):
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} has no entry in {var}={','.join(ids)}")
+    sr, window, step = 16000, int(args.window * 16000), int(round(0.1 * args.window * 16000))
+    total = int((args.strong_minutes if args.strong_minutes else 240.0) * 60 * sr)
+    c0, c1, s0, ns = shard_slice(total, window, step, rank, world)
+    mine = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "torch_device": f"cuda:{local_rank}",
+            "physical_device": ids[local_rank] if ids is not None else str(local_rank),
+            "windows": [c0, c1], "samples": [s0, s0 + ns]}
     ranks = [None] * world
-    dist.all_gather_object(ranks, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()})
+    dist.all_gather_object(ranks, mine)
+    C = ranks[-1]["windows"][1]
+    # the exchange on a stand-in payload: u8 decisions [c, 3, 4] and f32 embeddings [c, 4, 2] that carry the window index
+    idx = torch.arange(c0, c1)
+    seg = (idx % 251).to(torch.uint8).view(-1, 1, 1).expand(c1 - c0, 3, 4).contiguous()
+    emb = idx.to(torch.float32).view(-1, 1, 1).expand(c1 - c0, 4, 2).contiguous()
+    gs, ge = gather_windows(seg, emb, expected_total=C, to_host=True)
+    problems = []
+    phys = [r["physical_device"] for r in ranks]
+    if len(set(phys)) != world:
+        problems.append(f"ranks share a physical device: {phys}")
+    if [r["windows"] for r in ranks] != [list(shard_range(C, r, world)) for r in range(world)] or ranks[0]["windows"][0] != 0:
+        problems.append("window blocks are not the block partition of the recording")
+    for r in ranks:
+        w0, w1 = r["windows"]
+        if w1 > w0 and (r["samples"][0] != w0 * step or r["samples"][1] < min((w1 - 1) * step + window, total)):
+            problems.append(f"rank {r['rank']}: sample range {r['samples']} does not cover its windows {r['windows']}")
+    if not (torch.equal(ge[:, 0, 0], torch.arange(C, dtype=torch.float32)) and gs.shape == (C, 3, 4)):
+        problems.append("gathered payload is not in window order")
     if rank == 0:
-        print(json.dumps({"rendezvous": "ok", "n_gpus": world, "backend": "gloo", "sum_of_rank_ids": t.item(), "ranks": ranks}))
+        print(json.dumps({"rendezvous": "ok" if not problems else "FAILED", "n_gpus": world, "backend": "gloo",
+                          "sum_of_rank_ids": t.item(), "visible_devices_var": var, "ranks": ranks,
+                          "strong_leg_windows": C, "gathered_windows": int(gs.shape[0]), "problems": problems}))
     dist.barrier()
     dist.destroy_process_group()
+    if problems:
+        raise SystemExit("bench.py --rendezvous-check: " + "; ".join(problems))
 
 
 def main():

@@ -222,10 +222,23 @@ def load_flac(src: Union[str, bytes, BinaryIO, io.BytesIO], verify_md5: bool = T
     rc = lib.dzn_flac_info(buf, len(data), C.byref(sr), C.byref(ch), C.byref(bits), C.byref(total), md5)
     if rc != 0:
         raise ValueError("not a FLAC stream (or a malformed STREAMINFO block)")
-    cap = total.value if total.value > 0 else max(1, len(data) * 8)      # unknown length: no frame codes < 1 bit per sample pair
-    out = np.empty((cap, ch.value), dtype=np.int32)
+    # Output capacity.  A frame is at least 11 bytes (header 5 + one CONSTANT subframe + CRC-16) and carries at most 65535
+    # samples per channel, so a stream of len(data) bytes cannot hold more than `bound` samples: a STREAMINFO total beyond it
+    # is a lie (36-bit field: up to 2^36 samples = a multi-TB allocation before any frame is checked) and is refused.  A stream
+    # of unknown length (total 0: piped encoders) starts from 4 samples per byte and doubles on DZN_E_NOMEM up to the bound -
+    # digital silence codes 4096 samples in ~10 bytes, so a fixed guess would call a valid file corrupt.
+    bound = (len(data) // 11 + 1) * 65535
+    if total.value > bound:
+        raise ValueError(f"FLAC STREAMINFO claims {total.value} samples, a {len(data)}-byte stream holds at most {bound}")
+    cap = total.value if total.value > 0 else max(4096, len(data) * 4)
     done = C.c_int64()
-    rc = lib.dzn_flac_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), cap, C.byref(done))
+    while True:
+        out = np.empty((cap, ch.value), dtype=np.int32)
+        rc = lib.dzn_flac_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), cap, C.byref(done))
+        if rc == -2 and total.value == 0 and cap < bound:      # DZN_E_NOMEM (include/dzn.h): capacity too small
+            cap = min(cap * 2, bound)
+            continue
+        break
     if rc != 0:
         raise ValueError(f"FLAC decode failed (code {rc}): corrupt frame (CRC / syntax) or an unsupported stream")
     out = out[:done.value]

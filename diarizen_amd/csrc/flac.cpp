@@ -11,6 +11,8 @@
 //
 // C ABI (include/dzn.h):  dzn_flac_info  -> stream parameters;  dzn_flac_decode -> int32 samples, interleaved [samples][channels].
 #include <stdint.h>
+
+#include <vector>
 #include <string.h>
 
 #include "../../include/dzn.h"
@@ -96,17 +98,23 @@ uint8_t crc8(const uint8_t* d, size_t n) {
   return c;
 }
 
-uint16_t crc16(const uint8_t* d, size_t n) {
-  static uint16_t table[256];
-  static bool init = false;
-  if (!init) {
+struct Crc16Table {
+  uint16_t t[256];
+  Crc16Table() {
     for (int i = 0; i < 256; ++i) {
       uint16_t c = (uint16_t)(i << 8);
       for (int b = 0; b < 8; ++b) c = (uint16_t)((c & 0x8000) ? ((c << 1) ^ 0x8005) : (c << 1));
-      table[i] = c;
+      t[i] = c;
     }
-    init = true;
   }
+};
+
+uint16_t crc16(const uint8_t* d, size_t n) {
+  // function-local static: initialised exactly once under the language's guard - the loader thread of diarize_many and a
+  // caller's own load_flac may decode at the same time (ctypes releases the GIL); a hand-rolled `static bool init` could let
+  // the second thread read a half-written table and report a good frame as corrupt
+  static const Crc16Table table_obj;
+  const uint16_t* table = table_obj.t;
   uint16_t c = 0;
   for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ table[(c >> 8) ^ d[i]]);
   return c;
@@ -257,7 +265,17 @@ extern "C" int dzn_flac_decode(const uint8_t* data, size_t n, int32_t* out, int6
   const int C = si.channels;
   int64_t done = 0;
   size_t at = si.first_frame;
-  static thread_local int64_t buf[8][65536];
+  // per-call scratch sized by the stream's own maximum block (STREAMINFO; 65535 when it states none) instead of 4 MiB of
+  // thread-local storage paid by every thread that ever decodes
+  const int max_bs = si.max_block >= 16 && si.max_block <= 65535 ? si.max_block : 65536;
+  std::vector<int64_t> scratch;
+  try {
+    scratch.resize((size_t)C * (size_t)max_bs);
+  } catch (...) {
+    return DZN_E_NOMEM;
+  }
+  int64_t* buf[8];
+  for (int c = 0; c < 8; ++c) buf[c] = scratch.data() + (size_t)(c < C ? c : 0) * (size_t)max_bs;
   while (at + 2 <= n && (si.total == 0 || done < si.total)) {
     if (!(data[at] == 0xff && (data[at + 1] & 0xfe) == 0xf8)) {
       if (si.total == 0) break;                       // trailing bytes behind the last frame of a stream of unknown length
@@ -302,7 +320,7 @@ extern "C" int dzn_flac_decode(const uint8_t* data, size_t n, int32_t* out, int6
     if (ch_code < 8) nch = ch_code + 1;
     else if (ch_code <= 10) nch = 2;
     else return DZN_E_INVALID;
-    if (nch != C || blocksize > 65536 || blocksize < 1) return DZN_E_INVALID;
+    if (nch != C || blocksize > max_bs || blocksize < 1) return DZN_E_INVALID;
     for (int c = 0; c < nch; ++c) {
       int sub_bps = bps;
       if ((ch_code == 8 && c == 1) || (ch_code == 9 && c == 0) || (ch_code == 10 && c == 1)) sub_bps += 1;   // the side channel

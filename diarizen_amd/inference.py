@@ -89,16 +89,30 @@ class WindowRunner:
             free, total = torch.cuda.mem_get_info(device)
             need = int(self.engine.workspace_bytes)
             if free - need < max(self.RESERVE_BYTES, total // 4):
-                self._max_engines = len(self.engines)
+                self._declined(f"a further engine handle needs {need >> 20} MiB, {free >> 20} MiB of {total >> 20} MiB are free and "
+                               f"{max(self.RESERVE_BYTES, total // 4) >> 20} MiB must stay free")
                 break
             try:
                 e = self._factory()
-            except Exception:            # MemoryError / DznError: run on the handles that exist
-                self._max_engines = len(self.engines)
+            except Exception as ex:      # MemoryError / DznError: run on the handles that exist
+                self._declined(f"creating a further engine handle failed: {ex}")
                 break
             self._owned.append(e)
             self.engines = self.engines + (e,)
             self._streams = None
+
+    grow_declined: Optional[str] = None      # why fewer handles than asked for are in use (None: all were created / none asked)
+
+    def _declined(self, why: str) -> None:
+        """num_streams is an upper bound; say ONCE when it is not reached (on a device with <= 64 GB the documented
+        default of two streams would otherwise be silently one)"""
+        import warnings
+        asked = self._max_engines
+        self._max_engines = len(self.engines)
+        if self.grow_declined is None:
+            self.grow_declined = why
+            warnings.warn(f"diarizen_amd: running on {len(self.engines)} engine handle(s) / stream(s) instead of {asked}: {why}",
+                          RuntimeWarning, stacklevel=3)
 
     def close(self) -> None:
         """release the handles this runner created (their weights and workspaces) — not the caller's engine"""

@@ -405,6 +405,7 @@ class DiariZenPipeline:
                 with open(os.path.join(self.rttm_out_dir, sess_name + ".rttm"), "w") as f:
                     f.write(result.to_rttm())
         t3 = time.perf_counter()
+        self.streams_in_use = len(self._runner.engines)       # <= num_streams (WindowRunner.grow_declined says why when fewer)
         self.timings = {"load_s": t1 - t0, "device_s": t2 - t1, "host_s": t3 - t2,
                         "audio_s": num_samples / self.segmentation_model.sample_rate}
         return result

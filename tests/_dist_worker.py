@@ -49,7 +49,7 @@ seg_l = res.segmentations if res is not None else torch.empty((0, runner.num_fra
 emb_l = res.embeddings if res is not None else torch.empty((0, S, 256), device=dev)
 if backend != "nccl":
     seg_l, emb_l = seg_l.cpu(), emb_l.cpu()
-seg, emb = dz.gather_windows(seg_l, emb_l)
+seg, emb = dz.gather_windows(seg_l, emb_l, expected_total=C)      # one packed collective, blocks verified by their headers
 if rank == 0:
     full = runner.run(wave.to(dev), with_embeddings=True)
     torch.cuda.synchronize()

@@ -110,3 +110,27 @@ def test_flac_of_the_reference_example_equals_its_wav(built_lib):
     data = encode(pcm, sr, 16, frames=[FrameSpec(blocksize=4096, subs=[SubSpec("fixed", 2, partition_order=4)])])
     assert len(data) < 0.7 * 2 * len(pcm)                                   # it does compress
     assert np.array_equal(first_channel_16k(data), x[0, :160000])
+
+
+def test_unknown_length_stream_of_digital_silence_and_a_lying_total(built_lib):
+    """(r6) a stream without a STREAMINFO total (piped encoder) whose frames are CONSTANT subframes codes 4096 samples
+    in ~14 bytes: the loader must grow its output instead of calling the file corrupt; a STREAMINFO total that the byte count
+    cannot hold is refused before anything is allocated."""
+    from diarizen_amd.audio import load_flac
+    from testkit.flac_encoder import FrameSpec, SubSpec, encode
+    x = np.zeros(4096 * 40, dtype=np.int64)
+    spec = [FrameSpec(blocksize=4096, subs=[SubSpec("constant")])]
+    data = encode(x, 16000, 16, frames=spec)
+    assert len(data) * 4 < len(x)                            # under the loader's first guess of 4 samples per byte
+    y, sr = load_flac(data)
+    assert sr == 16000 and y.shape == (1, len(x)) and not y.any()
+    unknown = encode(x, 16000, 16, frames=spec, md5=False, total_in_header=False)
+    y2, _ = load_flac(unknown)
+    assert y2.shape == y.shape and not y2.any()
+    # STREAMINFO body starts at byte 8: min/max block (4), min/max frame (6), then 20 bits rate | 3 ch | 5 bps | 36 bits total
+    lying = bytearray(data)
+    off = 8 + 10
+    v = int.from_bytes(lying[off:off + 8], "big")
+    lying[off:off + 8] = (v | ((1 << 36) - 1)).to_bytes(8, "big")          # total = 2^36 - 1 samples
+    with pytest.raises(ValueError, match="holds at most"):
+        load_flac(bytes(lying))

@@ -42,6 +42,35 @@ def test_gpus_flag_spawns_that_many_ranks():
     assert out["sum_of_rank_ids"] == 3.0                                     # both contributed to the collective
 
 
+def test_eight_rank_dry_run_binds_distinct_devices_under_a_visibility_permutation():
+    """(r6) `--gpus 8` without a GPU: eight processes, rank -> cuda:LOCAL_RANK -> the physical device the
+    HIP_VISIBLE_DEVICES permutation puts there (eight distinct ones), the 4 h recording's window blocks tile it with their
+    sample ranges, and the packed all-gather returns every window in order on every rank."""
+    env = dict(_clean_env(), HIP_VISIBLE_DEVICES="3,2,1,0,7,6,5,4", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--rendezvous-check"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["rendezvous"] == "ok" and out["n_gpus"] == 8 and out["problems"] == []
+    by_rank = sorted(out["ranks"], key=lambda x: x["rank"])
+    assert [x["torch_device"] for x in by_rank] == [f"cuda:{i}" for i in range(8)]
+    assert [x["physical_device"] for x in by_rank] == ["3", "2", "1", "0", "7", "6", "5", "4"]
+    assert out["visible_devices_var"] == "HIP_VISIBLE_DEVICES"
+    C = out["strong_leg_windows"]
+    assert C == 17991 and out["gathered_windows"] == C                       # 4 h, 8 s windows, 0.8 s step
+    assert by_rank[0]["windows"][0] == 0 and by_rank[-1]["windows"][1] == C
+    assert all(a["windows"][1] == b["windows"][0] for a, b in zip(by_rank, by_rank[1:]))
+    assert out["sum_of_rank_ids"] == 36.0
+
+
+def test_dry_run_refuses_two_ranks_on_one_physical_device():
+    env = dict(_clean_env(), HIP_VISIBLE_DEVICES="0,0", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--rendezvous-check"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "share a physical device" in (r.stdout + r.stderr)
+
+
 def test_world_size_must_equal_gpus():
     env = _clean_env()
     env.update(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")

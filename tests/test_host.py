@@ -226,6 +226,37 @@ def test_resampler_properties(tmp_path):
     assert z.shape == (16000,) and np.abs(z[200:-200] - y[200:-200]).max() < 1e-3
 
 
+@pytest.mark.parametrize("sr0", [48000, 44100, 22050, 8000])
+def test_resampler_against_scipy_resample_poly_on_band_limited_input(sr0):
+    """(r6) torchaudio is not in the image, so the sinc / Hann resampler of audio.py (a restatement of
+    `torchaudio.functional.resample`'s defaults: 6 zero crossings, roll-off 0.99 - what PA/core/io.py:214-218 calls) is held to
+    an INDEPENDENT polyphase resampler: `scipy.signal.resample_poly` with a long Kaiser(14) filter, which reproduces the
+    analytic signal to 4e-7.  Input: twelve tones below HALF the lower Nyquist frequency, amplitude ~0.35 rms.  Tolerance 2e-3
+    absolute (measured 3e-4 ... 1.2e-3): what is left is the pass-band ripple of the short 6-crossing Hann window, a property
+    of torchaudio's default filter, not of this implementation - a wrong phase, gain, length or polyphase order would show as
+    1e-1."""
+    from scipy.signal import resample_poly
+    from diarizen_amd.audio import resample
+    sr1 = 16000
+    r = np.random.default_rng(sr0)
+    nyq = min(sr0, sr1) / 2
+    amps, fs, ps = r.uniform(0.05, 0.2, 12), r.uniform(50, 0.5 * nyq, 12), r.uniform(0, 6.28, 12)
+
+    def sig(t):
+        return sum(a * np.sin(2 * np.pi * f * t + p) for a, f, p in zip(amps, fs, ps))
+
+    x = sig(np.arange(2 * sr0) / sr0).astype(np.float32)
+    y = resample(x, sr0, sr1)
+    assert y.dtype == np.float32 and len(y) == 2 * sr1
+    g = int(np.gcd(sr0, sr1))
+    ref = resample_poly(x.astype(np.float64), sr1 // g, sr0 // g, window=("kaiser", 14.0))
+    truth = sig(np.arange(len(y)) / sr1)
+    inner = slice(400, -400)
+    assert np.abs(ref[:len(y)] - truth)[inner].max() < 5e-6          # the independent resampler is a faithful yardstick
+    assert np.abs(y - ref[:len(y)])[inner].max() < 2e-3
+    assert np.abs(y - truth)[inner].max() < 2e-3
+
+
 # ----------------------------------------------------------------------------- multi-process exchange
 def _free_port():
     s = socket.socket()
