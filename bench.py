@@ -606,6 +606,13 @@ def strong_leg(args, dev, rank, world, minutes):
             "e2e_audio_seconds_per_s": round(audio_s / (dev_s + host_s), 1),
             "device_only_audio_seconds_per_s": round(audio_s / dev_s, 1),
             "amdahl_serial_frac": round(host_s / (dev_s + host_s), 4),
+            # (r6) what the measured components allow at more GPUs: the sharded part (range decode + upload +
+            # device stage of a contiguous window block) divides by N, the host stage of the ONE recording stays on rank 0
+            "projected_from_this_run": (None if world != 1 else {
+                f"{n}_gpus": {"e2e_s": round(dev_s / n + host_s, 3), "audio_seconds_per_s": round(audio_s / (dev_s / n + host_s), 1),
+                              "efficiency": round((dev_s + host_s) / (n * (dev_s / n + host_s)), 3)} for n in (2, 4, 8)}),
+            "projection_note": "PROJECTED, not measured: T(N) = sharded_s / N + serial_host_s from this run's two figures (blocks are "
+                               "balanced to one window; the all-gather moves 5.7 KB per window: 13 MB at 4 h)" if world == 1 else None,
             "speakers": len(ann.labels()), "rttm_lines": len(ann.to_rttm().splitlines()),
             "note": "sharded_s = max over ranks of [byte-range decode of the rank's block of a 16-bit PCM file + upload + segmentation + embeddings + RCCL all-gather + D2H]; "
                     "serial_host_s = rank 0's counting + AHC + assignment + reconstruction + RTTM; seeded turn-taking weights"}

@@ -97,6 +97,8 @@ class DznGemmDesc(C.Structure):
         ("z_count", C.c_void_p), ("z_list", C.c_void_p), ("ln_centered", C.c_int32),
         ("Wmx", C.c_void_p), ("col_scale_mx", C.c_void_p),
         ("amax_count", C.c_int32),
+        ("kv_planes", C.c_void_p), ("kv_plane_stride", C.c_int64), ("kv_scale", C.c_void_p), ("kv_ld", C.c_int32),
+        ("kv_col0", C.c_int32),
     ]
 
 
@@ -188,6 +190,9 @@ def load() -> C.CDLL:
     sig("dzn_op_row_stats", i32, [vp, i64, i64, i32, f32, vp, vp])
     sig("dzn_op_gate_stats", i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp])
     sig("dzn_op_attention_h2", i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp])
+    sig("dzn_op_set_attention_qb", i32, [i32])
+    sig("dzn_op_set_attention_prefetch", i32, [i32])
+    sig("dzn_op_attention_planes", i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp])
     sig("dzn_op_attention", i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp])
     _LIB = lib
     return lib
@@ -199,7 +204,7 @@ EXPORTED = [
     "dzn_workspace_bytes", "dzn_last_error", "dzn_destroy", "dzn_version", "dzn_linkage_centroid", "dzn_cdist_cosine", "dzn_host_workspace_release",
     "dzn_host_workspace_bytes",
     "dzn_flac_info", "dzn_flac_decode", "dzn_vbx_create", "dzn_vbx_stats", "dzn_vbx_estep", "dzn_vbx_gamma", "dzn_vbx_destroy",
-    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_split_weights_mx", "dzn_op_set_gemm_mx_cfg", "dzn_checked_status", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_resblock32_fused", "dzn_op_resblock_ws", "dzn_op_set_resblock_np", "dzn_op_set_attention_noskip", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2",
+    "dzn_op_gemm", "dzn_op_split_weights", "dzn_op_split_weights_h2", "dzn_op_split_weights_mx", "dzn_op_set_gemm_mx_cfg", "dzn_checked_status", "dzn_op_set_gemm_cfg", "dzn_op_amax", "dzn_op_conv3x3_c32", "dzn_op_conv3x3_c32_h2", "dzn_op_resblock32_fused", "dzn_op_resblock_ws", "dzn_op_set_resblock_np", "dzn_op_set_attention_noskip", "dzn_op_split_rows", "dzn_op_layernorm", "dzn_op_row_stats", "dzn_op_gate", "dzn_op_gate_stats", "dzn_op_attention", "dzn_op_attention_h2", "dzn_op_attention_planes", "dzn_op_set_attention_qb", "dzn_op_set_attention_prefetch",
     "dzn_profile_enable", "dzn_profile_collect", "dzn_profile_reserve", "dzn_op_relpos_bucket",
 ]
 

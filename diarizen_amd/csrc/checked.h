@@ -40,4 +40,4 @@
 #endif
 
 // check ids: 0x1xx gemm_split, 0x2xx gemm_mx, 0x3xx gemm_split_pre, 0x4xx resblock_fused, 0x5xx resblock_ws,
-//            0x6xx attention_split, 0x7xx frontend_fused
+//            0x60x attention_split, 0x61x attention_planes, 0x7xx frontend_fused

@@ -164,6 +164,10 @@ int launch_attention_split(const float* qkv, float* out, const float* gate, cons
 int launch_attention(const float* qkv, float* out, const float* gate, const float* table,
                      const int32_t* head_idx, int B, int L, int h, int Htot, int ldqkv, int ldo,
                      float scale, int precision, hipStream_t s);
+// attention_planes.hip (r6): K / V arrive as the fp16 two-term planes the q/k/v contraction's epilogue wrote (dzn_gemm_desc.kv_planes)
+int launch_attention_planes(const float* qkv, const void* planes, int64_t plane_stride, const float* kvs, int kv_ld, float* out,
+                            const float* gate, const float* table, const int32_t* head_idx, int B, int L, int h, int Htot,
+                            int ldqkv, int ldo, float scale, hipStream_t s, const float* amax);
 
 // frontend.hip
 int launch_conv0(const float* wave, int B, int N, const float* stats, const float* w,

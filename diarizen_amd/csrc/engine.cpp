@@ -160,6 +160,12 @@ struct dzn_handle {
   float *x = nullptr, *xpad = nullptr, *y = nullptr, *ws = nullptr, *qkv = nullptr, *ao = nullptr,
         *gate = nullptr, *mid = nullptr;
   float *hz = nullptr, *ht = nullptr, *hmid = nullptr, *hv = nullptr;
+  // (r6) K / V of the encoder's attention as pre-split fp16 planes + per-(row, head slot) inverse scales, written by the q/k/v
+  // contraction's epilogue (csrc/attention_planes.hip); nullptr = fp32 K / V and the in-kernel split of attention_split.hip
+  void* kvp = nullptr;
+  float* kvs = nullptr;
+  int64_t kvp_rows = 0;
+  int kvp_ldmax = 0;
   // (r4) pre-norm encoders: every layer writes its output rows into ITS OWN buffer (xl + layer * rows * D) and the
   // layer-weighted sum (model_wavlm_conformer.py:236,253-254) is ONE pass over those buffers after the last layer, instead of
   // a read-modify-write of `ws` in every FFN-output epilogue: 25 reads + 1 write of [rows, D] where there were 25 reads and
@@ -754,6 +760,14 @@ void finalize_seg(H* h) {
   h->xl_elems = (c.layer_norm_first && h->fold_ln && c.n_layers > 0 && c.n_layers < WS_SUM_MAX && D % 4 == 0 &&
                  !getenv("DZN_NO_WS_DEFER")) ? (int64_t)c.n_layers * ML * D : 0;
   h->qkv = dalloc<float>(h, ML * 3 * maxQ);
+  if (c.precision == DZN_PREC_F32_H2 && maxQ > 0 && !getenv("DZN_NO_ATT_PLANES")) {
+    // two fp16 planes of [rows + 64][2 * maxQ] (the bytes of the fp32 K / V they replace) and the slot scales; zero-filled once:
+    // the 64 rows past a batch are only ever read for keys that are masked, but they must be finite
+    h->kvp_rows = ML + 64;
+    h->kvp_ldmax = 2 * maxQ;
+    h->kvp = dalloc<uint16_t>(h, 2 * h->kvp_rows * h->kvp_ldmax);
+    h->kvs = dalloc<float>(h, h->kvp_rows * (h->kvp_ldmax / 64));
+  }
   h->ao = dalloc<float>(h, ML * maxQ);
   h->gate = dalloc<float>(h, ML * h->H);
   h->mid = dalloc<float>(h, ML * maxF);
@@ -1307,8 +1321,21 @@ void seg_forward(H* h, const float* wave, int B, int N, float* d_logp, uint8_t* 
       if (fold1) folded(d, Ly.qkv);
       d.a_amax = am(yin == xr ? dzn_handle::AM_X : dzn_handle::AM_Y);
       d.c_amax = am(dzn_handle::AM_QKV);
+      const bool planes = h->kvp != nullptr && !y16 && d.W2h && d.col_scale && d.a_amax;     // the f32h contraction writes them
+      const int64_t pstride = (ML + 64) * (int64_t)(2 * hd);
+      if (planes) {
+        d.kv_planes = h->kvp;
+        d.kv_plane_stride = pstride;
+        d.kv_scale = h->kvs;
+        d.kv_ld = 2 * hd;
+        d.kv_col0 = hd;
+      }
       gemm(d, y16, false, "qkv");
-      if (prec_is_split(c.precision))
+      if (planes)
+        chk(launch_attention_planes(h->qkv, h->kvp, pstride, h->kvs, 2 * hd, h->ao, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H,
+                                    3 * hd, hd, 0.125f, st, am(dzn_handle::AM_QKV)),
+            "attention");
+      else if (prec_is_split(c.precision))
         chk(launch_attention_split(h->qkv, h->ao, h->gate, h->table, Ly.head_idx, B, L, Ly.h, h->H, 3 * hd, hd,
                                    0.125f, st, am(dzn_handle::AM_QKV)),
             "attention");
@@ -1910,6 +1937,7 @@ int dzn_checked_collect_gemm_split_pre(unsigned int*, int);
 int dzn_checked_collect_resblock_fused(unsigned int*, int);
 int dzn_checked_collect_resblock_ws(unsigned int*, int);
 int dzn_checked_collect_attention_split(unsigned int*, int);
+int dzn_checked_collect_attention_planes(unsigned int*, int);
 int dzn_checked_collect_frontend_fused(unsigned int*, int);
 }
 #endif
@@ -1918,7 +1946,8 @@ int dzn_checked_status(uint32_t* out4, int32_t reset) {
   typedef int (*collect_fn)(unsigned int*, int);
   const collect_fn fns[] = {dzn_checked_collect_gemm_split, dzn_checked_collect_gemm_mx, dzn_checked_collect_gemm_split_pre,
                             dzn_checked_collect_resblock_fused, dzn_checked_collect_resblock_ws,
-                            dzn_checked_collect_attention_split, dzn_checked_collect_frontend_fused};
+                            dzn_checked_collect_attention_split, dzn_checked_collect_attention_planes,
+                            dzn_checked_collect_frontend_fused};
   unsigned int tot[4] = {0u, 0u, 0u, 0u};
   for (collect_fn f : fns) {
     unsigned int w[4] = {0u, 0u, 0u, 0u};

@@ -455,6 +455,16 @@ int launch_gemm(const dzn_gemm_desc& din, hipStream_t s) {
     return launch_prec<true>(d, s);
   }
   if (!d.W) return DZN_E_INVALID;
+  if (d.kv_planes) {
+    // (r6) K / V slots as pre-split planes: written by the epilogue of the 16x16-block split contractions only, whose automatic
+    // tiles (128 x 64 / 128 x 128) walk a wavefront tile in 64-column groups when N % 64 == 0; anything else is refused here
+    // rather than left to an epilogue that would silently store fp32 where the attention kernel expects planes
+    const bool ok = d.kv_scale && d.precision == DZN_PREC_F32_H2 && d.W3 && d.W2h && d.col_scale && d.a_amax && !(d.K & 31) &&
+                    !(d.kc & 31) && d.ldw == d.K && !d.a_split3 && d.nz == 1 && !d.c_rowoff && d.kv_col0 >= 0 &&
+                    d.kv_col0 < d.N && !(d.kv_col0 & 63) && !(d.N & 63) && d.kv_ld == d.N - d.kv_col0 &&
+                    !(d.kv_plane_stride & 3) && d.N > 32 && !getenv("DZN_GEMM_CFG") && !getenv("DZN_NO_H2");
+    if (!ok) return DZN_E_INVALID;
+  }
   if (d.ln_centered && !(d.precision == DZN_PREC_F16 && d.W3 && !(d.K & 31) && !(d.kc & 31) && d.ldw == d.K && !d.a_split3))
     return DZN_E_INVALID;    // only gemm_split.hip's single-term kernel subtracts the row mean (see launch_gemm_split)
   if (d.a_split3) return prec_is_split(d.precision) ? launch_gemm_split_pre(d, s) : DZN_E_INVALID;

@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "split.h"
 
 namespace {
 
@@ -339,10 +340,53 @@ __device__ __forceinline__ void gemm_epilogue(const dzn_gemm_desc& d, f32x4 (&ac
         // erf chains of 16 elements costs ~100 live registers and spills
         __builtin_amdgcn_sched_barrier(0x00E0 | 0x0200);
       }
+      // (r6) K / V head slots leave as pre-split fp16 planes with their own per-(row, slot) power-of-two scale (dzn_ops.h:
+      // kv_planes): the slot's 64 columns of a row sit in 4 column blocks x the 4 lanes lr, lr + 16, lr + 32, lr + 48
+      if constexpr (JC % 4 == 0 && RS == 16 && CS == 16) {
+        if (d.kv_planes) {
+#pragma unroll
+          for (int g4 = 0; g4 < JC / 4; ++g4) {
+            const int jg = jc * JC + g4 * 4;
+            const int nslot = tn * BN + wn * TN + jg * CS;                  // wave-uniform first column of the slot
+            if (nslot >= d.kv_col0 && nslot < d.N) {
+              float am = 0.f;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(acc[i][jg + q][0]), fabsf(acc[i][jg + q][1]))),
+                           fmaxf(fabsf(acc[i][jg + q][2]), fabsf(acc[i][jg + q][3])));
+              am = fmaxf(am, __shfl_xor(am, 16, 64));
+              am = fmaxf(am, __shfl_xor(am, 32, 64));
+              float ks, kinv;
+              h2_scale(am, ks, kinv);
+              uint16_t* p0 = reinterpret_cast<uint16_t*>(d.kv_planes) + (int64_t)mcl[i] * d.kv_ld + (nslot - d.kv_col0) + lq * 4;
+              uint16_t* p1 = p0 + d.kv_plane_stride;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                f32x2 x0, x1;
+                x0[0] = acc[i][jg + q][0] * ks; x0[1] = acc[i][jg + q][1] * ks;
+                x1[0] = acc[i][jg + q][2] * ks; x1[1] = acc[i][jg + q][3] * ks;
+                const f16x2 h0 = __builtin_convertvector(x0, f16x2), h1 = __builtin_convertvector(x1, f16x2);
+                const f32x2 f0 = __builtin_convertvector(h0, f32x2), f1 = __builtin_convertvector(h1, f32x2);
+                f32x2 r0, r1;
+                r0[0] = x0[0] - f0[0]; r0[1] = x0[1] - f0[1]; r1[0] = x1[0] - f1[0]; r1[1] = x1[1] - f1[1];   // exact in fp32
+                const f16x2 l0 = __builtin_convertvector(r0, f16x2), l1 = __builtin_convertvector(r1, f16x2);
+                if (mok[i]) {
+                  *reinterpret_cast<uint2*>(p0 + q * CS) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+                  *reinterpret_cast<uint2*>(p1 + q * CS) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+                }
+              }
+              if (lq == 0 && mok[i]) d.kv_scale[(int64_t)mcl[i] * (d.kv_ld >> 6) + ((nslot - d.kv_col0) >> 6)] = kinv;
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int jj = 0; jj < JC; ++jj) {
         const int j = jc * JC + jj;
-        if (mok[i] && nok_(j))
+        bool plain = true;
+        if constexpr (JC % 4 == 0 && RS == 16 && CS == 16)
+          plain = !(d.kv_planes && tn * BN + wn * TN + (j & ~3) * CS >= d.kv_col0);      // the slot went out as planes
+        if (plain && mok[i] && nok_(j))
           *reinterpret_cast<float4*>(d.C + crow[i] + nc_(j)) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     }

@@ -26,8 +26,10 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
          ldws=0, act=0, alpha=1.0, post_relu=False, nz=1, zdiv=1, zs=None, precision=0,
          W16=None, W3=None, a_planes=None, ln_stats=None, ln_colsum=None, W2h=None, col_scale=None,
          a_amax=None, c_amax=None, amax_unit=None, want_row_stats=False, stat_eps=1e-5, mx=False, Wmx=None,
-         col_scale_mx=None):
-    """C = epilogue(A @ W^T); see dzn_gemm_desc.  A: [M, K] (or raw buffer with lda / rowoff),
+         col_scale_mx=None, kv_col0=None):
+    """C = epilogue(A @ W^T); see dzn_gemm_desc.  kv_col0 (r6): columns >= kv_col0 leave as fp16 two-term planes with per-(row,
+    64-column slot) scales instead of fp32 (dzn_gemm_desc.kv_planes) -> returns (C, planes int16 [2, M, N - kv_col0], inv f32
+    [M, (N - kv_col0) / 64]).  A: [M, K] (or raw buffer with lda / rowoff),
     W: [N, K] fp32 (and optionally W16 bf16)."""
     lib = _lib.load()
     assert A.is_cuda and A.dtype in (torch.float32, torch.bfloat16)
@@ -87,8 +89,29 @@ def gemm(A, W, *, M=None, N=None, K=None, bias=None, R=None, C_out=None, WS=None
         part = torch.empty((M, 32, 2), device=A.device, dtype=torch.float32)
         stats = torch.empty((M, 2), device=A.device, dtype=torch.float32)
         d.stat_partial, d.stat_final, d.stat_C, d.stat_eps = _p(part), _p(stats), N, stat_eps
+    kvp = kvs = None
+    if kv_col0 is not None:
+        kvp = torch.zeros((2, M, N - kv_col0), device=A.device, dtype=torch.int16)
+        kvs = torch.zeros((M, (N - kv_col0) // 64), device=A.device, dtype=torch.float32)
+        d.kv_planes, d.kv_plane_stride, d.kv_scale, d.kv_ld, d.kv_col0 = _p(kvp), kvp.stride(0), _p(kvs), N - kv_col0, kv_col0
     check(lib.dzn_op_gemm(C.byref(d), _stream()), what="dzn_op_gemm")
+    if kv_col0 is not None:
+        return C_out, kvp, kvs
     return (C_out, stats) if want_row_stats else C_out
+
+
+def attention_planes(qkv, B, L, h, gate=None, table=None, head_idx=None, Htot=0, scale=0.125):
+    """(r6) csrc/attention_planes.hip through its test entry point: the K / V slots of `qkv` are packed into fp16 two-term planes
+    with per-(row, head) power-of-two scales (as the q/k/v contraction's epilogue does) and the planes kernel runs on them."""
+    lib = _lib.load()
+    assert qkv.is_cuda and qkv.dtype == torch.float32 and qkv.shape == (B * L, 3 * h * 64)
+    out = torch.empty((B * L, h * 64), device=qkv.device, dtype=torch.float32)
+    am = qkv.reshape(B, -1).abs().amax(dim=1).float().contiguous()
+    planes = torch.zeros((2, B * L + 64, 2 * h * 64), device=qkv.device, dtype=torch.int16)
+    kvs = torch.zeros((B * L + 64, 2 * h), device=qkv.device, dtype=torch.float32)
+    check(lib.dzn_op_attention_planes(_p(qkv), _p(out), _p(gate), _p(table), _p(head_idx), B, L, h, Htot, qkv.stride(0),
+                                      out.stride(0), scale, _p(am), _p(planes), _p(kvs), _stream()), what="dzn_op_attention_planes")
+    return out
 
 
 def split_weights(W):

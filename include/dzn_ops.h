@@ -121,6 +121,18 @@ typedef struct dzn_gemm_desc {
   /* number of entries of the a_amax / c_amax arrays (0 = not stated): only read by CHECKED builds (csrc/checked.h), which
    * assert that every scale-unit index stays inside them */
   int32_t amax_count;
+  /* (r6) attention operands written by the q/k/v contraction itself (csrc/attention_planes.hip; reference arithmetic
+   * W2V/components.py:453-486): the columns n >= kv_col0 of C = [q | k | v] x heads x 64 — the K and V slots — are NOT stored to C
+   * as fp32; every (row, 64-column head slot) is scaled by the exact power of two that puts its own |max| into [2^14, 2^15) and
+   * stored as the two fp16 terms of the f32h split: kv_planes = fp16 [2][rows][kv_ld] (plane p at p * kv_plane_stride elements,
+   * row-major, kv_ld = N - kv_col0), kv_scale = f32 [rows][kv_ld / 64] = the INVERSE scale of the slot.  The attention kernel then
+   * stages ready tiles (no split, no 7-fold re-split per query tile) and un-scales per key.  NULL = plain fp32 store.  Needs the
+   * 16x16-block f32h / f32s contraction kernels, kv_col0 % 64 == 0 and N % 64 == 0 (refused otherwise). */
+  void* kv_planes;
+  int64_t kv_plane_stride;
+  float* kv_scale;
+  int32_t kv_ld;
+  int32_t kv_col0;
 } dzn_gemm_desc;
 
 /* (r4) One BasicBlock of the 32-channel ResNet stage in one kernel (csrc/resblock_fused.hip):
@@ -229,6 +241,21 @@ int dzn_op_gate_stats(const float* x, int64_t ldx, const float* gamma, const flo
 int dzn_op_attention_h2(const float* qkv, float* out, const float* gate, const float* table, const int32_t* head_idx,
                         int32_t B, int32_t L, int32_t h, int32_t Htot, int32_t ldqkv, int32_t ldo, float scale,
                         const float* amax, void* stream);
+
+/* (r6) the attention on PRE-SPLIT K / V (csrc/attention_planes.hip): packs the K and V slots of a plain fp32 qkv = [B L][3 h 64]
+ * into fp16 two-term planes with one power-of-two scale per (row, head slot) — exactly what the q/k/v contraction's epilogue
+ * writes (dzn_gemm_desc.kv_planes) — and runs the kernel the engine runs.  planes / kvs: caller's scratch, fp16 [2][B L + 64][2 h 64]
+ * and f32 [B L + 64][2 h], zero-filled by the caller. */
+int dzn_op_attention_planes(const float* qkv, float* out, const float* gate, const float* table, const int32_t* head_idx,
+                            int32_t B, int32_t L, int32_t h, int32_t Htot, int32_t ldqkv, int32_t ldo, float scale,
+                            const float* amax, void* planes, float* kvs, void* stream);
+
+/* test / A-B switch of the planes kernel: 16-query blocks per wavefront — 1 (default: 64 queries per workgroup, three workgroups
+ * per CU) or 2 (128 queries per workgroup: every staged tile and LDS fragment read serves twice the matrix work; measured 4 % SLOWER,
+ * profiles/r6_attention_planes_ab.txt) */
+int dzn_op_set_attention_qb(int32_t query_blocks_per_wavefront);
+/* ... and whether the next K / V tile is requested before the current one is computed (default 1) */
+int dzn_op_set_attention_prefetch(int32_t on);
 
 int dzn_op_attention(const float* qkv, float* out, const float* gate, const float* table,
                      const int32_t* head_idx, int32_t B, int32_t L, int32_t h,

@@ -357,6 +357,92 @@ def test_attention_query_less_wavefronts_skip_with_the_same_bits(built_lib, gpu,
         assert torch.equal(full, skip)
 
 
+@pytest.mark.parametrize("L", [15, 64, 99, 399])
+def test_attention_planes_kernel_matches_float64_and_the_split_kernel(built_lib, gpu, L):
+    """(r6) csrc/attention_planes.hip: K / V arrive as fp16 two-term planes with ONE power-of-two scale per (row, head) - what
+    the q/k/v contraction's epilogue writes - the scores are un-scaled per key and V's scale rides in the probabilities.  Against
+    a float64 attention (W2V/components.py:453-486 with the gated relative-position bias of :690-725) at the tolerance of the
+    in-kernel-split kernel, and against that kernel itself.  Rows of very different magnitude (x 2^-9 ... 2^9 per row and head:
+    what per-row scales exist for) are part of the input; a transposed or permuted V gather would show as O(1)."""
+    from diarizen_amd import ops
+    g = torch.Generator().manual_seed(3 * L + 2)
+    B, Htot = 3, 16
+    heads = [1, 4, 7, 12, 13]
+    h = len(heads)
+    qkv = torch.randn(B * L, 3 * h * 64, generator=g)
+    # per-(row, head) magnitudes over 18 binades for K and V (the q side keeps one window scale)
+    mag = torch.exp2(torch.randint(-9, 10, (B * L, 2 * h), generator=g).float())
+    qkv[:, h * 64:] = (qkv[:, h * 64:].view(B * L, 2 * h, 64) * mag[..., None]).view(B * L, 2 * h * 64)
+    qkv[:, :h * 64] *= 0.05                              # keep the softmax from saturating on the large keys
+    gate = torch.rand(B * L, Htot, generator=g) * 2
+    table = torch.randn(Htot, 2 * L - 1, generator=g)
+    q, k, v = [qkv[:, i * h * 64:(i + 1) * h * 64].view(B, L, h, 64).permute(0, 2, 1, 3) for i in range(3)]
+    idx = torch.arange(L)[None, :] - torch.arange(L)[:, None] + L - 1
+    bias = (gate.view(B, L, Htot).permute(0, 2, 1)[..., None] * table[:, idx][None])[:, heads]
+    hidx = torch.tensor(heads, dtype=torch.int32, device=gpu)
+    for kw, b_ in ((dict(), None), (dict(gate=gate.to(gpu), table=table.to(gpu), head_idx=hidx, Htot=Htot), bias)):
+        ref = _attn_ref(q, k, v, b_).permute(0, 2, 1, 3).reshape(B * L, h * 64)
+        old = ops.attention(qkv.to(gpu), B, L, h, precision=_lib_prec("f32h"), **kw)
+        outs = {}
+        for qb, pf in ((1, 1), (1, 0), (2, 0)):  # the shipped form (64 queries per workgroup, next tile prefetched), without the
+            try:                                 # prefetch, and 128 queries per workgroup
+                _lib_handle().dzn_op_set_attention_qb(qb)
+                _lib_handle().dzn_op_set_attention_prefetch(pf)
+                outs[(qb, pf)] = ops.attention_planes(qkv.to(gpu), B, L, h, **kw).clone()
+            finally:
+                _lib_handle().dzn_op_set_attention_qb(1)
+                _lib_handle().dzn_op_set_attention_prefetch(1)
+        torch.cuda.synchronize()
+        tol = 2e-5 * max(1.0, float(ref.abs().max()))
+        e_old = (old.cpu().double() - ref).abs().max().item()
+        for qb, out in outs.items():
+            assert torch.isfinite(out).all()
+            e_new = (out.cpu().double() - ref).abs().max().item()
+            print(f"[attention planes L={L} bias={b_ is not None} qb={qb}] max err vs float64: planes {e_new:.2e}, in-kernel split "
+                  f"{e_old:.2e} (|out| max {float(ref.abs().max()):.1f})")
+            assert e_new < tol, (qb, e_new, tol)
+        assert torch.equal(outs[(1, 1)], outs[(1, 0)]) and torch.equal(outs[(1, 1)], outs[(2, 0)])    # schedules, not arithmetic
+
+
+def _lib_handle():
+    from diarizen_amd import _lib
+    return _lib.load()
+
+
+def _lib_prec(name):
+    from diarizen_amd import _lib
+    return {"f32h": _lib.DZN_PREC_F32_H2, "f32s": _lib.DZN_PREC_F32_SPLIT, "f32": _lib.DZN_PREC_F32}[name]
+
+
+@pytest.mark.parametrize("M,N,K,col0", [(399 * 2, 3 * 5 * 64, 256, 5 * 64), (1000, 3 * 16 * 64, 1024, 16 * 64), (130, 192, 64, 64)])
+def test_gemm_epilogue_writes_kv_planes(built_lib, gpu, M, N, K, col0):
+    """(r6) dzn_gemm_desc.kv_planes: the f32h contraction stores the columns >= kv_col0 as fp16 two-term planes with one exact
+    power-of-two scale per (row, 64-column slot) and leaves the columns below as fp32.  (hi + lo) * inv reproduces the plain
+    launch's fp32 value to 2^-21 of the slot's |max| (two fp16 terms = 22 bits), the slot |max| lands in [2^14, 2^15) and the Q
+    columns are bit-identical to the plain launch; with a bias and a folded LayerNorm as the engine's q/k/v site has them."""
+    from diarizen_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-3, 4, (M, 1), generator=g).float())).to(gpu)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu)
+    bias = torch.randn(N, generator=g).to(gpu)
+    prec = _lib.DZN_PREC_F32_H2
+    plain = ops.gemm(A, W, bias=bias, precision=prec)
+    C, planes, inv = ops.gemm(A, W, bias=bias, precision=prec, kv_col0=col0)
+    torch.cuda.synchronize()
+    assert torch.equal(C[:, :col0], plain[:, :col0])
+    hi = planes[0].view(torch.float16).float()
+    lo = planes[1].view(torch.float16).float()
+    S = (N - col0) // 64
+    rec = ((hi + lo).view(M, S, 64) * inv[..., None]).view(M, N - col0)
+    want = plain[:, col0:]
+    slot_max = want.view(M, S, 64).abs().amax(-1, keepdim=True)
+    err = ((rec - want).view(M, S, 64).abs() / slot_max.clamp_min(1e-30)).max().item()
+    scaled = (hi.view(M, S, 64).abs().amax(-1))
+    assert err <= 2.0 ** -21, err
+    assert float(scaled.min()) >= 2.0 ** 14 - 8 and float(scaled.max()) < 2.0 ** 15 + 1
+    assert torch.all(inv > 0) and torch.equal(inv, torch.exp2(torch.floor(torch.log2(inv))))     # exact powers of two
+
+
 def test_gate(built_lib, gpu):
     from diarizen_amd import ops
     g = torch.Generator().manual_seed(11)
