@@ -32,6 +32,38 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ R, float* __r
         x.x += 1.f; x.y += 1.f; x.z += 1.f; x.w += 1.f;
         if (m < M) *reinterpret_cast<float4*>(C + (size_t)m * N + col0 + 16 * j + 4 * lq) = x;
       }
+  } else if constexpr (SHAPE == 2) {     // full rows in HBM, accumulator shape in registers, transposed through wave-private LDS
+    __shared__ __attribute__((aligned(16))) float scr[4][16 * 68];
+    float* my = scr[wave];
+    const int lr = lane & 15, lq = lane >> 4, fr = lane >> 4, fc = (lane & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {        // one 16-row block at a time
+      float4 r[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int m = row0 + 16 * i + 4 * t + fr;
+        r[t] = m < M ? *reinterpret_cast<const float4*>(R + (size_t)m * N + col0 + fc) : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(my + (4 * t + fr) * 68 + fc) = r[t];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      float4 a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(my + lr * 68 + 16 * j + 4 * lq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j].x += 1.f; a[j].y += 1.f; a[j].z += 1.f; a[j].w += 1.f; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(my + lr * 68 + 16 * j + 4 * lq) = a[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int m = row0 + 16 * i + 4 * t + fr;
+        const float4 x = *reinterpret_cast<const float4*>(my + (4 * t + fr) * 68 + fc);
+        if (m < M) *reinterpret_cast<float4*>(C + (size_t)m * N + col0 + fc) = x;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
   } else {                               // full rows: instruction t: rows 4 t + lane / 16, columns 4 (lane % 16): 4 rows x 256 B
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -54,14 +86,19 @@ int main() {
   hipMemset(R, 0, (size_t)M * N * 4);
   const int grid = ((M + 127) / 128) * (N / 64);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int shape = 0; shape < 2; ++shape)
+  for (int shape = 0; shape < 3; ++shape)
     for (int rep = 0; rep < 2; ++rep) {
-      for (int w = 0; w < 3; ++w) { if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, R, C, M, N); else hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, R, C, M, N); }
+      auto go = [&] {
+        if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, R, C, M, N);
+        else if (shape == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, R, C, M, N);
+        else hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, R, C, M, N);
+      };
+      for (int w = 0; w < 3; ++w) go();
       hipEventRecord(a);
-      for (int w = 0; w < 20; ++w) { if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, R, C, M, N); else hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, R, C, M, N); }
+      for (int w = 0; w < 20; ++w) go();
       hipEventRecord(b); hipEventSynchronize(b);
       float ms; hipEventElapsedTime(&ms, a, b); ms /= 20;
-      printf("%s: %.1f us per pass, %.2f TB/s (read + write %.2f GB)\n", shape == 0 ? "accumulator shape (16 rows x 64 B per instruction)" : "full rows (4 rows x 256 B per instruction)      ",
+      printf("%s: %.1f us per pass, %.2f TB/s (read + write %.2f GB)\n", shape == 0 ? "accumulator shape (16 rows x 64 B per instruction)" : shape == 1 ? "full rows (4 rows x 256 B per instruction)      " : "full rows in HBM, accumulator shape via LDS     ",
              ms * 1e3, 2.0 * M * N * 4 / (ms * 1e-3) / 1e12, 2.0 * M * N * 4 / 1e9);
     }
   return 0;
