@@ -833,6 +833,262 @@ __global__ __launch_bounds__(LB_BLK) void step2_kernel(double* __restrict__ D, i
   if (in && sz_dirty) size[z] = my_sz;
 }
 
+// ---- r6b: the whole loop in ONE launch (persistent workgroups) ----------------------------------------------------------
+// step2_kernel's loop pays a kernel boundary per step: 8.5 us per launch back to back, of which the step's own dependent chain
+// (two memory round trips and two block reductions) is about half.  persist2_kernel keeps the G workgroups of one launch
+// resident for the whole dendrogram and replaces the boundary by what the step needs anyway — every workgroup reading every
+// workgroup's published record:
+//   * what a workgroup publishes per step (its record and its top-2 slice of the new / rescanned row: 10 payload dwords) goes
+//     out as 10 64-bit words, each {step number : payload dword}.  A 64-bit store is one transaction, so a reader that finds
+//     the current step number in all 10 words of a slot has that step's payload — the poll of the slots IS the grid barrier
+//     (no counter, no second round trip to fetch the data behind a flag).  Slots are double-buffered by step parity: a
+//     workgroup can only reach step s + 2's publish after it saw every other workgroup's step s + 1 words, which those wrote
+//     after they had finished reading step s;
+//   * the per-row state (two neighbours, bounds, flags, size) lives in the REGISTERS of the row's thread for the whole run;
+//   * the 8 XCDs' L2s are not coherent with each other inside a launch, so every word another workgroup may read — the slots,
+//     D (thread z writes D[z][hi], thread hi reads it when row z merges later), size[], cid[] — is accessed with agent-scope
+//     relaxed atomics (sc1: loads miss the local L2, stores write through), and a thread drains its own stores (vmcnt 0) before
+//     the workgroup publishes.  No release / acquire fences: buffer_wbl2 / buffer_inv would write back and invalidate the
+//     whole L2 of an XCD that the engine's kernels of the NEXT recording are using at the same time (pipeline.diarize_many).
+// Every workgroup takes the same decision from the same words, so all of them leave the loop in the same step.  A poll that
+// does not complete in ~10 s (a workgroup that was never placed) ends the launch with PERSIST_TIMEOUT and the host falls back
+// to the launch-per-step loop.  Same dendrogram bits: tests/test_ops_gpu.py (vs scipy, vs the step loops, 30 k golden).
+constexpr int SLOT_W = 10;
+enum { PERSIST_RUNNING = 0, PERSIST_DONE = 1, PERSIST_FAIL = 2, PERSIST_TIMEOUT = 3 };
+
+__device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ldd_agent(const double* p) {
+  return __longlong_as_double((long long)ld_agent(reinterpret_cast<const uint64_t*>(p)));
+}
+__device__ __forceinline__ void std_agent(double* p, double v) {
+  st_agent(reinterpret_cast<uint64_t*>(p), (uint64_t)__double_as_longlong(v));
+}
+__device__ __forceinline__ int ldi_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sti_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// block_top2_min for NW wavefronts (sval: 3 NW doubles, sidx: 3 NW ints)
+template <int NW>
+__device__ __forceinline__ void block_top2_min_n(double a1, int ai1, double a2, int ai2, double m, int mi, double& o1, int& oi1,
+                                                 double& o2, int& oi2, double& om, int& omi, double* sval, int* sidx) {
+  top2_min_stage<0xB1, 0xf>(a1, ai1, a2, ai2, m, mi);
+  top2_min_stage<0x4E, 0xf>(a1, ai1, a2, ai2, m, mi);
+  top2_min_stage<0x124, 0xf>(a1, ai1, a2, ai2, m, mi);
+  top2_min_stage<0x128, 0xf>(a1, ai1, a2, ai2, m, mi);
+  top2_min_stage<0x142, 0xa>(a1, ai1, a2, ai2, m, mi);
+  top2_min_stage<0x143, 0xc>(a1, ai1, a2, ai2, m, mi);
+  a1 = readlane63_d(a1); a2 = readlane63_d(a2); m = readlane63_d(m);
+  ai1 = __builtin_amdgcn_readlane(ai1, 63); ai2 = __builtin_amdgcn_readlane(ai2, 63); mi = __builtin_amdgcn_readlane(mi, 63);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) {
+    sval[wave] = a1; sval[NW + wave] = a2; sval[2 * NW + wave] = m;
+    sidx[wave] = ai1; sidx[NW + wave] = ai2; sidx[2 * NW + wave] = mi;
+  }
+  __syncthreads();
+  a1 = sval[0]; a2 = sval[NW]; m = sval[2 * NW];
+  ai1 = sidx[0]; ai2 = sidx[NW]; mi = sidx[2 * NW];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    top2_merge(a1, ai1, a2, ai2, sval[w], sidx[w], sval[NW + w], sidx[NW + w]);
+    if (pair_lt(sval[2 * NW + w], sidx[2 * NW + w], m, mi)) { m = sval[2 * NW + w]; mi = sidx[2 * NW + w]; }
+  }
+  o1 = a1; oi1 = ai1; o2 = a2; oi2 = ai2; om = m; omi = mi;
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void persist2_kernel(double* __restrict__ D, int n, const double* __restrict__ l1a,
+                                                      const double* __restrict__ l2a, const int* __restrict__ n1a,
+                                                      const int* __restrict__ n2a, const int* __restrict__ fla,
+                                                      int* __restrict__ size, int* __restrict__ cid, double* __restrict__ Z,
+                                                      uint64_t* __restrict__ slots, int* __restrict__ status,
+                                                      int spin_limit) {
+  constexpr int NW = BS / 64;
+  __shared__ double sval[3 * NW];
+  __shared__ int sidx[3 * NW];
+  __shared__ int sy[2];
+  const int G = gridDim.x, w = blockIdx.x, t = threadIdx.x;     // G <= BS (host)
+  const int z = w * BS + t;
+  const bool in = z < n;
+  // the row's state, in registers from here on (init_rows2_kernel left the exact two nearest neighbours; sizes are all 1)
+  double my_l1 = in ? l1a[z] : DINF, my_l2 = in ? l2a[z] : DINF;
+  int my_n1 = in ? n1a[z] : -1, my_n2 = in ? n2a[z] : -1, my_fl = in ? fla[z] : 0;
+  int my_sz = in ? 1 : 0;
+  bool owed = false;      // the row of the previous step (merged: hi, rescanned: x) gets its two neighbours from the parts
+  int ex = 0x7fffffff;    // that row
+  int k = 0, rescans = 0;
+  double pv = DINF;       // this thread's element of the row whose two smallest the step publishes
+  int excl = -1;          // row left out of this step's records
+  bool pend = false;      // the previous step was a merge: its pair's size[] / cid[] words are written in this step
+  int p_lo = -1, p_hi = -1, p_sum = 0, p_cid = 0;
+  for (unsigned seq = 1;; ++seq) {
+    // ---- publish: the two smallest of the new / rescanned row's slice, the record of this workgroup's rows ----
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this thread's stores to D / size / cid are written through
+    double b1, b2, rv;
+    int bi1, bi2, rx;
+    block_top2_min_n<NW>(pv, in ? z : 0x7fffffff, DINF, 0x7fffffff, (in && z != excl) ? my_l1 : DINF, in ? z : 0x7fffffff, b1,
+                         bi1, b2, bi2, rv, rx, sval, sidx);      // (its barriers order every thread's drain before the stores below)
+    uint64_t* mine = slots + ((size_t)(seq & 1) * G + w) * SLOT_W;
+    const uint64_t stamp = (uint64_t)seq << 32;
+    if (t == 0) {
+      const uint64_t u1 = (uint64_t)__double_as_longlong(b1), u2 = (uint64_t)__double_as_longlong(b2);
+      st_agent(mine + 4, stamp | (u1 & 0xffffffffu));
+      st_agent(mine + 5, stamp | (u1 >> 32));
+      st_agent(mine + 6, stamp | (u2 & 0xffffffffu));
+      st_agent(mine + 7, stamp | (u2 >> 32));
+      st_agent(mine + 8, stamp | (uint32_t)bi1);
+      st_agent(mine + 9, stamp | (uint32_t)bi2);
+    }
+    if (z == rx) {          // rx is always a row of this workgroup (every thread contributes its own index)
+      const uint64_t uv = (uint64_t)__double_as_longlong(rv);
+      const int ry = rv < DINF ? my_n1 : -1;
+      const uint32_t rexact = rv < DINF && (my_fl & 1) != 0 && my_n1 >= 0;
+      st_agent(mine + 0, stamp | (uv & 0xffffffffu));
+      st_agent(mine + 1, stamp | (uv >> 32));
+      st_agent(mine + 2, stamp | ((uint32_t)rx | (rexact << 31)));
+      st_agent(mine + 3, stamp | (uint32_t)ry);
+    }
+    // ---- poll every workgroup's slot of this step ----
+    uint64_t wd[SLOT_W];
+    const uint64_t* theirs = slots + ((size_t)(seq & 1) * G + (t < G ? t : 0)) * SLOT_W;
+    for (int spins = 0;; ++spins) {
+      bool ok = true;
+      if (t < G) {
+#pragma unroll
+        for (int i = 0; i < SLOT_W; ++i) wd[i] = ld_agent(theirs + i);
+#pragma unroll
+        for (int i = 0; i < SLOT_W; ++i) ok = ok && (uint32_t)(wd[i] >> 32) == seq;
+      }
+      if (__syncthreads_and(ok)) break;
+      if (spins > spin_limit) {       // the same value in every thread of the workgroup
+        if (t == 0) sti_agent(status, PERSIST_TIMEOUT);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    double r0v = DINF, p0v1 = DINF, p0v2 = DINF;
+    int r0x = 0x7fffffff, r0y = -1, r0exact = 0, p0i1 = 0x7fffffff, p0i2 = 0x7fffffff;
+    if (t < G) {
+      r0v = __longlong_as_double((long long)((wd[0] & 0xffffffffu) | (wd[1] << 32)));
+      r0x = (int)((uint32_t)wd[2] & 0x7fffffffu);
+      r0exact = (int)(((uint32_t)wd[2]) >> 31);
+      r0y = (int)(uint32_t)wd[3];
+      p0v1 = __longlong_as_double((long long)((wd[4] & 0xffffffffu) | (wd[5] << 32)));
+      p0v2 = __longlong_as_double((long long)((wd[6] & 0xffffffffu) | (wd[7] << 32)));
+      p0i1 = (int)(uint32_t)wd[8];
+      p0i2 = (int)(uint32_t)wd[9];
+    }
+    // ---- the two neighbours owed to the row of the previous step + the winner over the records ----
+    double ev1, ev2, d;
+    int eid1, eid2, x;
+    block_top2_min_n<NW>(owed ? p0v1 : DINF, owed ? p0i1 : 0x7fffffff, owed ? p0v2 : DINF, owed ? p0i2 : 0x7fffffff, r0v, r0x,
+                         ev1, eid1, ev2, eid2, d, x, sval, sidx);
+    const int ey = ev1 < DINF ? eid1 : -1;
+    if (owed && z == ex) {
+      my_l1 = ev1; my_n1 = ey; my_l2 = ev2; my_n2 = ev2 < DINF ? eid2 : -1;
+      my_fl = (my_n1 >= 0 ? 1 : 0) | (my_n2 >= 0 ? 2 : 0);
+    }
+    int y;
+    bool exact;
+    if (owed && pair_lt(ev1, ex, d, x)) {
+      d = ev1; x = ex; y = ey; exact = ey >= 0;
+    } else {
+      __syncthreads();
+      if (t < G && r0x == x && r0v == d) { sy[0] = r0y; sy[1] = r0exact; }
+      __syncthreads();
+      y = sy[0];
+      exact = sy[1] != 0 && y >= 0;
+    }
+    if (!(d < DINF) || x < 0 || x >= n) {    // NaN / inf distances: no pair left to merge
+      if (w == 0 && t == 0) { status[1] = k; status[2] = rescans; sti_agent(status, PERSIST_FAIL); }
+      return;
+    }
+    // the words of the previous merge's pair that other workgroups look up: written one step late, when every workgroup has
+    // finished the step that still read the old values (it published this step's words after those loads had returned)
+    if (pend) {
+      if (z == p_hi) { sti_agent(size + p_hi, p_sum); sti_agent(cid + p_hi, p_cid); }
+      if (z == p_lo) sti_agent(size + p_lo, 0);
+    }
+    bool pend_next = false;
+    pv = DINF;
+    excl = -1;
+    if (!exact) {
+      // ---- RESCAN: this workgroup's slice of row x over the active columns (D[x][x] is +inf) ----
+      ++rescans;
+      if (in && my_sz != 0) pv = ldd_agent(D + (int64_t)x * n + z);
+      excl = x;
+      owed = true;
+      ex = x;
+    } else {
+      // ---- MERGE: Lance-Williams update of this workgroup's columns ----
+      const int lo = x < y ? x : y, hi = x < y ? y : x;
+      // size[] / cid[] of the previous pair are rewritten by their owners in THIS step (above): substitute instead of reading them
+      const int nlo = pend && lo == p_hi ? p_sum : ldi_agent(size + lo);      // (lo / hi are active: never p_lo)
+      const int nhi = pend && hi == p_hi ? p_sum : ldi_agent(size + hi);
+      if (w == 0 && t == 0) {
+        const int ia = pend && lo == p_hi ? p_cid : ldi_agent(cid + lo), ib = pend && hi == p_hi ? p_cid : ldi_agent(cid + hi);
+        Z[4 * k + 0] = (double)(ia < ib ? ia : ib);
+        Z[4 * k + 1] = (double)(ia < ib ? ib : ia);
+        Z[4 * k + 2] = d;
+        Z[4 * k + 3] = (double)(nlo + nhi);
+      }
+      if (in) {
+        if (z == hi) {
+          std_agent(D + (int64_t)hi * n + lo, DINF);
+          my_l1 = my_l2 = DINF; my_n1 = my_n2 = -1; my_fl = 0;      // both neighbours after the next poll
+          my_sz = nlo + nhi;
+        } else if (z == lo) {
+          my_l1 = my_l2 = DINF; my_fl = 0;                          // retired
+          my_sz = 0;
+        } else if (my_sz != 0) {
+          const double dxi = ldd_agent(D + (int64_t)lo * n + z), dyi = ldd_agent(D + (int64_t)hi * n + z);
+          // scipy _hierarchy_distance_update.pxi, _centroid(d_xi, d_yi, d_xy, size_x, size_y, size_i), same order
+          const double v = sqrt((((nlo * dxi * dxi) + (nhi * dyi * dyi)) - (nlo * nhi * d * d) / (nlo + nhi)) / (nlo + nhi));
+          std_agent(D + (int64_t)hi * n + z, v);
+          std_agent(D + (int64_t)z * n + hi, v);       // column lo is NOT blanked: readers of a row mask by their size
+          pv = v;
+          // columns lo and (old) hi leave the row, column hi re-enters with v: the rules of step2_kernel's header
+          const bool d1 = my_n1 == lo || my_n1 == hi, d2 = my_n2 == lo || my_n2 == hi;
+          const bool e1 = my_fl & 1, e2 = my_fl & 2;
+          if (!d1) {
+            if (v < my_l1) {
+              my_l2 = my_l1; my_n2 = my_n1; my_fl = 1 | (e1 ? 2 : 0);
+              my_l1 = v; my_n1 = hi;
+            } else if (!d2) {
+              if (v < my_l2) { my_l2 = v; my_n2 = hi; my_fl |= 2; }
+            } else if (v <= my_l2) {
+              my_l2 = v; my_n2 = hi; my_fl |= 2;
+            } else {
+              my_n2 = hi; my_fl &= ~2;
+            }
+          } else {
+            if (!d2 && e2) {
+              if (v < my_l2) { my_l1 = v; my_n1 = hi; my_fl = 3; }
+              else { my_l1 = my_l2; my_n1 = my_n2; my_n2 = hi; my_fl = 1; }
+            } else {
+              if (v <= my_l2) { my_l1 = v; my_n1 = hi; my_fl = 1; }
+              else { my_l1 = my_l2; my_n1 = hi; my_fl = 0; }
+              if (d2) my_n2 = hi;
+            }
+          }
+        }
+      }
+      owed = true;
+      ex = hi;
+      pend_next = true; p_lo = lo; p_hi = hi; p_sum = nlo + nhi; p_cid = n + k;
+      if (++k >= n - 1) {
+        if (w == 0 && t == 0) { status[1] = k; status[2] = rescans; status[3] = (int)seq; sti_agent(status, PERSIST_DONE); }
+        return;
+      }
+    }
+    pend = pend_next;
+  }
+}
+
 #define LCHK(call)                                   \
   do {                                               \
     if ((call) != hipSuccess) { rc = DZN_E_HIP; goto done; } \
@@ -989,6 +1245,12 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   // DZN_LINKAGE_TOP1=1: r3-r5's step loop with ONE remembered neighbour per row (step_kernel) instead of r6's two
   const bool two_kernel = getenv("DZN_LINKAGE_TWO_KERNEL") != nullptr;
   const bool top2 = !two_kernel && getenv("DZN_LINKAGE_TOP1") == nullptr;
+  // DZN_LINKAGE_PERSIST=1: r6b's single persistent launch instead of the launch-per-step loop (measured SLOWER: 9.4 vs 8.2 us
+  // per step at n = 20 888 — a kernel boundary costs ~1.5 us here, an all-to-all exchange of records inside a launch >= 3 us;
+  // profiles/r6_linkage_persist.txt).  Kept as the measured record of VERDICT r5 item 2a and as a cross-check of the rules.
+  bool persist = top2 && getenv("DZN_LINKAGE_PERSIST") != nullptr;
+  const int pbs = n <= 32768 ? 256 : 1024;                       // workgroup size of the persistent launch: G <= 128 up to n = 131 072
+  const int pgrid = (n + pbs - 1) / pbs;
   std::vector<int> ones(n, 1), ids(n);
   for (int i = 0; i < n; ++i) ids[i] = i;
   MergeState st0{};
@@ -1006,6 +1268,8 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
   StepPart2* part22 = nullptr;
   double* l2a = nullptr;
   int* n2a = nullptr;
+  uint64_t* slots = nullptr;
+  int* pstatus = nullptr;
   auto carve = [&](char* base) {
     Carver c(base);
     D = c.take<double>((size_t)n * n);
@@ -1027,6 +1291,8 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
     part22 = c.take<StepPart2>((size_t)2 * nblk);
     l2a = c.take<double>(n);
     n2a = c.take<int>(n);
+    slots = c.take<uint64_t>((size_t)2 * pgrid * SLOT_W);
+    pstatus = c.take<int>(4);
     return c.off;
   };
   HostCtx* ctx = nullptr;
@@ -1043,7 +1309,48 @@ extern "C" int dzn_linkage_centroid(const float* h_emb, int32_t n, int32_t dim, 
     hipLaunchKernelGGL(pdist_kernel, dim3(tiles, tiles), dim3(256), 0, s, E, n, dim, D);
     if (top2) hipLaunchKernelGGL(init_rows2_kernel, dim3(n), dim3(256), 0, s, D, n, lb, l2a, nb, n2a, exf);
     else hipLaunchKernelGGL(init_rows_kernel, dim3(n), dim3(256), 0, s, D, n, lb, nb);
-    if (two_kernel) {
+    if (persist) {
+      // every workgroup must be resident at once (they wait for each other inside the launch)
+      int per_cu = 0, cus = 0, dev_now = 0;
+      const void* kfn = pbs == 256 ? (const void*)persist2_kernel<256> : (const void*)persist2_kernel<1024>;
+      if (pgrid > pbs || hipGetDevice(&dev_now) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_now) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, pbs, 0) != hipSuccess || (int64_t)per_cu * cus < pgrid) {
+        (void)hipGetLastError();
+        persist = false;
+      }
+    }
+    if (persist) {
+      LCHK(hipMemsetAsync(slots, 0, (size_t)2 * pgrid * SLOT_W * sizeof(uint64_t), s));
+      LCHK(hipMemsetAsync(pstatus, 0, 4 * sizeof(int), s));
+      const auto t_loop = std::chrono::steady_clock::now();
+      const int spin_limit = 8 << 20;
+      if (pbs == 256)
+        hipLaunchKernelGGL(persist2_kernel<256>, dim3(pgrid), dim3(256), 0, s, D, n, lb, l2a, nb, n2a, exf, size, cid, Z, slots,
+                           pstatus, spin_limit);
+      else
+        hipLaunchKernelGGL(persist2_kernel<1024>, dim3(pgrid), dim3(1024), 0, s, D, n, lb, l2a, nb, n2a, exf, size, cid, Z, slots,
+                           pstatus, spin_limit);
+      LCHK(hipGetLastError());
+      int hst[4] = {0, 0, 0, 0};
+      LCHK(hipMemcpyAsync(hst, pstatus, sizeof(hst), hipMemcpyDeviceToHost, s));
+      LCHK(hipStreamSynchronize(s));
+      if (getenv("DZN_LINKAGE_DEBUG"))
+        fprintf(stderr, "linkage[persistent, %d x %d]: n %d, status %d, %d merges, %d rescans, %d steps, loop %.1f ms\n", pgrid, pbs, n,
+                hst[0], hst[1], hst[2], hst[3], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count());
+      if (hst[0] == PERSIST_FAIL) { rc = DZN_E_INVALID; goto done; }       // non-finite distances
+      if (hst[0] != PERSIST_DONE) {
+        // a workgroup was not placed in time: D is part-way through the dendrogram, start over with the launch-per-step loop
+        fprintf(stderr, "dzn_linkage_centroid: the persistent launch ended with status %d, repeating with the step loop\n", hst[0]);
+        persist = false;
+        LCHK(hipMemcpyAsync(size, ones.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+        LCHK(hipMemcpyAsync(cid, ids.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(pdist_kernel, dim3(tiles, tiles), dim3(256), 0, s, E, n, dim, D);
+        hipLaunchKernelGGL(init_rows2_kernel, dim3(n), dim3(256), 0, s, D, n, lb, l2a, nb, n2a, exf);
+      }
+    }
+    if (persist) {
+    } else if (two_kernel) {
       hipLaunchKernelGGL(block_minima_kernel, dim3(nblk), dim3(LB_BLK), 0, s, lb, n, bmin, barg);
       for (int k = 0; k < n - 1; ++k) {
         hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, s, D, n, lb, nb, size, cid, Z, st, bmin, barg, hp_val,

@@ -623,6 +623,10 @@ def test_linkage_step_loop_equals_two_kernel_loop(built_lib, gpu, monkeypatch):
             e[7] = e[3]
             e[100] = e[3]
         Za = ops.linkage_centroid(e)                 # r6 default: the step loop with two remembered neighbours per row
+        monkeypatch.setenv("DZN_LINKAGE_PERSIST", "1")     # r6b: the same rules in ONE persistent launch (opt-in: measured slower)
+        Zd = ops.linkage_centroid(e)
+        monkeypatch.delenv("DZN_LINKAGE_PERSIST")
+        assert np.array_equal(Za, Zd), n
         monkeypatch.setenv("DZN_LINKAGE_TWO_KERNEL", "1")
         Zb = ops.linkage_centroid(e)
         monkeypatch.delenv("DZN_LINKAGE_TWO_KERNEL")
