@@ -192,6 +192,7 @@ int launch_col_scale(void* x, int x_bf16, int64_t rows, int C, int64_t ld, const
                      hipStream_t st);
 // frontend_fused.hip (DZN_PREC_F32_H2): conv0 + LN + GELU + conv1 in one kernel
 int launch_split_weights_h2_natural(const float* W, int64_t rows, int K, void* W2, float* col_scale, hipStream_t s);
+int launch_fragment_major(const void* W2, int rows, int K, void* out, hipStream_t s);   // frontend_fused.hip: conv1 planes for the producer / consumer kernel
 int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, const float* w0, const float* gamma0,
                         const float* beta0, const float* lnq, int C0, int T0, int T1, const void* W2h,
                         const float* col_scale, int N1p, float act_bound, float eps, float* out, hipStream_t st,

@@ -485,6 +485,19 @@ void finalize_seg(H* h) {
         const double lam = std::max(Aj[e * 10 + e], 0.0);
         for (int j = 0; j < 10; ++j) lq[10 + e * 10 + j] = (float)(std::sqrt(lam) * V[j * 10 + e]);
       }
+      if (k0 == 10 && C0 % 2 == 0) {
+        // behind the coefficients (from float 112 on): conv0's taps + LayerNorm affine, two channels per 24-float record
+        // [w c[10], w c+1[10], gamma c, gamma c+1, beta c, beta c+1] — what a producer wavefront of frontend_fused.hip's
+        // conv01_ws_kernel needs per channel pair, as ONE contiguous scalar load
+        const std::vector<float>& g0 = need(h, pre + ".layer_norm.weight").v;
+        const std::vector<float>& b0 = need(h, pre + ".layer_norm.bias").v;
+        lq.resize(112 + (size_t)(C0 / 2) * 24, 0.f);
+        for (int cp = 0; cp < C0 / 2; ++cp) {
+          float* r = lq.data() + 112 + (size_t)cp * 24;
+          for (int t = 0; t < 10; ++t) { r[t] = w.v[(size_t)(2 * cp) * 10 + t]; r[10 + t] = w.v[(size_t)(2 * cp + 1) * 10 + t]; }
+          r[20] = g0[2 * cp]; r[21] = g0[2 * cp + 1]; r[22] = b0[2 * cp]; r[23] = b0[2 * cp + 1];
+        }
+      }
       h->conv0_lnq = upload(h, lq);
     }
     if (c.extractor_layer_norm) {   // |LN(x)_c| <= sqrt(C - 1), |GELU(t)| <= |t|
@@ -510,10 +523,13 @@ void finalize_seg(H* h) {
     if (i == 1 && prec_is_h2(c.precision) && c.extractor_layer_norm && h->conv0_lnq && c.conv_k[0] == 10 &&
         c.conv_s[0] == 5 && k == 3 && c.conv_s[1] == 2 && h->C[0] % 64 == 0 && h->Cp[0] == h->C[0] &&
         h->Cp[1] == 160 && !getenv("DZN_NO_CONV01_FUSION")) {
-      h->conv1_W2n = dalloc<u16>(h, (int64_t)2 * h->Cp[1] * k * cip, false);
+      // two copies of the planes: [row][K/32][2][32] (phase-alternating kernel), then fragment-major (producer / consumer kernel)
+      h->conv1_W2n = dalloc<u16>(h, (int64_t)4 * h->Cp[1] * k * cip, false);
       h->conv1_wscn = dalloc<float>(h, h->Cp[1], false);
       if (launch_split_weights_h2_natural(h->conv[1].W, h->Cp[1], k * cip, h->conv1_W2n, h->conv1_wscn, nullptr) != DZN_OK)
         throw EngineError(DZN_E_HIP, "split_weights_h2_natural launch failed");
+      if (launch_fragment_major(h->conv1_W2n, h->Cp[1], k * cip, h->conv1_W2n + (int64_t)2 * h->Cp[1] * k * cip, nullptr) != DZN_OK)
+        throw EngineError(DZN_E_HIP, "fragment_major launch failed");
       HIPCHK(hipDeviceSynchronize());
     }
   }

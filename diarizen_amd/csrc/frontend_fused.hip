@@ -297,6 +297,344 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv01_fused_kernel(const F
   }
 }
 
+// ---- r6: producer / consumer wavefronts, persistent workgroups (conv01_ws_kernel) ---------------------------------------
+// conv01_fused_kernel above alternates its two phases per workgroup and relies on a second workgroup of the CU being in the
+// other phase: measured alone the VALU phase takes 11.7 ms and the MFMA phase 12.5 ms per 561-window launch, together 21.3 —
+// they overlap by chance, and BOTH are inefficient on their own (the VALU phase issues ~47 slots per activation, 14 of them LDS
+// traffic with one lane per CHANNEL: 10 broadcast sample reads and two 2-byte plane writes per frame; the MFMA phase keeps the
+// matrix pipe 36 % busy).  Here one 512-thread workgroup per CU walks over (window, tile) items, and in every step of a
+// slab-granular pipeline
+//   * wavefronts 0-3 (producers) compute conv0 + LayerNorm + GELU + split of slab s + 1 into one of two plane buffers with one
+//     lane per FRAME: the frame's 10 samples, mean and 1/std stay in registers for the whole tile, the weights of two channels
+//     at a time arrive as scalars (s_load: w0 is [C0][10], two channels are 20 consecutive floats), conv0's 10 products are
+//     summed as (even taps, odd taps) on v_pk_fma_f32, the two channels share the LayerNorm / erf polynomial as one float2
+//     (packed fp32: two results per lane and issue slot), and 8 channels leave as ONE ds_write_b128 per plane — no LDS reads,
+//     ~30 issue slots per activation;
+//   * wavefronts 4-7 (consumers) multiply slab s from the other buffer (same fragments and MFMA order as above) — on every
+//     SIMD one VALU wavefront and one MFMA wavefront, by construction, with ONE s_barrier per step;
+//   * a tile is 127 conv1 frames (255 conv0 frames + one spare = 256 lanes; row 127 of the 128-row MFMA tile is dead), and
+//     conv1's LayerNorm + GELU epilogue needs one exchange between the two wavefronts that share a row: each leaves the mean and
+//     the centred sum of squares of ITS 80 (73) channels before the step's barrier, both combine them after it (Chan et al.'s
+//     pairwise update: as stable as the two-pass form, one exchange instead of two) and finish the tile at the start of the next
+//     step, while the producers are already a slab into the next tile.
+constexpr int WS_OUT = 127;                    // conv1 frames stored per tile
+constexpr int WS_ROWS = 258;                   // plane rows: frames 0 .. 256 are read (row 256 only by the dead MFMA row), one slack
+constexpr int WS_PLANE = WS_ROWS * FF_ROW;
+constexpr int WS_LDS = 4 * WS_PLANE + (int)sizeof(float2) * 2 * 128 + (int)sizeof(float) * 112;
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) float* cfloat_ptr;
+
+// gelu_erf (common.h) on two values: the same operations per component, the multiply-adds through packed fp32 instructions
+__device__ __forceinline__ v2f gelu_erf2(v2f v) {
+  const v2f x = v * (v2f){0.70710678118654752440f, 0.70710678118654752440f};
+  const v2f ax = {fabsf(x[0]), fabsf(x[1])};
+  const v2f den = __builtin_elementwise_fma((v2f){0.3275911f, 0.3275911f}, ax, (v2f){1.0f, 1.0f});
+  const v2f t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  v2f p = __builtin_elementwise_fma((v2f){1.061405429f, 1.061405429f}, t, (v2f){-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, (v2f){1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, (v2f){-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, (v2f){0.254829592f, 0.254829592f});
+  const v2f q = (v2f){-1.4426950408889634f, -1.4426950408889634f} * ax * ax;
+  const v2f e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+  const v2f y = __builtin_elementwise_fma(-p * t, e, (v2f){1.0f, 1.0f});
+  const v2f er = {copysignf(y[0], x[0]), copysignf(y[1], x[1])};
+  return (v2f){0.5f, 0.5f} * v * ((v2f){1.0f, 1.0f} + er);
+}
+
+__global__ __launch_bounds__(512, 1) void conv01_ws_kernel(const FusedArgs a, const int B, const int ntile) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [buffer][plane][WS_ROWS][128 B], then the row statistics of the epilogue, then the LayerNorm-statistics coefficients
+  float2* red = reinterpret_cast<float2*>(smem + 4 * WS_PLANE);     // [2 wn][128 rows] (local mean, centred sum of squares)
+  float* slnq = reinterpret_cast<float*>(red + 2 * 128);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave < 4;
+  const int nitem = B * ntile;
+  const int nslab = a.C0 / 64;
+  // rows 256 / 257 of every plane are read by the dead MFMA row only, and never written: give them finite contents once
+  if (tid < 4 * (FF_ROW / 4)) {
+    const int pl = tid / (FF_ROW / 4), w = tid % (FF_ROW / 4);
+    *reinterpret_cast<unsigned*>(smem + pl * WS_PLANE + 256 * FF_ROW + 4 * w) = 0u;
+    *reinterpret_cast<unsigned*>(smem + pl * WS_PLANE + 257 * FF_ROW + 4 * w) = 0u;
+  }
+  if (tid < 110) slnq[tid] = a.lnq[tid];
+  __syncthreads();
+  int my_items = 0;
+  for (int it = blockIdx.x; it < nitem; it += gridDim.x) ++my_items;
+  const int nstep = my_items * nslab;
+
+  if (producer) {
+    // ================================ producers: lane -> conv0 frame f0 + 64 wave + lane ================================
+    const int fl = wave * 64 + lane;                 // frame inside the tile = plane row
+    const int swz = (fl >> 1) & 7;
+    float x[10], xn[10];
+    float mu = 0.f, rstd = 0.f, sc = 0.f;
+    auto fetch = [&](int item, float (&dst)[10]) {   // raw samples of this lane's frame of `item` (clamped inside the window)
+      const int b = item / ntile, tile = item - b * ntile;
+      const int f = 2 * tile * WS_OUT + fl;
+      const int fc = f < a.T0 ? f : a.T0 - 1;
+      const float* wp = a.wave + (int64_t)b * a.N + (int64_t)fc * 5;
+#pragma unroll
+      for (int t = 0; t < 10; ++t) dst[t] = wp[t];
+    };
+    if (my_items > 0) fetch(blockIdx.x, xn);
+    for (int g = 0; g <= nstep; ++g) {
+      if (g < nstep) {
+        const int k = g / nslab, slab = g - k * nslab;
+        const int item = blockIdx.x + k * gridDim.x;
+        if (slab == 0) {
+          const int b = item / ntile, tile = item - b * ntile;
+          const float wmean = a.wstats ? a.wstats[2 * b] : 0.f;
+          const float wrstd = a.wstats ? a.wstats[2 * b + 1] : 1.f;
+#pragma unroll
+          for (int t = 0; t < 10; ++t) x[t] = (xn[t] - wmean) * wrstd;
+          // LayerNorm statistics of the frame from its 10 samples (header of this file)
+          float m = 0.f, var = 0.f;
+#pragma unroll
+          for (int i = 0; i < 10; ++i) {
+            m = fmaf(slnq[i], x[i], m);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) q = fmaf(slnq[10 + i * 10 + j], x[j], q);
+            var = fmaf(q, q, var);
+          }
+          mu = m;
+          rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + a.eps);
+          sc = 2 * tile * WS_OUT + fl < a.T0 ? a.a_scale : 0.f;      // frames past the window are zero rows
+        }
+        if (slab == nslab - 1 && k + 1 < my_items) fetch(item + gridDim.x, xn);     // lands during this slab's arithmetic
+        unsigned char* pl0 = smem + (g & 1) * 2 * WS_PLANE;
+        unsigned char* pl1 = pl0 + WS_PLANE;
+        const v2f xp[5] = {{x[0], x[1]}, {x[2], x[3]}, {x[4], x[5]}, {x[6], x[7]}, {x[8], x[9]}};
+        const v2f mup = {mu, mu}, rsp = {rstd, rstd}, scp = {sc, sc};
+        for (int cg = ((a.abl & 3) == 1 ? 8 : 0); cg < 8; ++cg) {        // 8 channels -> one 16-byte slot of the row, per plane
+          u32x4 hw, lw;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = __builtin_amdgcn_readfirstlane(slab * 64 + cg * 8 + q * 2);
+            // uniform addresses in the CONSTANT address space: the weights are read-only for the launch, and only loads the
+            // compiler may treat as invariant become s_load (as plain global loads they were 20 broadcast vector loads per
+            // 8 channels into 80 registers, waited for at the top of every iteration)
+            const cfloat_ptr w = (cfloat_ptr)(uintptr_t)(a.w0 + c * 10);      // 20 scalars for the two channels
+            const cfloat_ptr gp = (cfloat_ptr)(uintptr_t)(a.gamma0 + c), bp = (cfloat_ptr)(uintptr_t)(a.beta0 + c);
+            v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+              a0 = __builtin_elementwise_fma(xp[t], (v2f){w[2 * t], w[2 * t + 1]}, a0);
+              a1 = __builtin_elementwise_fma(xp[t], (v2f){w[10 + 2 * t], w[10 + 2 * t + 1]}, a1);
+            }
+            v2f y;
+            y[0] = a0[0] + a0[1];
+            y[1] = a1[0] + a1[1];
+            y = __builtin_elementwise_fma((y - mup) * rsp, (v2f){gp[0], gp[1]}, (v2f){bp[0], bp[1]});
+            const v2f xs = gelu_erf2(y) * scp;
+            const v2h h = {(_Float16)xs[0], (_Float16)xs[1]};
+            const v2f r = xs - (v2f){(float)h[0], (float)h[1]};
+            const v2h l = {(_Float16)r[0], (_Float16)r[1]};
+            hw[q] = __builtin_bit_cast(unsigned, h);
+            lw[q] = __builtin_bit_cast(unsigned, l);
+          }
+          const int off = fl * FF_ROW + ((cg ^ swz) << 4);
+          *reinterpret_cast<u32x4*>(pl0 + off) = hw;
+          *reinterpret_cast<u32x4*>(pl1 + off) = lw;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ==================================== consumers: 2 x 2 wavefronts over the 128 x 160 tile ====================================
+  const int cw = wave - 4;
+  const int wm = cw >> 1, wn = cw & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  constexpr int MI = 4, NI = 5;
+  f32x4 acc[MI][NI];
+  const int nw = wn == 0 ? 80 : a.C1 - 80;           // channels of a row this wavefront holds (LayerNorm epilogue)
+  bool pending = false;                              // the previous tile's epilogue waits for the sibling's row statistics
+  int p_b = 0, p_t1 = 0;
+  u32x4 wfa[NI][2], wfb[NI][2];                      // W fragments of two consecutive k-steps (wfa lives across the step barrier)
+  // fragment-major copy of the planes (fragment_major_kernel, behind the natural-order copy): [kblk][n / 16][plane][16][32]
+  const u16* wbase = a.W2h + (int64_t)2 * a.N1p * 3 * a.C0 + (wn * 5) * 1024 + lr * 32 + lq * 8;
+  // finish the LayerNorm + GELU epilogue of the pending tile: the sibling's (mean, M2) were written before the last barrier
+  auto finish = [&]() {
+    float* ob = a.out + (int64_t)p_b * a.T1 * a.N1p;
+    float mean[MI], rs[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int r = wm * 64 + i * 16 + lr;
+      const float2 s0 = red[r], s1 = red[128 + r];
+      const float n0 = 80.f, n1 = (float)(a.C1 - 80), n = (float)a.C1;
+      const float dl = s1.x - s0.x;
+      mean[i] = s0.x + dl * (n1 / n);
+      const float m2 = s0.y + s1.y + dl * dl * (n0 * n1 / n);
+      rs[i] = 1.0f / sqrtf(m2 / n + a.eps);
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) {
+      const int n0 = wn * 80 + jn * 16 + lq * 4;
+      float gm[4], be[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        gm[e] = n0 + e < a.C1 ? a.gamma1[n0 + e] : 0.f;
+        be[e] = n0 + e < a.C1 ? a.beta1[n0 + e] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int rr = wm * 64 + i * 16 + lr;
+        const int t1 = p_t1 + rr;
+        if (rr >= WS_OUT || t1 >= a.T1) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = n0 + e < a.C1 ? gelu_erf((acc[i][jn][e] - mean[i]) * rs[i] * gm[e] + be[e]) : 0.f;
+          mx = fmaxf(mx, fabsf(o[e]));
+        }
+        *reinterpret_cast<float4*>(ob + (int64_t)t1 * a.N1p + n0) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    if (a.amax1) track_amax(a.amax1 + p_b, mx);
+    pending = false;
+  };
+
+  for (int g = 0; g <= nstep; ++g) {
+    if (g >= 1) {
+      const int gc = g - 1;
+      const int k = gc / nslab, slab = gc - k * nslab;
+      const int item = blockIdx.x + k * gridDim.x;
+      const int b = item / ntile, tile = item - b * ntile;
+      if (slab == 0) {
+        if (pending) finish();
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      const unsigned char* pl0 = smem + (gc & 1) * 2 * WS_PLANE;
+      const unsigned char* pl1 = pl0 + WS_PLANE;
+      // One MFMA wavefront per SIMD: nothing else fills the matrix pipe while this one waits, so the order is pinned
+      // (sched_barrier: hipcc otherwise sinks the W loads of step ks + 1 into the middle of step ks and chains dependent
+      // accumulators back to back).  W of step ks + 1 (L2 -> registers) is requested BEFORE step ks multiplies, W of the next
+      // slab's first step before this step's barrier (wfa travels across it); the A fragments of row block i + 1 are read
+      // from LDS while block i multiplies; within a block the 15 MFMAs go term-major (5 independent accumulators apart).
+      auto load_w = [&](int sl, int ks, u32x4 (&wf)[NI][2]) {
+        const int j = ks >> 1, kb = ks & 1;
+        const int kblk = j * (a.C0 / 32) + sl * 2 + kb;
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) {
+          const u16* wpn = wbase + (int64_t)kblk * (a.N1p / 16) * 1024 + jn * 1024;
+          wf[jn][0] = *reinterpret_cast<const u32x4*>(wpn);
+          wf[jn][1] = *reinterpret_cast<const u32x4*>(wpn + 512);
+        }
+      };
+      auto load_a = [&](int ks, int i, u32x4 (&af)[2]) {
+        const int j = ks >> 1, kb = ks & 1;
+        const int f = 2 * (wm * 64 + i * 16 + lr) + j;
+        const int off = f * FF_ROW + (((kb * 4 + lq) ^ ((f >> 1) & 7)) << 4);
+        af[0] = *reinterpret_cast<const u32x4*>(pl0 + off);
+        af[1] = *reinterpret_cast<const u32x4*>(pl1 + off);
+      };
+      auto mma_block = [&](int i, const u32x4 (&wf)[NI][2], const u32x4 (&af)[2]) {
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+#pragma unroll
+          for (int jn = 0; jn < NI; ++jn)
+            acc[i][jn] = mfma_np<2>(wf[jn][SplitTerms<2>::A[tt]], af[SplitTerms<2>::B[tt]], acc[i][jn]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if ((a.abl & 3) != 2) {
+        u32x4 afa[2], afb[2];
+        if (gc == 0) load_w(slab, 0, wfa);          // (later steps: requested before the previous barrier)
+        load_a(0, 0, afa);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+          u32x4 (&wc)[NI][2] = (ks & 1) ? wfb : wfa;
+          u32x4 (&wx)[NI][2] = (ks & 1) ? wfa : wfb;
+          if (ks + 1 < 6 && !(a.abl & 4)) load_w(slab, ks + 1, wx);      // (abl 4 / 8: timing probes without the W / A traffic)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            u32x4 (&ac)[2] = (i & 1) ? afb : afa;
+            u32x4 (&ax)[2] = (i & 1) ? afa : afb;
+            if (!(a.abl & 8)) {
+              if (i + 1 < MI) load_a(ks, i + 1, ax);
+              else if (ks + 1 < 6) load_a(ks + 1, 0, ax);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_block(i, wc, ac);
+          }
+        }
+        // 6 steps, MI = 4 blocks each: the buffers alternate evenly, so the next slab starts on wfa / afa again
+        if (g < nstep && !(a.abl & 4)) load_w(slab + 1 < nslab ? slab + 1 : 0, 0, wfa);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (slab == nslab - 1) {
+        // ---- the tile is complete: undo the exact power-of-two operand scales ----
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) {
+          const float4 c4 = *reinterpret_cast<const float4*>(a.col_scale + wn * 80 + jn * 16 + lq * 4);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            acc[i][jn][0] *= a.a_inv * c4.x; acc[i][jn][1] *= a.a_inv * c4.y;
+            acc[i][jn][2] *= a.a_inv * c4.z; acc[i][jn][3] *= a.a_inv * c4.w;
+          }
+        }
+        const int t1_0 = tile * WS_OUT;
+        if (a.gamma1) {
+          // local statistics of this wavefront's channels of every row: mean, then centred sum of squares (two passes over
+          // registers), left for the sibling; the tile is finished after the step's barrier (finish())
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) s1 += wn * 80 + jn * 16 + lq * 4 + e < a.C1 ? acc[i][jn][e] : 0.f;
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            const float ml = s1 / (float)nw;
+            float s2 = 0.f;
+#pragma unroll
+            for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float d = acc[i][jn][e] - ml;
+                s2 += wn * 80 + jn * 16 + lq * 4 + e < a.C1 ? d * d : 0.f;
+              }
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lq == 0) red[wn * 128 + wm * 64 + i * 16 + lr] = make_float2(ml, s2);
+          }
+          pending = true;
+          p_b = b;
+          p_t1 = t1_0;
+        } else {
+          float* ob = a.out + (int64_t)b * a.T1 * a.N1p;
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int rr = wm * 64 + i * 16 + lr;
+            const int t1 = t1_0 + rr;
+            if (rr >= WS_OUT || t1 >= a.T1) continue;
+#pragma unroll
+            for (int jn = 0; jn < NI; ++jn) {
+              const int n0 = wn * 80 + jn * 16 + lq * 4;
+              const f32x4 v = acc[i][jn];
+              *reinterpret_cast<float4*>(ob + (int64_t)t1 * a.N1p + n0) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (pending) finish();
+}
+
 // W [rows][K] fp32 -> fp16 planes [rows][K/32][2][32] in NATURAL k order (the fused kernel writes its A planes channel
 // by channel), w * 2^e_row with max |row| in [2^14, 2^15); col_scale[row] = 2^-e_row
 __global__ __launch_bounds__(256) void split_weights_h2_natural_kernel(const float* __restrict__ W, int64_t rows, int K,
@@ -320,7 +658,35 @@ __global__ __launch_bounds__(256) void split_weights_h2_natural_kernel(const flo
   }
 }
 
+// conv1's planes for conv01_ws_kernel: [K/32][N/16][2 planes][16 rows][32] — the 64 lanes of one fragment load
+// (row lr, 16-byte piece lq) read ONE contiguous KB, a wavefront's whole k-step 10 contiguous KB.  In the [row][K/32][2][32]
+// order above a fragment load touches sixteen 64-byte pieces 6 KB apart, and the consumers' W stream (40 KB per k-step and CU
+// through the vector L1) then set the pace: 15.0 ms per 561-window launch for the consumers alone against 11.3 ms with this
+// order and 8.3 ms without any W traffic (profiles/r6_conv01_ws_probe.txt).
+__global__ __launch_bounds__(256) void fragment_major_kernel(const u16* __restrict__ W2, int rows, int KB, u16* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one 16-byte piece each
+  const int64_t total = (int64_t)rows * KB * 2 * 4;
+  if (idx >= total) return;
+  const int lq = (int)(idx & 3);
+  const int lr = (int)((idx >> 2) & 15);
+  const int pl = (int)((idx >> 6) & 1);
+  const int64_t rest = idx >> 7;
+  const int nb = (int)(rest % (rows / 16)), kblk = (int)(rest / (rows / 16));
+  const int n = nb * 16 + lr;
+  const u32x4 v = *reinterpret_cast<const u32x4*>(W2 + ((int64_t)n * KB + kblk) * 64 + pl * 32 + lq * 8);
+  *reinterpret_cast<u32x4*>(out + idx * 8) = v;
+}
+
 }  // namespace
+
+// second copy of conv1's planes in fragment-major order (rows % 16 == 0), written behind the first: out = W2 + 2 rows K
+int launch_fragment_major(const void* W2, int rows, int K, void* out, hipStream_t s) {
+  if (rows <= 0 || (rows & 15) || K <= 0 || (K & 31)) return DZN_E_INVALID;
+  const int64_t total = (int64_t)rows * (K / 32) * 8;
+  hipLaunchKernelGGL(fragment_major_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, static_cast<const u16*>(W2), rows, K / 32,
+                     static_cast<u16*>(out));
+  return hipGetLastError() == hipSuccess ? DZN_OK : DZN_E_HIP;
+}
 
 int launch_split_weights_h2_natural(const float* W, int64_t rows, int K, void* W2, float* col_scale, hipStream_t s) {
   if (rows <= 0) return DZN_OK;
@@ -371,7 +737,24 @@ int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, co
   // algorithmic work: conv0 + conv1 flops; algorithmic HBM bytes: waveform in, conv1's raw output out
   const int pid = prof_begin(st, "conv01_fused", 2.0 * B * ((double)T0 * C0 * 10 + (double)T1 * 153.0 * 3 * C0),
                              B * (4.0 * N + 4.0 * (double)T1 * N1p));
-  if (pp && uf == 8) hipLaunchKernelGGL((conv01_fused_kernel<true, 8>), dim3((ntile + 1) / 2, B), dim3(512), 2 * group_lds, st, a);
+  // (r6) producer / consumer wavefronts in persistent workgroups (conv01_ws_kernel); DZN_CONV01_WS=0: the phase-alternating kernel
+  static const bool ws = !(getenv("DZN_CONV01_WS") && atoi(getenv("DZN_CONV01_WS")) == 0);
+  if (ws && !pp && (!gamma1 || (C1 > 80 && C1 <= 160))) {
+    static unsigned long long ws_mask = 0;
+    static int cus[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (first_use_on_device(ws_mask)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv01_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      cus[dev & 63] = n;
+    }
+    const int wtile = (T1 + WS_OUT - 1) / WS_OUT;
+    const int64_t items = (int64_t)B * wtile;
+    const int grid = (int)(items < cus[dev & 63] ? items : cus[dev & 63]);
+    hipLaunchKernelGGL(conv01_ws_kernel, dim3(grid), dim3(512), WS_LDS, st, a, B, wtile);
+  } else if (pp && uf == 8) hipLaunchKernelGGL((conv01_fused_kernel<true, 8>), dim3((ntile + 1) / 2, B), dim3(512), 2 * group_lds, st, a);
   else if (pp) hipLaunchKernelGGL((conv01_fused_kernel<true, 4>), dim3((ntile + 1) / 2, B), dim3(512), 2 * group_lds, st, a);
   else if (uf == 8) hipLaunchKernelGGL((conv01_fused_kernel<false, 8>), dim3(ntile, B), dim3(256), group_lds, st, a);
   else hipLaunchKernelGGL((conv01_fused_kernel<false, 4>), dim3(ntile, B), dim3(256), group_lds, st, a);
