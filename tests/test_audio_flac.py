@@ -1,10 +1,12 @@
 """Row f3 (audio ingest): the native FLAC decoder (diarizen_amd/csrc/flac.cpp, C ABI dzn_flac_info / dzn_flac_decode) behind
 diarizen_amd.audio.load_flac / load_audio.  CPU only (host code of libdzn_hip.so).
 
-No libFLAC / flac binary / FLAC file exists in this image, so the streams are made by testkit/flac_encoder.py, written from the
-same specification: parity with libFLAC is therefore UNPINNED here (stated in DESIGN.md) — what these tests hold is the bit
-stream syntax construct by construct (every subframe type, Rice method, stereo mode, header coding), the CRC-8 / CRC-16 /
-MD5 integrity checks, and exact sample equality with the WAV path on the reference's own example recording."""
+No libFLAC / flac binary exists in this image, so most streams are made by testkit/flac_encoder.py, written from the same
+specification — what those tests hold is the bit stream syntax construct by construct (every subframe type, Rice method, stereo
+mode, header coding), the CRC-8 / CRC-16 / MD5 integrity checks, and exact sample equality with the WAV path on the reference's
+own example recording.  (r6) Independent evidence: the three example files of RFC 9639, appendix D (made by libFLAC 1.3.3,
+tests/golden/flac_rfc9639_example*.flac) decode to the samples the RFC walks through, with their CRCs and STREAMINFO MD5s
+verified — verbatim + stereo, fixed predictors + Rice partitions + mid-side + metadata blocks, 8-bit LPC."""
 import os
 
 import numpy as np
@@ -134,3 +136,42 @@ def test_unknown_length_stream_of_digital_silence_and_a_lying_total(built_lib):
     lying[off:off + 8] = (v | ((1 << 36) - 1)).to_bytes(8, "big")          # total = 2^36 - 1 samples
     with pytest.raises(ValueError, match="holds at most"):
         load_flac(bytes(lying))
+
+
+# ---- r6: streams of an INDEPENDENT encoder: the example files of RFC 9639, appendix D (libFLAC 1.3.3) ----
+RFC_EXAMPLES = {
+    # D.1: one frame of one inter-channel sample, 16-bit stereo 44.1 kHz, verbatim subframes
+    1: dict(sr=44100, bits=16, samples=[[25588], [10416]]),
+    # D.2: two frames (16 + 3 samples), left/side + right/side decorrelation, fixed predictors, Rice partitions; SEEKTABLE,
+    #      VORBIS_COMMENT and PADDING blocks before the audio
+    2: dict(sr=44100, bits=16, samples=[
+        [10372, 18041, 14942, 17876, 15627, 17899, 16242, 18077, 16824, 18263, 17295, -14418, -15201, -14508, -15195, -14818,
+         -15486, -15349, -16054],
+        [6070, 10545, 8743, 10449, 9143, 10463, 9502, 10569, 9840, 10680, 10113, -8428, -8895, -8476, -8896, -8653, -9072,
+         -8958, -9410]]),
+    # D.3: 24 samples, 8-bit mono 32 kHz, one LPC subframe of order 3
+    3: dict(sr=32000, bits=8, samples=[[0, 79, 111, 78, 8, -61, -90, -68, -13, 42, 67, 53, 13, -27, -46, -38, -12, 14, 24, 19, 6, -4, -5,
+                                        0]]),
+}
+
+
+@pytest.mark.parametrize("ex", [1, 2, 3])
+def test_rfc9639_example_files_decode_to_the_documented_samples(built_lib, ex):
+    """The byte streams are the RFC's hex dumps; the decoder checks every frame's CRC-8 / CRC-16 and (load_flac) the STREAMINFO
+    MD5 of the decoded PCM — a stream made by libFLAC, not by this repo's encoder."""
+    import hashlib
+    from diarizen_amd.audio import load_flac
+    want = RFC_EXAMPLES[ex]
+    data = open(os.path.join(GOLD, f"flac_rfc9639_example{ex}.flac"), "rb").read()
+    y, sr = load_flac(data)                      # verify_md5=True: raises when the MD5 of the samples differs
+    full = float(1 << (want["bits"] - 1))
+    got = np.rint(y * full).astype(np.int64)
+    assert sr == want["sr"] and np.array_equal(got, np.asarray(want["samples"], np.int64))
+    # the MD5 field itself, over the interleaved little-endian PCM (RFC 9639 8.2)
+    pcm = np.asarray(want["samples"], np.int64).T.astype("<i2" if want["bits"] == 16 else "i1").tobytes()
+    assert hashlib.md5(pcm).digest() == data[26:42]
+    # one flipped bit inside the first frame is caught by the frame's CRC
+    bad = bytearray(data)
+    bad[-4] ^= 0x10
+    with pytest.raises(ValueError):
+        load_flac(bytes(bad))
