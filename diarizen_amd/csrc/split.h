@@ -75,6 +75,30 @@ __device__ __forceinline__ f32x4 mfma_np(const u32x4& a, const u32x4& b, f32x4 c
 }
 
 // 8 fp32 values (two float4), pre-scaled by the exact power of two s -> two fp16x8 fragments (hi, lo)
+// (r6) DZN_SPLIT_MIX: the same arithmetic on the mixed-precision FMA instructions — hi = f16(fma(x, s, 0)) and
+// lo = f16(fma(x, s, -hi)) with hi read as an fp16 operand (v_fma_mixlo_f16 / v_fma_mixhi_f16: fp32 FMA, result rounded to
+// nearest even into the low / high half of the destination) — 4 instructions per pair of values instead of the 6 hipcc picks for
+// the natural form (v_pk_mul_f32, v_cvt_pk_f16_f32, 2 v_cvt_f32_f16, v_pk_fma_f32, v_cvt_pk_f16_f32), no conversions back, no
+// packing.  x s is an exact scaling by a power of two and x s - hi is exact in fp32, so both roundings are the same single
+// roundings as before: bit-identical fragments.  (A form on plain v_mul / v_cvt / v_sub / v_pack — 12 instructions per pair,
+// none of them in the matrix pipe's way, which packed fp32 / packed converts are: profiles/r6_mfma_valu_coissue.txt — measured
+// 3.5 % SLOWER on the 128 x 128 class, this form the same time as the default (1.349 vs 1.342 ms): the loop is not bound by its
+// operand split; profiles/r6_split_forms_ab.txt.  Compile with -DDZN_SPLIT_MIX to select it.)
+#ifdef DZN_SPLIT_MIX
+__device__ __forceinline__ void split8_h2(const f32x4& u, const f32x4& v, float s, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a0 = p < 2 ? u[2 * p] : v[2 * p - 4], a1 = p < 2 ? u[2 * p + 1] : v[2 * p - 3];
+    unsigned hp, lp;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hp) : "v"(a0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hp) : "v"(a1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lp) : "v"(a0), "v"(s), "v"(hp));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lp) : "v"(a1), "v"(s), "v"(hp));
+    hi[p] = hp;
+    lo[p] = lp;
+  }
+}
+#else
 __device__ __forceinline__ void split8_h2(const f32x4& u, const f32x4& v, float s, u32x4& hi, u32x4& lo) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -90,6 +114,7 @@ __device__ __forceinline__ void split8_h2(const f32x4& u, const f32x4& v, float 
     lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
   }
 }
+#endif
 
 // DZN_PREC_F16: 8 fp32 values, pre-scaled by the power of two s -> ONE fp16x8 fragment (the leading term only)
 __device__ __forceinline__ void cvt8_h1(const f32x4& u, const f32x4& v, float s, u32x4& hi) {

@@ -37,7 +37,15 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters, int mode) {  
           for (int j = 0; j < 8; ++j) {
             if constexpr (VKIND == 0) x[j] = __builtin_elementwise_fma(x[j], m, c);                 // v_pk_fma_f32
             else if constexpr (VKIND == 1) { x[j][0] = __builtin_fmaf(x[j][0], m[0], c[0]); }      // v_fma_f32
-            else { x[j][0] = __builtin_amdgcn_exp2f(x[j][0]); }                                    // v_exp_f32 (transcendental)
+            else if constexpr (VKIND == 2) { x[j][0] = __builtin_amdgcn_exp2f(x[j][0]); }               // v_exp_f32 (transcendental)
+            else if constexpr (VKIND == 3) { x[j] = x[j] * m; }                                          // v_pk_mul_f32
+            else if constexpr (VKIND == 4) { x[j] = x[j] + c; }                                          // v_pk_add_f32
+            else if constexpr (VKIND == 5) {                                                             // v_cvt_pk_f16_f32 (+ v_cvt_f32_f16 back)
+              typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+              const h2 h = __builtin_convertvector(x[j], h2);
+              x[j][0] = (float)h[0] + x[j][1];
+            }
+            else { x[j][0] = x[j][0] * m[0]; }                                                           // v_mul_f32
           }
       }
     float s = 0.f;
@@ -66,5 +74,9 @@ int main() {
   run<0>("v_pk_fma_f32", out);
   run<1>("v_fma_f32", out);
   run<2>("v_exp_f32", out);
+  run<3>("v_pk_mul_f32", out);
+  run<4>("v_pk_add_f32", out);
+  run<5>("v_cvt_pk_f16_f32 + v_cvt_f32_f16 + v_add_f32", out);
+  run<6>("v_mul_f32", out);
   return 0;
 }
