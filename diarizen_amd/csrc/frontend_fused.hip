@@ -437,6 +437,7 @@ __global__ __launch_bounds__(512, 1) void conv01_ws_kernel(const FusedArgs a, co
             lw[q] = __builtin_bit_cast(unsigned, l);
           }
           const int off = fl * FF_ROW + ((cg ^ swz) << 4);
+          DZN_CHECK(off + 16 <= 256 * FF_ROW && slab * 64 + cg * 8 + 7 < a.C0, 0x711, off);                            // 8 channels of a frame inside its plane rows
           *reinterpret_cast<u32x4*>(pl0 + off) = hw;
           *reinterpret_cast<u32x4*>(pl1 + off) = lw;
         }
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(512, 1) void conv01_ws_kernel(const FusedArgs a, co
 #pragma unroll
         for (int jn = 0; jn < NI; ++jn) {
           const u16* wpn = wbase + (int64_t)kblk * (a.N1p / 16) * 1024 + jn * 1024;
+          DZN_CHECK(kblk < 3 * a.C0 / 32 && wn * 5 + jn < a.N1p / 16, 0x713, kblk);                      // weight fragment inside the fragment-major planes
           wf[jn][0] = *reinterpret_cast<const u32x4*>(wpn);
           wf[jn][1] = *reinterpret_cast<const u32x4*>(wpn + 512);
         }
@@ -534,6 +536,7 @@ __global__ __launch_bounds__(512, 1) void conv01_ws_kernel(const FusedArgs a, co
         const int j = ks >> 1, kb = ks & 1;
         const int f = 2 * (wm * 64 + i * 16 + lr) + j;
         const int off = f * FF_ROW + (((kb * 4 + lq) ^ ((f >> 1) & 7)) << 4);
+        DZN_CHECK(f <= 256 && off + 16 <= WS_PLANE, 0x712, f);                                          // conv1 fragment (frame 2 t + tap) inside the plane
         af[0] = *reinterpret_cast<const u32x4*>(pl0 + off);
         af[1] = *reinterpret_cast<const u32x4*>(pl1 + off);
       };

@@ -4,6 +4,6 @@
 export DZN_HIP_LIB="$(pwd)/diarizen_amd/lib/libdzn_hip_checked.so"
 mkdir -p gpurun_out
 rm -f gpurun_out/checked_build_status.txt
-python -m pytest tests/test_ops_gpu.py tests/test_seg_gpu.py tests/test_emb_gpu.py -m gpu -q -x -k "not linkage and not vbx and not cdist and not clustering" 2>&1 | tail -15 > gpurun_out/r5_checked_build.log
-cat gpurun_out/checked_build_status.txt >> gpurun_out/r5_checked_build.log
-tail -6 gpurun_out/r5_checked_build.log
+python -m pytest tests/test_ops_gpu.py tests/test_seg_gpu.py tests/test_emb_gpu.py -m gpu -q -x -k "not linkage and not vbx and not cdist and not clustering" 2>&1 | tail -15 > gpurun_out/${DZN_CHECKED_LOG:-r6_checked_build.log}
+cat gpurun_out/checked_build_status.txt >> gpurun_out/${DZN_CHECKED_LOG:-r6_checked_build.log}
+tail -6 gpurun_out/${DZN_CHECKED_LOG:-r6_checked_build.log}
