@@ -45,7 +45,22 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters, int mode) {  
               const h2 h = __builtin_convertvector(x[j], h2);
               x[j][0] = (float)h[0] + x[j][1];
             }
-            else { x[j][0] = x[j][0] * m[0]; }                                                           // v_mul_f32
+            else if constexpr (VKIND == 6) { x[j][0] = x[j][0] * m[0]; }                                 // v_mul_f32
+            else if constexpr (VKIND == 7) {                                                             // v_fma_mixlo_f16 (fp32 FMA -> f16 half)
+              unsigned h = __float_as_uint(x[j][1]);
+              asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x[j][0]), "v"(m[0]));
+              x[j][1] = __uint_as_float(h);
+            }
+            else if constexpr (VKIND == 8) {                                                             // v_cvt_f16_f32 (plain convert)
+              unsigned h;
+              asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(x[j][0]));
+              x[j][1] = __uint_as_float(h);
+            }
+            else {                                                                                       // v_pack_b32_f16
+              unsigned h;
+              asm volatile("v_pack_b32_f16 %0, %1, %2" : "=v"(h) : "v"(x[j][0]), "v"(x[j][1]));
+              x[j][1] = __uint_as_float(h);
+            }
           }
       }
     float s = 0.f;
@@ -78,5 +93,8 @@ int main() {
   run<4>("v_pk_add_f32", out);
   run<5>("v_cvt_pk_f16_f32 + v_cvt_f32_f16 + v_add_f32", out);
   run<6>("v_mul_f32", out);
+  run<7>("v_fma_mixlo_f16", out);
+  run<8>("v_cvt_f16_f32", out);
+  run<9>("v_pack_b32_f16", out);
   return 0;
 }
