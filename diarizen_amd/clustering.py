@@ -24,7 +24,10 @@ from scipy.special import logsumexp, softmax
 
 
 # --------------------------------------------------------------------------- centroid linkage
-HIP_LINKAGE_MIN = 2048   # below this scipy's host loop is faster than the launch-bound device loop
+# From this many embeddings up the device loop is used.  (r6) with two remembered neighbours per row the device overtakes scipy's host
+# loop at n ~ 300 on an idle device (3.9 vs 7.0 ms at 512, 15 vs 137 ms at 2048: profiles/r6_linkage_crossover.txt); 512 leaves a
+# factor for a device that is busy with the next recording's windows (pipeline.diarize_many).  Was 2048 (tuned on r3's loop).
+HIP_LINKAGE_MIN = 512
 
 
 def _hip_ready() -> bool:
