@@ -128,9 +128,12 @@ from testkit.synth import synth_recording  # noqa: E402
 
 
 # in-situ profiler class -> kernel symbol in the rocprofv3 tables (scripts/pmc_summary.py writes profiles/*.json)
-PMC_SYMBOLS = {"conv0_ln_gelu": "conv0_kernel", "conv01_fused": "conv01_fused_kernel",
-               "attention_relpos_f32s": "attn_split_kernel<true, 3>", "attention_relpos_f32h": "attn_split_kernel<true, 2>",
-               "attention_f32s": "attn_split_kernel<false, 3>", "attention_f32h": "attn_split_kernel<false, 2>",
+# (a tuple = candidates in order: r6's kernels first, then the ones they replaced — older committed tables carry those)
+PMC_SYMBOLS = {"conv0_ln_gelu": "conv0_kernel", "conv01_fused": ("conv01_ws_kernel", "conv01_fused_kernel"),
+               "attention_relpos_f32s": "attn_split_kernel<true, 3>",
+               "attention_relpos_f32h": ("attn_planes_kernel<true", "attn_split_kernel<true, 2>"),
+               "attention_f32s": "attn_split_kernel<false, 3>",
+               "attention_f32h": ("attn_planes_kernel<false", "attn_split_kernel<false, 2>"),
                "conv3x3_c32_f32s": "conv3x3_c32_split_kernel<3>", "conv3x3_c32_f32h": "conv3x3_c32_split_kernel<2>",
                "layernorm": "layernorm_v4_kernel<16", "row_stats": "row_stats_kernel<16>", "gate_ln_stats": "gate_stats_kernel",
                "ws_sum": "ws_sum_kernel", "stem_conv": "stem_conv_kernel", "glu_dwconv": "glu_dwconv_kernel",
@@ -258,8 +261,9 @@ def pmc_lookup(table, kernel_class: str, field: str):
                         break
             break
     else:
-        sym = PMC_SYMBOLS.get(kernel_class)
-        key = next((k for k in table if sym and k.startswith(sym)), None)
+        syms = PMC_SYMBOLS.get(kernel_class)
+        syms = (syms,) if isinstance(syms, str) else (syms or ())
+        key = next((k for sym in syms for k in table if k.startswith(sym)), None)
     return table[key].get(field) if key else None
 
 
