@@ -1072,7 +1072,7 @@ def main():
                 e["pmc_hbm_bytes_per_launch"] = pmc_lookup(traffic, p["name"], "hbm_bytes_per_launch")
                 e["pmc_mfma_util_pct"] = pmc_lookup(traffic, p["name"], "mfma_util_pct")
                 if p["name"] == "conv01_fused":
-                    e["note"] = ("conv0 + LayerNorm + GELU + conv1 fused (frontend_fused.hip): conv0's 13.2 GB / launch of "
+                    e["note"] = ("conv0 + LayerNorm + GELU + conv1 fused (frontend_fused.hip; r6: producer / consumer wavefronts in persistent workgroups, conv01_ws_kernel): conv0's 13.2 GB / launch of "
                                  "activations never reach HBM (was conv0_ln_gelu: 13.2 GB written at 2.7-2.8 TB/s = 0.34 of "
                                  "peak, then re-read by conv1); the kernel is MFMA/VALU-bound, its HBM traffic is the "
                                  "waveform in + conv1's raw output out (alg_bytes_per_launch; PMC beside it)")
