@@ -741,7 +741,8 @@ int launch_conv01_fused(const float* wave, int B, int N, const float* wstats, co
   const int pid = prof_begin(st, "conv01_fused", 2.0 * B * ((double)T0 * C0 * 10 + (double)T1 * 153.0 * 3 * C0),
                              B * (4.0 * N + 4.0 * (double)T1 * N1p));
   // (r6) producer / consumer wavefronts in persistent workgroups (conv01_ws_kernel); DZN_CONV01_WS=0: the phase-alternating kernel
-  static const bool ws = !(getenv("DZN_CONV01_WS") && atoi(getenv("DZN_CONV01_WS")) == 0);
+  const char* ws_env = getenv("DZN_CONV01_WS");      // read per call (tests compare the two kernels in one process)
+  const bool ws = !(ws_env && atoi(ws_env) == 0);
   if (ws && !pp && (!gamma1 || (C1 > 80 && C1 <= 160))) {
     static unsigned long long ws_mask = 0;
     static int cus[64];

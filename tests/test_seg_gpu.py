@@ -471,12 +471,23 @@ def test_conv01_fusion_matches_unfused(built_lib, gpu, monkeypatch):
         monkeypatch.setenv("DZN_CONV01_NO_LN", "1")
         l2, m2 = fused.segment(wave.to(gpu))
         monkeypatch.delenv("DZN_CONV01_NO_LN")
+        # (r6) the default is the producer / consumer kernel (conv01_ws_kernel: 127-frame tiles, one lane per conv0 frame, packed
+        # fp32, pairwise LayerNorm statistics in the epilogue); DZN_CONV01_WS=0 (read per call) runs the phase-alternating kernel it
+        # replaced, with and without the LayerNorm epilogue
+        monkeypatch.setenv("DZN_CONV01_WS", "0")
+        l3, m3 = fused.segment(wave.to(gpu))
+        monkeypatch.setenv("DZN_CONV01_NO_LN", "1")
+        l4, m4 = fused.segment(wave.to(gpu))
+        monkeypatch.delenv("DZN_CONV01_NO_LN")
+        monkeypatch.delenv("DZN_CONV01_WS")
         torch.cuda.synchronize()
         d = (lf - lp_).abs().max().item()
         d2 = (lf - l2).abs().max().item()
-        print(f"N={N}: max |logp fused - unfused| = {d:.2e}; LN in the epilogue vs stand-alone = {d2:.2e}")
-        assert d <= 2e-4 and d2 <= 2e-4
-        assert torch.equal(mf, mp) and torch.equal(mf, m2)
+        d3 = max((lf - l3).abs().max().item(), (l2 - l4).abs().max().item())
+        print(f"N={N}: max |logp fused - unfused| = {d:.2e}; LN in the epilogue vs stand-alone = {d2:.2e}; "
+              f"producer / consumer kernel vs the phase-alternating one = {d3:.2e}")
+        assert d <= 2e-4 and d2 <= 2e-4 and d3 <= 2e-4
+        assert torch.equal(mf, mp) and torch.equal(mf, m2) and torch.equal(mf, m3) and torch.equal(mf, m4)
         if N == 33333:
             ref = seg_model.seg_forward(sd, cfg, wave)
             assert (lf.cpu() - ref).abs().max().item() <= 1e-3
